@@ -1,0 +1,131 @@
+/*
+ * master_hip.h - C ABI of libmaster_hip.so: the MI355X (gfx950) kernels behind the Master
+ * stylization hot path  MasterStyleTransferModel.forward  (reference codes/full_model.py:214-226).
+ *
+ * The reference has no FFI of its own (it is pure PyTorch); its boundary is the nn.Module surface
+ * of codes/full_model.py.  These entry points are what a maintainer binds (ctypes stub shown in
+ * INTEGRATION.md) to replace the torch op sequences cited on each function.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer borrowed for the duration of the call; nothing is retained,
+ *     freed or allocated; work is enqueued on `stream` (a hipStream_t) and the call returns at once.
+ *   - activations are token-major ("NHWC"): a feature map [B,H,W,C] is a row-major matrix
+ *     [B*H*W, C]; images at the two ends are NCHW like the reference's.
+ *   - `dtype`: MASTER_F32 = fp32 storage + exact-fp32 MFMA (parity mode, <=1e-3 vs the CPU path);
+ *              MASTER_BF16 = bf16 storage + bf16 MFMA with fp32 accumulation (throughput mode).
+ *     Norm statistics, softmax and all epilogues are fp32 in both modes.
+ *   - return value: MASTER_OK or a negative master_status; master_last_error_string() describes
+ *     the last failure on the calling thread.  Nothing throws, nothing synchronises the device.
+ */
+#ifndef MASTER_HIP_H
+#define MASTER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* master_stream_t; /* hipStream_t */
+
+enum master_status {
+    MASTER_OK = 0,
+    MASTER_ERR_INVALID = -1,     /* bad argument / shape the kernels cannot take */
+    MASTER_ERR_UNSUPPORTED = -2, /* valid in the reference, not implemented here */
+    MASTER_ERR_LAUNCH = -3       /* hipLaunch reported an error */
+};
+
+enum master_dtype { MASTER_F32 = 0, MASTER_BF16 = 1 };
+enum master_act { MASTER_ACT_NONE = 0, MASTER_ACT_GELU = 1 /* exact erf */, MASTER_ACT_RELU = 2 };
+
+int master_version(void);
+const char* master_last_error_string(void);
+
+/* out[M,N] = r1 (.) act(a[M,K] . w[N,K]^T + bias[N]) + r2       (r1, r2, bias optional = NULL)
+ * Replaces F.linear / nn.Linear + GELU + residual adds:
+ *   style_transformer.py:114-116,156 (Wq/Wk/Wv/proj), :366,:839-841,:991 (torchvision MLP),
+ *   :390-397,:865-882,:1125 (residual adds), :1123 (Query*sigma+mu via r1=Query, r2=mu).
+ * Because a Linear acts per token, the projections run on the un-padded, un-rolled token matrix;
+ * padding/roll/window partition are index math inside master_window_attn_fwd.
+ * lda/ldo/ldr are row strides in elements (r1 and r2 share ldr).  K % 32 == 0. */
+int master_linear_fwd(const void* a, const void* w, const void* bias, const void* r1, const void* r2,
+                      void* out, int M, int N, int K, int lda, int ldo, int ldr, int act, int dtype,
+                      master_stream_t stream);
+
+/* 3x3 convolution, reflect padding 1, optional nearest x2 upsample of the input fused into the
+ * gather, optional ReLU.  x is NHWC [B,Hin,Win,Cin]; w is repacked [Cout][3][3][Cin] (= weight
+ * .permute(0,2,3,1)); out is NHWC [B,Hout,Wout,Cout] or, with out_nchw, NCHW [B,Cout,Hout,Wout]
+ * (always fp32 when out_nchw: it is the model output), Hout = Hin << upsample.
+ * Replaces nn.Upsample + nn.Conv2d(padding_mode='reflect') + nn.ReLU, decoder.py:23-55.
+ * Cin % 32 == 0. */
+int master_conv3x3_reflect_fwd(const void* x, const void* w, const void* bias, void* out, int B, int Hin,
+                               int Win, int Cin, int Cout, int upsample, int relu, int out_nchw, int dtype,
+                               master_stream_t stream);
+
+/* Windowed multi-head attention core for one or two value streams sharing one softmax.
+ * For batch b, window w, head h:   S = scale * Q K^T + bias[h] + mask(w);  P = softmax(S);
+ * out_s = P V_s  (s = 0, and 1 when v1 != NULL), written for real (non-padded) query tokens only.
+ *   q,k,v0,v1 : token matrices [B*T, *] with row strides ldq/ldk/ldv (elements); head h uses
+ *               columns [h*32, h*32+32) from the given base pointer (so a fused [M,3C] QKV buffer is
+ *               passed as three offset pointers with ld = 3C).  head_dim is 32.
+ *   src       : int32 [nW, 64]; src[w][t] = token index (h*W+w) feeding slot t of window w after
+ *               pad -> roll -> partition, -1 for a zero-padded slot, slots >= N unused.
+ *   k_pad, v0_pad, v1_pad : the key/value row a padded slot holds (= the projection bias, because
+ *               the reference pads BEFORE the Linear); [C] or, with *_pad_bstride = C, [B, C].
+ *   bias      : fp32 [heads, 64, 64]; bias[h][i][j] = rel-pos bias for query i, key j; entries with
+ *               j >= N must be -1e30 (they mask the tile padding).
+ *   region    : uint8 [nW, 64] shift-mask region id per slot, or NULL when no shift is active;
+ *               mask = -100 where region[i] != region[j].
+ * Replaces style_transformer.py:120-155 and :536-575,594 (heads split, scale, QK^T, bias, mask,
+ * softmax, AV) plus the gathers of :83-111 and scatters of :160-168. */
+int master_window_attn_fwd(const void* q, const void* k, const void* v0, const void* v1, int ldq, int ldk,
+                           int ldv, const void* k_pad, const void* v0_pad, const void* v1_pad,
+                           int k_pad_bstride, int v_pad_bstride, const float* bias, const int32_t* src,
+                           const uint8_t* region, void* out0, void* out1, int ldo, int B, int T, int heads,
+                           int nW, int N, float scale, int dtype, master_stream_t stream);
+
+/* out[m,:] = LayerNorm(x[m,:]) * gamma + beta over C channels (nn.LayerNorm, eps inside the sqrt;
+ * style_transformer.py:340-343,:390-392).  C % 4 == 0, C <= 1024. */
+int master_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* out, int M, int C,
+                         float eps, int dtype, master_stream_t stream);
+
+/* InstanceNorm2d(affine=False) on a token-major map: per (b, c) over the T tokens of image b, biased
+ * variance.  When n_pad > 0 the statistics also include n_pad copies of pad_row_in[c] (the bias-only
+ * rows of the zero-padded map, style_transformer.py:520-530) and pad_row_out[b, c] receives the
+ * normalised pad row.  Replaces style_transformer.py:468, :1056-1057, :526. */
+int master_instnorm_fwd(const void* x, void* out, const void* pad_row_in, void* pad_row_out, int B, int T,
+                        int C, int n_pad, float eps, int dtype, master_stream_t stream);
+
+/* Swin patch embedding: Conv2d(3, E, 4, stride 4) on an fp32 NCHW image, NHWC output, LayerNorm(E)
+ * fused.  w is the conv weight [E, 3, 4, 4] flattened to [E, 48].  (torchvision swin_b.features[0];
+ * reference codes/utils.py:89-93.)  H % 4 == 0, W % 4 == 0, E == 128. */
+int master_patch_embed_fwd(const float* img, const void* w, const void* bias, const void* gamma,
+                           const void* beta, void* out, int B, int H, int W, int E, float eps, int dtype,
+                           master_stream_t stream);
+
+/* Swin PatchMerging front half: gather x[0::2,0::2] | x[1::2,0::2] | x[0::2,1::2] | x[1::2,1::2]
+ * -> LayerNorm(4C).  x NHWC [B,H,W,C] -> out [B,H/2,W/2,4C].  The Linear(4C,2C,no bias) that follows
+ * is a master_linear_fwd.  H, W even. */
+int master_patch_merge_ln_fwd(const void* x, const void* gamma, const void* beta, void* out, int B, int H,
+                              int W, int C, float eps, int dtype, master_stream_t stream);
+
+/* Element type conversion fp32 <-> bf16 for n elements (weights at load, activations at the edges). */
+int master_convert(const void* src, void* dst, size_t n, int src_dtype, int dst_dtype, master_stream_t stream);
+
+/* Lightweight per-kernel timing used by bench.py's roofline leg: when enabled, every launch is
+ * bracketed by hipEvents on the launch stream.  master_prof_read() synchronises those events and
+ * returns, per kernel family, the launch count and the summed milliseconds. */
+enum master_kernel_family {
+    MASTER_K_LINEAR = 0, MASTER_K_CONV = 1, MASTER_K_ATTN = 2, MASTER_K_LAYERNORM = 3,
+    MASTER_K_INSTNORM = 4, MASTER_K_PATCH_EMBED = 5, MASTER_K_PATCH_MERGE = 6, MASTER_K_CONVERT = 7,
+    MASTER_K_COUNT = 8
+};
+int master_prof_enable(int on);
+int master_prof_reset(void);
+int master_prof_read(int family, int64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MASTER_HIP_H */

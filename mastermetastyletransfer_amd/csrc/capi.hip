@@ -1,0 +1,224 @@
+// extern "C" surface of libmaster_hip.so (include/master_hip.h): argument checks, dtype dispatch,
+// error strings and the optional per-launch event timing used by bench.py.
+#include <cstdarg>
+#include <cstdio>
+#include <mutex>
+#include <vector>
+#include "common.h"
+
+// ---- kernel launchers defined in the other translation units --------------------------------
+int gemm_f32_linear(const float*, const float*, const float*, const float*, const float*, float*, int, int, int, int,
+                    int, int, int, hipStream_t);
+int gemm_f32_conv3x3(const float*, const float*, const float*, float*, int, int, int, int, int, int, int, int,
+                     hipStream_t);
+int window_attn_f32(const float*, const float*, const float*, const float*, int, int, int, const float*, const float*,
+                    const float*, int, int, const float*, const int32_t*, const uint8_t*, float*, float*, int, int,
+                    int, int, int, int, float, hipStream_t);
+int gemm_bf16_linear(const bf16_t*, const bf16_t*, const float*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int,
+                     int, int, int, int, hipStream_t);
+int gemm_bf16_conv3x3(const bf16_t*, const bf16_t*, const float*, void*, int, int, int, int, int, int, int, int,
+                      hipStream_t);
+int window_attn_bf16(const bf16_t*, const bf16_t*, const bf16_t*, const bf16_t*, int, int, int, const bf16_t*,
+                     const bf16_t*, const bf16_t*, int, int, const float*, const int32_t*, const uint8_t*, bf16_t*,
+                     bf16_t*, int, int, int, int, int, int, float, hipStream_t);
+template <typename T> int layernorm_launch(const void*, const void*, const void*, void*, int, int, float, int, int, int, int, hipStream_t);
+template <typename T> int instnorm_launch(const void*, void*, const void*, void*, int, int, int, int, float, hipStream_t);
+template <typename T> int patch_embed_launch(const float*, const void*, const void*, const void*, const void*, void*, int, int, int, float, hipStream_t);
+int convert_launch(const void*, void*, size_t, int, int, hipStream_t);
+
+// ---- error string -------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void master_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+int master_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { master_set_error("%s: launch failed: %s", what, hipGetErrorString(e)); return MASTER_ERR_LAUNCH; }
+    return MASTER_OK;
+}
+
+// ---- profiling ----------------------------------------------------------------------------------
+namespace {
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+struct ProfRec { int family; hipEvent_t e0, e1; };
+std::vector<ProfRec> g_prof;
+int64_t g_launches[MASTER_K_COUNT];
+double g_ms[MASTER_K_COUNT];
+}  // namespace
+
+ProfScope::ProfScope(int f, hipStream_t st) : family(f), s(st), e0(nullptr), e1(nullptr), on(g_prof_on) {
+    if (!on) return;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, s);
+}
+ProfScope::~ProfScope() {
+    if (!on) return;
+    hipEventRecord(e1, s);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back({family, e0, e1});
+}
+
+static void prof_drain() {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof) {
+        hipEventSynchronize(r.e1);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { g_launches[r.family]++; g_ms[r.family] += ms; }
+        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+    }
+    g_prof.clear();
+}
+
+#define REQUIRE(cond, ...) do { if (!(cond)) { master_set_error(__VA_ARGS__); return MASTER_ERR_INVALID; } } while (0)
+static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" {
+
+int master_version(void) { return 100; }
+const char* master_last_error_string(void) { return g_err; }
+
+int master_prof_enable(int on) { prof_drain(); g_prof_on = on != 0; return MASTER_OK; }
+int master_prof_reset(void) {
+    prof_drain();
+    for (int i = 0; i < MASTER_K_COUNT; ++i) { g_launches[i] = 0; g_ms[i] = 0.0; }
+    return MASTER_OK;
+}
+int master_prof_read(int family, int64_t* launches, double* total_ms) {
+    REQUIRE(family >= 0 && family < MASTER_K_COUNT, "prof_read: bad family %d", family);
+    prof_drain();
+    if (launches) *launches = g_launches[family];
+    if (total_ms) *total_ms = g_ms[family];
+    return MASTER_OK;
+}
+
+int master_linear_fwd(const void* a, const void* w, const void* bias, const void* r1, const void* r2, void* out,
+                      int M, int N, int K, int lda, int ldo, int ldr, int act, int dtype, master_stream_t stream) {
+    REQUIRE(a && w && out, "linear: null operand");
+    REQUIRE(M > 0 && N > 0 && K > 0 && K % 32 == 0, "linear: need M,N>0 and K%%32==0 (M=%d N=%d K=%d)", M, N, K);
+    REQUIRE(lda >= K && ldo >= N && ((r1 == nullptr && r2 == nullptr) || ldr >= N), "linear: bad leading dims");
+    REQUIRE(act >= MASTER_ACT_NONE && act <= MASTER_ACT_RELU, "linear: bad act %d", act);
+    const int ea = dtype == MASTER_F32 ? 4 : 8;   // elements per 16 B
+    REQUIRE(al16(a) && al16(w) && lda % ea == 0, "linear: a/w must be 16-byte aligned, lda%%%d==0", ea);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_LINEAR, s);
+    if (dtype == MASTER_F32)
+        return gemm_f32_linear((const float*)a, (const float*)w, (const float*)bias, (const float*)r1,
+                               (const float*)r2, (float*)out, M, N, K, lda, ldo, ldr, act, s);
+    if (dtype == MASTER_BF16)
+        return gemm_bf16_linear((const bf16_t*)a, (const bf16_t*)w, (const float*)bias, (const bf16_t*)r1,
+                                (const bf16_t*)r2, (bf16_t*)out, M, N, K, lda, ldo, ldr, act, s);
+    master_set_error("linear: bad dtype %d", dtype);
+    return MASTER_ERR_INVALID;
+}
+
+int master_conv3x3_reflect_fwd(const void* x, const void* w, const void* bias, void* out, int B, int Hin, int Win,
+                               int Cin, int Cout, int upsample, int relu, int out_nchw, int dtype,
+                               master_stream_t stream) {
+    REQUIRE(x && w && out, "conv3x3: null operand");
+    REQUIRE(B > 0 && Hin > 0 && Win > 0 && Cout > 0 && Cin > 0 && Cin % 32 == 0, "conv3x3: need Cin%%32==0 (Cin=%d)", Cin);
+    REQUIRE(upsample == 0 || upsample == 1, "conv3x3: upsample must be 0/1");
+    REQUIRE((Hin << upsample) >= 2 && (Win << upsample) >= 2, "conv3x3: reflect pad needs H,W >= 2");
+    REQUIRE(al16(x) && al16(w), "conv3x3: x/w must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_CONV, s);
+    if (dtype == MASTER_F32)
+        return gemm_f32_conv3x3((const float*)x, (const float*)w, (const float*)bias, (float*)out, B, Hin, Win, Cin,
+                                Cout, upsample, relu, out_nchw, s);
+    if (dtype == MASTER_BF16)
+        return gemm_bf16_conv3x3((const bf16_t*)x, (const bf16_t*)w, (const float*)bias, out, B, Hin, Win, Cin, Cout,
+                                 upsample, relu, out_nchw, s);
+    master_set_error("conv3x3: bad dtype %d", dtype);
+    return MASTER_ERR_INVALID;
+}
+
+int master_window_attn_fwd(const void* q, const void* k, const void* v0, const void* v1, int ldq, int ldk, int ldv,
+                           const void* k_pad, const void* v0_pad, const void* v1_pad, int k_pad_bstride,
+                           int v_pad_bstride, const float* bias, const int32_t* src, const uint8_t* region, void* out0,
+                           void* out1, int ldo, int B, int T, int heads, int nW, int N, float scale, int dtype,
+                           master_stream_t stream) {
+    REQUIRE(q && k && v0 && out0 && bias && src, "window_attn: null operand");
+    REQUIRE(k_pad && v0_pad, "window_attn: pad rows are required (pass the projection bias)");
+    REQUIRE((v1 == nullptr) == (out1 == nullptr) && (v1 == nullptr || v1_pad), "window_attn: v1/out1/v1_pad must come together");
+    REQUIRE(B > 0 && T > 0 && heads > 0 && nW > 0 && N > 0 && N <= 64, "window_attn: window of %d tokens unsupported (max 64)", N);
+    const int ea = dtype == MASTER_F32 ? 4 : 8;
+    REQUIRE(ldq % ea == 0 && ldk % ea == 0 && ldv % ea == 0 && ldo % ea == 0, "window_attn: leading dims must be multiples of %d", ea);
+    REQUIRE(al16(q) && al16(k) && al16(v0) && al16(out0) && al16(k_pad) && al16(bias), "window_attn: operands must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_ATTN, s);
+    if (dtype == MASTER_F32)
+        return window_attn_f32((const float*)q, (const float*)k, (const float*)v0, (const float*)v1, ldq, ldk, ldv,
+                               (const float*)k_pad, (const float*)v0_pad, (const float*)v1_pad, k_pad_bstride,
+                               v_pad_bstride, bias, src, region, (float*)out0, (float*)out1, ldo, B, T, heads, nW, N,
+                               scale, s);
+    if (dtype == MASTER_BF16)
+        return window_attn_bf16((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v0, (const bf16_t*)v1, ldq, ldk,
+                                ldv, (const bf16_t*)k_pad, (const bf16_t*)v0_pad, (const bf16_t*)v1_pad, k_pad_bstride,
+                                v_pad_bstride, bias, src, region, (bf16_t*)out0, (bf16_t*)out1, ldo, B, T, heads, nW,
+                                N, scale, s);
+    master_set_error("window_attn: bad dtype %d", dtype);
+    return MASTER_ERR_INVALID;
+}
+
+int master_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* out, int M, int C, float eps,
+                         int dtype, master_stream_t stream) {
+    REQUIRE(x && gamma && beta && out, "layernorm: null operand");
+    REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "layernorm: need C%%4==0 and C<=1024 (C=%d)", C);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_LAYERNORM, s);
+    if (dtype == MASTER_F32) return layernorm_launch<float>(x, gamma, beta, out, M, C, eps, 0, 0, 0, C, s);
+    if (dtype == MASTER_BF16) return layernorm_launch<bf16_t>(x, gamma, beta, out, M, C, eps, 0, 0, 0, C, s);
+    master_set_error("layernorm: bad dtype %d", dtype);
+    return MASTER_ERR_INVALID;
+}
+
+int master_instnorm_fwd(const void* x, void* out, const void* pad_row_in, void* pad_row_out, int B, int T, int C,
+                        int n_pad, float eps, int dtype, master_stream_t stream) {
+    REQUIRE(x && out, "instnorm: null operand");
+    REQUIRE(B > 0 && T > 0 && C > 0 && C % 32 == 0, "instnorm: need C%%32==0 (C=%d)", C);
+    REQUIRE(n_pad >= 0 && (n_pad == 0 || pad_row_in), "instnorm: n_pad>0 needs pad_row_in");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_INSTNORM, s);
+    if (dtype == MASTER_F32) return instnorm_launch<float>(x, out, pad_row_in, pad_row_out, B, T, C, n_pad, eps, s);
+    if (dtype == MASTER_BF16) return instnorm_launch<bf16_t>(x, out, pad_row_in, pad_row_out, B, T, C, n_pad, eps, s);
+    master_set_error("instnorm: bad dtype %d", dtype);
+    return MASTER_ERR_INVALID;
+}
+
+int master_patch_embed_fwd(const float* img, const void* w, const void* bias, const void* gamma, const void* beta,
+                           void* out, int B, int H, int W, int E, float eps, int dtype, master_stream_t stream) {
+    REQUIRE(img && w && bias && gamma && beta && out, "patch_embed: null operand");
+    REQUIRE(B > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, "patch_embed: H,W must be multiples of 4");
+    if (E != 128) { master_set_error("patch_embed: embed dim %d unsupported (swin_B = 128)", E); return MASTER_ERR_UNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_PATCH_EMBED, s);
+    if (dtype == MASTER_F32) return patch_embed_launch<float>(img, w, bias, gamma, beta, out, B, H, W, eps, s);
+    if (dtype == MASTER_BF16) return patch_embed_launch<bf16_t>(img, w, bias, gamma, beta, out, B, H, W, eps, s);
+    master_set_error("patch_embed: bad dtype %d", dtype);
+    return MASTER_ERR_INVALID;
+}
+
+int master_patch_merge_ln_fwd(const void* x, const void* gamma, const void* beta, void* out, int B, int H, int W,
+                              int C, float eps, int dtype, master_stream_t stream) {
+    REQUIRE(x && gamma && beta && out, "patch_merge: null operand");
+    REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "patch_merge: H,W must be even (pad-to-even not needed for /8 images)");
+    REQUIRE(C % 4 == 0 && 4 * C <= 1024, "patch_merge: need C%%4==0 and 4C<=1024 (C=%d)", C);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_PATCH_MERGE, s);
+    const int M = B * (H / 2) * (W / 2);
+    if (dtype == MASTER_F32) return layernorm_launch<float>(x, gamma, beta, out, M, 4 * C, eps, 1, H, W, C, s);
+    if (dtype == MASTER_BF16) return layernorm_launch<bf16_t>(x, gamma, beta, out, M, 4 * C, eps, 1, H, W, C, s);
+    master_set_error("patch_merge: bad dtype %d", dtype);
+    return MASTER_ERR_INVALID;
+}
+
+int master_convert(const void* src, void* dst, size_t n, int src_dtype, int dst_dtype, master_stream_t stream) {
+    REQUIRE(src && dst, "convert: null operand");
+    REQUIRE((src_dtype == MASTER_F32 || src_dtype == MASTER_BF16) && (dst_dtype == MASTER_F32 || dst_dtype == MASTER_BF16), "convert: bad dtype");
+    if (n == 0) return MASTER_OK;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_CONVERT, s);
+    return convert_launch(src, dst, n, src_dtype, dst_dtype, s);
+}
+
+}  // extern "C"

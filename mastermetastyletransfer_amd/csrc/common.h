@@ -1,0 +1,43 @@
+// Shared device helpers for libmaster_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/master_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));   // 8 bf16 bit patterns = one MFMA A/B fragment
+typedef unsigned short bf16_t;                               // raw bf16 bits
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+// round-to-nearest-even; NaN handling left to the hardware convert the compiler picks for this cast
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // keep NaN a NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <int ACT>
+__device__ __forceinline__ float apply_act(float x) {
+    if (ACT == MASTER_ACT_GELU) return gelu_erf(x);
+    if (ACT == MASTER_ACT_RELU) return fmaxf(x, 0.0f);
+    return x;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- host side: error string + profiling hooks (defined in capi.hip) -------------------------
+void master_set_error(const char* fmt, ...);
+struct ProfScope {            // brackets one launch with events when profiling is on
+    int family; hipStream_t s; hipEvent_t e0, e1; bool on;
+    ProfScope(int family, hipStream_t s);
+    ~ProfScope();
+};
+int master_check_launch(const char* what);

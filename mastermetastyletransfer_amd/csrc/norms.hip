@@ -1,0 +1,258 @@
+// HBM-bound row kernels: LayerNorm (optionally on a 2x2 patch-merge gather), InstanceNorm over the
+// tokens of an image, Swin patch embedding (+LayerNorm), dtype conversion.  All statistics in fp32,
+// two-pass (mean, then centred sum of squares) like the CPU path.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    static __device__ __forceinline__ f32x4 load(const float* p) { return *(const f32x4*)p; }
+    static __device__ __forceinline__ void store(float* p, f32x4 v) { *(f32x4*)p = v; }
+};
+template <> struct Vec4<bf16_t> {
+    static __device__ __forceinline__ f32x4 load(const bf16_t* p) {
+        const uint2 u = *(const uint2*)p;
+        f32x4 v; v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+        v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+        return v;
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, f32x4 v) {
+        uint2 u;
+        u.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+        u.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        *(uint2*)p = u;
+    }
+};
+
+// ---- LayerNorm: one wave per output row of C <= 1024 channels; MERGE gathers the row from the four
+//      2x2 neighbours of an NHWC map (Swin PatchMerging order: (0,0) (1,0) (0,1) (1,1)). ------------
+template <typename T, bool MERGE>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, T* __restrict__ out, int M, int C,
+                                                        float eps, int H, int W, int Cin) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nch = C >> 2;                   // float4 chunks in the row
+    size_t base[4];
+    if (MERGE) {
+        const int W2 = W >> 1, H2 = H >> 1;
+        const int b = row / (H2 * W2), rem = row - b * (H2 * W2), y2 = rem / W2, x2 = rem - y2 * W2;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            base[s] = (((size_t)b * H + 2 * y2 + (s & 1)) * W + 2 * x2 + (s >> 1)) * Cin;
+    }
+    f32x4 v[4];
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (lane + 64 * i < nch) {
+            const T* src = MERGE ? x + base[c / Cin] + (c % Cin) : x + (size_t)row * C + c;
+            v[i] = Vec4<T>::load(src);
+            sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (lane + 64 * i < nch)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (lane + 64 * i < nch) {
+            const f32x4 g = *(const f32x4*)(gamma + c), bt = *(const f32x4*)(beta + c);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + bt[e];
+            Vec4<T>::store(out + (size_t)row * C + c, o);
+        }
+    }
+}
+
+// ---- InstanceNorm over tokens: block = (image b, 32-channel strip); 256 threads = 32 token groups x
+//      8 float4 channel chunks, so a wave reads 8 rows x 128 B.  Three sweeps of a 128-KB strip (L2). --
+template <typename T>
+__global__ __launch_bounds__(256) void instnorm_kernel(const T* __restrict__ x, T* __restrict__ out,
+                                                       const T* __restrict__ pad_in, T* __restrict__ pad_out, int Tn,
+                                                       int C, int n_pad, float eps) {
+    __shared__ f32x4 red[32][8];
+    const int strips = C >> 5;
+    const int b = blockIdx.x / strips, c0 = (blockIdx.x % strips) * 32;
+    const int cq = threadIdx.x & 7, tg = threadIdx.x >> 3;
+    const T* xb = x + (size_t)b * Tn * C + c0 + cq * 4;
+    T* ob = out + (size_t)b * Tn * C + c0 + cq * 4;
+    f32x4 pr = {0.f, 0.f, 0.f, 0.f};
+    if (n_pad > 0) pr = Vec4<T>::load(pad_in + c0 + cq * 4);
+    const float cnt = (float)(Tn + n_pad);
+
+    auto block_sum = [&](f32x4 v) -> f32x4 {
+        red[tg][cq] = v;
+        __syncthreads();
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 32; ++i) s += red[i][cq];
+        __syncthreads();
+        return s;
+    };
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int t = tg; t < Tn; t += 32) acc += Vec4<T>::load(xb + (size_t)t * C);
+    f32x4 mean = block_sum(acc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mean[e] = (mean[e] + (float)n_pad * pr[e]) / cnt;
+
+    acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = tg; t < Tn; t += 32) {
+        const f32x4 d = Vec4<T>::load(xb + (size_t)t * C) - mean;
+        acc += d * d;
+    }
+    f32x4 var = block_sum(acc), rstd;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float dp = pr[e] - mean[e];
+        rstd[e] = rsqrtf((var[e] + (float)n_pad * dp * dp) / cnt + eps);
+    }
+    for (int t = tg; t < Tn; t += 32)
+        Vec4<T>::store(ob + (size_t)t * C, (Vec4<T>::load(xb + (size_t)t * C) - mean) * rstd);
+    if (n_pad > 0 && pad_out && tg == 0)
+        Vec4<T>::store(pad_out + (size_t)b * C + c0 + cq * 4, (pr - mean) * rstd);
+}
+
+// ---- Swin patch embedding: Conv2d(3,128,4,4) + LayerNorm(128).  Block = 64 patches of one patch row.
+//      Thread (patch p, quarter eq) produces channels [32eq, 32eq+32) of patch p. ---------------------
+template <typename T>
+__global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, T* __restrict__ out, int H, int W,
+                                                          float eps) {
+    constexpr int E = 128, KP = 48, PSTR = 49;
+    __shared__ __attribute__((aligned(16))) float pix[64 * PSTR];
+    __shared__ __attribute__((aligned(16))) float wt[KP * E];   // [k][e]
+    const int PW = W >> 2, PH = H >> 2;
+    const int chunks = (PW + 63) / 64;
+    int bid = blockIdx.x;
+    const int pc = bid % chunks; bid /= chunks;
+    const int py = bid % PH; const int b = bid / PH;
+    const int px0 = pc * 64;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < KP * E; i += 256) {       // w[e][k] -> wt[k][e]
+        const int e = i / KP, k = i - e * KP;
+        wt[k * E + e] = w[i];
+    }
+    for (int seg = 0; seg < 12; ++seg) {            // (c, dy) image row segments, 256 contiguous pixels
+        const int c = seg >> 2, dy = seg & 3;
+        const int xx = px0 * 4 + tid;
+        if (xx < W) pix[(tid >> 2) * PSTR + c * 16 + dy * 4 + (tid & 3)] =
+            img[(((size_t)b * 3 + c) * H + py * 4 + dy) * W + xx];
+    }
+    __syncthreads();
+
+    const int p = tid >> 2, eq = tid & 3;
+    float acc[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+        acc[e] = bias[eq * 32 + e];
+    }
+    for (int k = 0; k < KP; ++k) {
+        const float a = pix[p * PSTR + k];
+        const f32x4* wr = (const f32x4*)(wt + k * E + eq * 32);
+#pragma unroll
+        for (int e4 = 0; e4 < 8; ++e4) {
+            const f32x4 wv = wr[e4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e4 * 4 + e] = fmaf(a, wv[e], acc[e4 * 4 + e]);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) s += acc[e];
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+    const float mean = s / (float)E;
+    float sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) { const float d = acc[e] - mean; sq += d * d; }
+    sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64);
+    const float rstd = rsqrtf(sq / (float)E + eps);
+    if (px0 + p < PW) {
+        T* op = out + ((((size_t)b * PH + py) * PW + px0 + p) * E) + eq * 32;
+#pragma unroll
+        for (int e4 = 0; e4 < 8; ++e4) {
+            const f32x4 g = *(const f32x4*)(gamma + eq * 32 + e4 * 4), bt = *(const f32x4*)(beta + eq * 32 + e4 * 4);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (acc[e4 * 4 + e] - mean) * rstd * g[e] + bt[e];
+            Vec4<T>::store(op + e4 * 4, o);
+        }
+    }
+}
+
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void convert_kernel(const S* __restrict__ src, D* __restrict__ dst, size_t n) {
+    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (; i + 3 < n; i += stride) Vec4<D>::store(dst + i, Vec4<S>::load(src + i));
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (size_t t = n & ~(size_t)3; t < n; ++t) {
+            float v = sizeof(S) == 4 ? ((const float*)src)[t] : bf16_to_f32(((const bf16_t*)src)[t]);
+            if (sizeof(D) == 4) ((float*)dst)[t] = v; else ((bf16_t*)dst)[t] = f32_to_bf16(v);
+        }
+}
+
+}  // namespace
+
+template <typename T>
+int layernorm_launch(const void* x, const void* g, const void* b, void* out, int M, int C, float eps, int merge, int H,
+                     int W, int Cin, hipStream_t s) {
+    const int grid = (M + 3) / 4;
+    if (merge)
+        hipLaunchKernelGGL((layernorm_kernel<T, true>), dim3(grid), dim3(256), 0, s, (const T*)x, (const float*)g,
+                           (const float*)b, (T*)out, M, C, eps, H, W, Cin);
+    else
+        hipLaunchKernelGGL((layernorm_kernel<T, false>), dim3(grid), dim3(256), 0, s, (const T*)x, (const float*)g,
+                           (const float*)b, (T*)out, M, C, eps, 0, 0, C);
+    return master_check_launch("layernorm");
+}
+template int layernorm_launch<float>(const void*, const void*, const void*, void*, int, int, float, int, int, int, int, hipStream_t);
+template int layernorm_launch<bf16_t>(const void*, const void*, const void*, void*, int, int, float, int, int, int, int, hipStream_t);
+
+template <typename T>
+int instnorm_launch(const void* x, void* out, const void* pad_in, void* pad_out, int B, int Tn, int C, int n_pad,
+                    float eps, hipStream_t s) {
+    hipLaunchKernelGGL((instnorm_kernel<T>), dim3(B * (C / 32)), dim3(256), 0, s, (const T*)x, (T*)out,
+                       (const T*)pad_in, (T*)pad_out, Tn, C, n_pad, eps);
+    return master_check_launch("instnorm");
+}
+template int instnorm_launch<float>(const void*, void*, const void*, void*, int, int, int, int, float, hipStream_t);
+template int instnorm_launch<bf16_t>(const void*, void*, const void*, void*, int, int, int, int, float, hipStream_t);
+
+template <typename T>
+int patch_embed_launch(const float* img, const void* w, const void* bias, const void* g, const void* b, void* out,
+                       int B, int H, int W, float eps, hipStream_t s) {
+    const int PW = W / 4, PH = H / 4, chunks = (PW + 63) / 64;
+    hipLaunchKernelGGL((patch_embed_kernel<T>), dim3(B * PH * chunks), dim3(256), 0, s, img, (const float*)w,
+                       (const float*)bias, (const float*)g, (const float*)b, (T*)out, H, W, eps);
+    return master_check_launch("patch_embed");
+}
+template int patch_embed_launch<float>(const float*, const void*, const void*, const void*, const void*, void*, int, int, int, float, hipStream_t);
+template int patch_embed_launch<bf16_t>(const float*, const void*, const void*, const void*, const void*, void*, int, int, int, float, hipStream_t);
+
+int convert_launch(const void* src, void* dst, size_t n, int sdt, int ddt, hipStream_t s) {
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    if (sdt == MASTER_F32 && ddt == MASTER_BF16)
+        hipLaunchKernelGGL((convert_kernel<float, bf16_t>), dim3(blocks), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, n);
+    else if (sdt == MASTER_BF16 && ddt == MASTER_F32)
+        hipLaunchKernelGGL((convert_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, n);
+    else if (sdt == MASTER_F32 && ddt == MASTER_F32)
+        hipLaunchKernelGGL((convert_kernel<float, float>), dim3(blocks), dim3(256), 0, s, (const float*)src, (float*)dst, n);
+    else
+        hipLaunchKernelGGL((convert_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
+    return master_check_launch("convert");
+}

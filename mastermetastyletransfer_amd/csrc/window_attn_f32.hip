@@ -1,0 +1,187 @@
+// Windowed attention core, fp32 parity mode: one wave per (batch, window, head), nothing in LDS.
+//
+// Swapped product S^T = K Q^T on v_mfma_f32_32x32x2_f32: the C/D map puts the QUERY on the lane
+// (col = lane&31) and the KEYS in the 16 accumulator registers (row = (reg&3) + 8*(reg>>2) + 4*half),
+// so each lane owns 32 of one query's 64 (padded) keys and its half-wave partner the other 32:
+// softmax max/sum = 31 in-lane ops + one cross-half exchange.  The probabilities never leave the
+// accumulators: for O^T = V^T P^T the accumulator tile IS the B operand (k-step <-> register), and
+// the A operand V^T[d][key] is read straight from global memory with the channel on the lane
+// (128-B coalesced rows).  Pad -> roll -> window partition (reference style_transformer.py:83-111)
+// is a per-window gather table; zero-padded slots take the projection bias as their K/V row because
+// the reference pads before the Linear.  Outputs are written back un-windowed, for real tokens only
+// (reverse partition/roll/un-pad, :160-168).
+#include "common.h"
+
+namespace {
+
+struct AttnArgs {
+    const float* q; const float* k; const float* v0; const float* v1;
+    int ldq, ldk, ldv;
+    const float* k_pad; const float* v0_pad; const float* v1_pad;
+    int k_pad_bs, v_pad_bs;
+    const float* bias;        // [heads][64][64], key >= N pre-set to -1e30
+    const int32_t* src;       // [nW][64]
+    const uint8_t* region;    // [nW][64] or null
+    float* out0; float* out1; int ldo;
+    int B, T, heads, nW, N;
+    float scale_log2e;        // head_dim^-0.5 * log2(e): softmax evaluated with exp2
+};
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <bool DUAL>
+__global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    // problem id: heads of one window are adjacent waves (same gather table, same rows of K/V in L2)
+    const int pid = blockIdx.x * 4 + wave;
+    const int total = p.B * p.nW * p.heads;
+    if (pid >= total) return;
+    const int head = pid % p.heads;
+    const int w = (pid / p.heads) % p.nW;
+    const int b = pid / (p.heads * p.nW);
+    const int32_t* src = p.src + w * 64;
+    const size_t tok0 = (size_t)b * p.T;
+    const int coff = head * 32;
+
+    // ---- Q (B operand of S^T = K Q^T) and K (A operand): lane (row r, half h) holds channels
+    //      [16h, 16h+16) of its token row; k-step s pairs channel s with channel 16+s.
+    f32x4 qv[2][4], kv[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int slot = t * 32 + r;
+        const int idx = slot < p.N ? src[slot] : -1;
+        const float* qp = p.q + (tok0 + (idx >= 0 ? idx : 0)) * p.ldq + coff + 16 * h;
+        const float* kp = idx >= 0 ? p.k + (tok0 + idx) * p.ldk + coff + 16 * h
+                                   : p.k_pad + (size_t)b * p.k_pad_bs + coff + 16 * h;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            qv[t][c] = *(const f32x4*)(qp + 4 * c);     // padded query slots: any finite row, never stored
+            kv[t][c] = *(const f32x4*)(kp + 4 * c);     // key slots >= N: masked by bias = -1e30
+        }
+    }
+
+    // ---- S^T tiles [key tile kt][query tile qt], initialised with bias (+ shift mask), pre-scaled
+    //      by log2(e) so that P = exp2(S' - max').
+    f32x16 st[2][2];
+    const float* bias = p.bias + (size_t)head * 64 * 64;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const float* brow = bias + (qt * 32 + r) * 64;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *(const f32x4*)(brow + kt * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) st[kt][qt][4 * g + e] = bv[e] * LOG2E;
+            }
+    }
+    if (p.region) {
+        const uint8_t* reg = p.region + w * 64;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const unsigned rq = reg[qt * 32 + r];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const unsigned rk4 = *(const unsigned*)(reg + kt * 32 + 8 * g + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (((rk4 >> (8 * e)) & 0xffu) != rq) st[kt][qt][4 * g + e] += -100.0f * LOG2E;
+                }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                    st[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[kt][c][e], qv[qt][c][e] * p.scale_log2e,
+                                                                      st[kt][qt], 0, 0, 0);
+
+    // ---- softmax over keys: 32 in-lane values + the partner half (lane ^ 32) ------------------
+    float inv[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float m = st[0][qt][0];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) m = fmaxf(m, st[kt][qt][e]);
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float s = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pe = exp2f(st[kt][qt][e] - m);
+                st[kt][qt][e] = pe;
+                s += pe;
+            }
+        s += __shfl_xor(s, 32, 64);
+        inv[qt] = 1.0f / s;
+    }
+
+    // ---- O^T[d][q] = sum_key V^T[d][key] P^T[key][q]; k-step (kt, reg) covers keys
+    //      kt*32 + (reg&3) + 8*(reg>>2) + 4*half, exactly the rows the accumulator register holds.
+    auto pv = [&](const float* v, const float* v_pad, float* out) {
+        f32x16 o[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[qt][e] = 0.0f;
+        const float* vpad = v_pad + (size_t)b * p.v_pad_bs + coff + r;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            float vv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int idx = key < p.N ? src[key] : -1;
+                vv[e] = key < p.N ? (idx >= 0 ? v[(tok0 + idx) * p.ldv + coff + r] : *vpad) : 0.0f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                    o[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[e], st[kt][qt][e], o[qt], 0, 0, 0);
+        }
+        // o[qt][e]: query = qt*32 + r (lane), channel d = (e&3) + 8*(e>>2) + 4*h  -> 4 x 16-B stores
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int slot = qt * 32 + r;
+            const int idx = slot < p.N ? src[slot] : -1;
+            if (idx < 0) continue;
+            float* op = out + (tok0 + idx) * p.ldo + coff + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = o[qt][4 * g + e] * inv[qt];
+                *(f32x4*)(op + 8 * g) = ov;
+            }
+        }
+    };
+    pv(p.v0, p.v0_pad, p.out0);
+    if (DUAL) pv(p.v1, p.v1_pad, p.out1);
+}
+
+}  // namespace
+
+int window_attn_f32(const float* q, const float* k, const float* v0, const float* v1, int ldq, int ldk, int ldv,
+                    const float* k_pad, const float* v0_pad, const float* v1_pad, int k_pad_bs, int v_pad_bs,
+                    const float* bias, const int32_t* src, const uint8_t* region, float* out0, float* out1, int ldo,
+                    int B, int T, int heads, int nW, int N, float scale, hipStream_t s) {
+    AttnArgs p{q, k, v0, v1, ldq, ldk, ldv, k_pad, v0_pad, v1_pad, k_pad_bs, v_pad_bs, bias, src, region,
+               out0, out1, ldo, B, T, heads, nW, N, scale * LOG2E};
+    const int total = B * nW * heads;
+    const int grid = (total + 3) / 4;
+    if (v1) hipLaunchKernelGGL(window_attn_f32_kernel<true>, dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(window_attn_f32_kernel<false>, dim3(grid), dim3(256), 0, s, p);
+    return master_check_launch("window_attn_f32");
+}

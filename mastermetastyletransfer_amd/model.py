@@ -1,0 +1,156 @@
+"""Drop-in for the reference's ``codes/full_model.py::MasterStyleTransferModel`` on MI355X.
+
+Same constructor keywords (all 37 of full_model.py:22-60), same attributes (``swin_encoder``,
+``style_transformer``, ``decoder``), same ``forward(content_image, style_image,
+transformer_layer_count=1)`` contract (fp32 NCHW in, fp32 NCHW out, full_model.py:214-226), same
+state-dict keys.  The forward enqueues only the HIP kernels of libmaster_hip.so.
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from typing import Callable, List, Optional
+
+import torch
+from torch import nn, Tensor
+
+from . import ops
+from .modules import Decoder, StyleTransformer, SwinEncoder, _HipModule, _inference_only
+
+project_absolute_path = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+_SWIN_VARIANTS = {  # embed_dim, heads of the first two stages (torchvision swin_t/s/b), depths of those stages
+    "swin_T": (96, (3, 6), (2, 2)), "swin_S": (96, (3, 6), (2, 2)), "swin_B": (128, (4, 8), (2, 2)),
+}
+
+
+def _load_swin_encoder(path: Optional[str], variant: str) -> SwinEncoder:
+    if variant not in _SWIN_VARIANTS:        # same message as codes/utils.py:71-72
+        raise ValueError("Invalid Swin Transformer variant. Please choose one of the following: swin_T, swin_S, swin_B")
+    embed, heads, depths = _SWIN_VARIANTS[variant]
+    if variant != "swin_B":
+        raise NotImplementedError(f"{variant}: head_dim-32 kernels are built for swin_B (embed 128) only")
+    enc = SwinEncoder(embed_dim=embed, depths=depths, num_heads=heads)
+    if path and os.path.exists(path):
+        # the reference pickles the whole torchvision nn.Sequential (utils.py:93-102); a plain state dict works too
+        obj = torch.load(path, map_location="cpu", weights_only=False)
+        sd = obj.state_dict() if isinstance(obj, nn.Module) else obj
+        enc.load_state_dict(sd)
+    else:
+        warnings.warn("no Swin encoder weights found at %r: the encoder keeps its random initialisation "
+                      "(the reference would download ImageNet weights through torchvision; there is no network here)" % (path,))
+    return enc
+
+
+class MasterStyleTransferModel(nn.Module):
+    def __init__(self,
+                 project_absolute_path: str = project_absolute_path,
+                 swin_model_relative_path: str = None,
+                 swin_variant: str = "swin_B",
+                 style_encoder_dim: int = 256,
+                 style_decoder_dim: int = 256,
+                 style_encoder_num_heads: int = 8,
+                 style_decoder_num_heads: int = 8,
+                 style_encoder_window_size: List[int] = [8, 8],
+                 style_decoder_window_size: List[int] = [8, 8],
+                 style_encoder_shift_size: List[int] = [4, 4],
+                 style_decoder_shift_size: List[int] = [4, 4],
+                 style_encoder_mlp_ratio: float = 4.0,
+                 style_decoder_mlp_ratio: float = 4.0,
+                 style_encoder_dropout: float = 0.0,
+                 style_decoder_dropout: float = 0.0,
+                 style_encoder_attention_dropout: float = 0.0,
+                 style_decoder_attention_dropout: float = 0.0,
+                 style_encoder_qkv_bias: bool = True,
+                 style_decoder_qkv_bias: bool = True,
+                 style_encoder_proj_bias: bool = True,
+                 style_decoder_proj_bias: bool = True,
+                 style_encoder_stochastic_depth_prob: float = 0.1,
+                 style_decoder_stochastic_depth_prob: float = 0.1,
+                 style_encoder_norm_layer: Callable[..., nn.Module] = None,
+                 style_decoder_norm_layer: Callable[..., nn.Module] = nn.LayerNorm,
+                 style_encoder_MLP_activation_layer: Optional[Callable[..., nn.Module]] = nn.GELU,
+                 style_decoder_MLP_activation_layer: Optional[Callable[..., nn.Module]] = nn.GELU,
+                 style_encoder_if_use_processed_Key_in_Scale_and_Shift_calculation: bool = True,
+                 style_decoder_use_instance_norm_with_affine: bool = False,
+                 style_decoder_use_regular_MHA_instead_of_Swin_at_the_end: bool = False,
+                 style_decoder_use_Key_instance_norm_after_linear_transformation: bool = True,
+                 style_decoder_exclude_MLP_after_Fcs_self_MHA: bool = False,
+                 style_transformer_load_pretrained_weights: bool = False,
+                 style_transformer_pretrained_weights_path: str = None,
+                 decoder_initializer: str = "kaiming_normal_",
+                 direct_pretrained_style_transformer_path: str = '',
+                 direct_pretrained_decoder_path: str = '',
+                 compute_dtype: torch.dtype = torch.float32):
+        super().__init__()
+        for k, v in list(locals().items()):          # the reference mirrors every ctor argument as an attribute
+            if k.startswith(("style_", "decoder_initializer", "direct_pretrained")):
+                setattr(self, k, v)
+
+        swin_path = None
+        if swin_model_relative_path is not None:
+            swin_path = os.path.join(project_absolute_path, swin_model_relative_path)
+        else:
+            swin_path = os.path.join(project_absolute_path, "models", f"{swin_variant}_first_2_stages.pt")
+        self.swin_encoder = _load_swin_encoder(swin_path, swin_variant)
+
+        self.style_transformer = StyleTransformer(
+            encoder_dim=style_encoder_dim, decoder_dim=style_decoder_dim,
+            encoder_num_heads=style_encoder_num_heads, decoder_num_heads=style_decoder_num_heads,
+            encoder_window_size=style_encoder_window_size, decoder_window_size=style_decoder_window_size,
+            encoder_shift_size=style_encoder_shift_size, decoder_shift_size=style_decoder_shift_size,
+            encoder_mlp_ratio=style_encoder_mlp_ratio, decoder_mlp_ratio=style_decoder_mlp_ratio,
+            encoder_dropout=style_encoder_dropout, decoder_dropout=style_decoder_dropout,
+            encoder_attention_dropout=style_encoder_attention_dropout, decoder_attention_dropout=style_decoder_attention_dropout,
+            encoder_qkv_bias=style_encoder_qkv_bias, decoder_qkv_bias=style_decoder_qkv_bias,
+            encoder_proj_bias=style_encoder_proj_bias, decoder_proj_bias=style_decoder_proj_bias,
+            encoder_stochastic_depth_prob=style_encoder_stochastic_depth_prob,
+            decoder_stochastic_depth_prob=style_decoder_stochastic_depth_prob,
+            encoder_norm_layer=style_encoder_norm_layer, decoder_norm_layer=style_decoder_norm_layer,
+            encoder_MLP_activation_layer=style_encoder_MLP_activation_layer,
+            decoder_MLP_activation_layer=style_decoder_MLP_activation_layer,
+            encoder_if_use_processed_Key_in_Scale_and_Shift_calculation=style_encoder_if_use_processed_Key_in_Scale_and_Shift_calculation,
+            decoder_use_instance_norm_with_affine=style_decoder_use_instance_norm_with_affine,
+            decoder_use_regular_MHA_instead_of_Swin_at_the_end=style_decoder_use_regular_MHA_instead_of_Swin_at_the_end,
+            decoder_use_Key_instance_norm_after_linear_transformation=style_decoder_use_Key_instance_norm_after_linear_transformation,
+            decoder_exclude_MLP_after_Fcs_self_MHA=style_decoder_exclude_MLP_after_Fcs_self_MHA)
+        self.decoder = Decoder(channel_dim=style_decoder_dim, initializer=decoder_initializer)
+
+        if style_transformer_load_pretrained_weights and not direct_pretrained_style_transformer_path:
+            self.load_pretained_weights_to_style_transformer(style_transformer_pretrained_weights_path)
+        if direct_pretrained_style_transformer_path != '':           # full_model.py:147-150
+            self.style_transformer.load_state_dict(torch.load(direct_pretrained_style_transformer_path, map_location="cpu"))
+        if direct_pretrained_decoder_path != '':                     # full_model.py:152-155
+            self.decoder.load_state_dict(torch.load(direct_pretrained_decoder_path, map_location="cpu"))
+        self.set_compute_dtype(compute_dtype)
+
+    def load_pretained_weights_to_style_transformer(self, pretrained_weights_path: str):
+        if pretrained_weights_path is None:                          # full_model.py:160-161
+            raise ValueError("Please provide the path of the pretrained weights")
+        raise NotImplementedError(
+            "remapping an MS-Swin block checkpoint into the StyleTransformer (reference "
+            "codes/load_pretrained_weights_to_style_transformer.py) is init-time host code outside the hot path; "
+            "load a StyleTransformer state dict through direct_pretrained_style_transformer_path instead")
+
+    def set_compute_dtype(self, dtype: torch.dtype) -> "MasterStyleTransferModel":
+        """torch.float32: exact-fp32 matrix cores, parity mode.  torch.bfloat16: bf16 MFMA, throughput mode."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute_dtype must be torch.float32 or torch.bfloat16")
+        self.compute_dtype = dtype
+        for m in self.modules():
+            if isinstance(m, (_HipModule, SwinEncoder)):
+                m.compute_dtype = dtype
+        return self
+
+    def forward(self, content_image: Tensor, style_image: Tensor, transformer_layer_count: int = 1) -> Tensor:
+        _inference_only(self)
+        if content_image.shape != style_image.shape:
+            raise ValueError("content and style batches must have the same shape")
+        B = content_image.shape[0]
+        # the two encoder passes of full_model.py:219-220 are independent -> one batch of 2B images
+        x, _, h, w = self.swin_encoder.run(torch.cat([content_image, style_image], dim=0))
+        fc, fs = x[: B * h * w], x[B * h * w:]
+        fcs = self.style_transformer.run(fc, fs, transformer_layer_count, B, h, w)
+        # the reference permutes NHWC->NCHW here (:222); the decoder kernels read NHWC directly and the
+        # last convolution writes the NCHW image
+        return self.decoder.run_nhwc(fcs.view(B, h, w, -1))

@@ -1,0 +1,631 @@
+"""Host-side mirror of the reference's module tree for the stylization path.
+
+Same class names, constructor arguments, sub-module names and state-dict keys as
+codes/style_transformer.py, codes/decoder.py and torchvision's swin_b.features[:4], so checkpoints
+written by the reference's trainers load unchanged.  The modules only HOLD
+parameters; every forward enqueues hand-written HIP kernels through the C ABI (ops.py).  There is no
+torch-op fallback: CPU tensors raise.
+
+Layout: activations are token-major [B*H*W, C] matrices in the compute dtype (fp32 parity mode, or
+bf16 throughput mode); the public forwards take/return the reference's [B,H,W,C] (or NCHW) fp32.
+Linear layers run on the un-padded token matrix; pad/roll/window-partition are index tables consumed
+by the attention kernel, and a zero-padded slot's key/value row is the projection bias.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn, Tensor
+
+from . import ops
+from .window_plan import relative_position_index, window_plan
+
+HEAD_DIM = 32
+EPS = 1e-5
+
+
+def _inference_only(m: nn.Module):
+    if m.training:
+        raise NotImplementedError(
+            "train-mode forward (StochasticDepth row masks, backward) is not on the HIP path yet "
+            "(SURVEY.md section 8f item 1); call .eval()")
+
+
+class _HipModule(nn.Module):
+    """nn.Module with a cache of tensors derived from parameters (fused / repacked / bf16 copies)."""
+    compute_dtype = torch.float32
+
+    def _derived(self, name: str, srcs: Sequence[Tensor], build: Callable[[], Tensor]) -> Tensor:
+        cache = self.__dict__.setdefault("_derived_cache", {})
+        key = tuple((s.data_ptr(), s._version, s.dtype, str(s.device)) for s in srcs) + (self.compute_dtype,)
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, build())
+            cache[name] = hit
+        return hit[1]
+
+    def _w(self, name: str, *params: Tensor) -> Tensor:
+        """weight(s) concatenated along dim 0, contiguous, in the compute dtype"""
+        def build():
+            w = params[0] if len(params) == 1 else torch.cat(list(params), dim=0)
+            return ops.convert(w.detach().contiguous(), self.compute_dtype)
+        return self._derived("w:" + name, params, build)
+
+    def _b(self, name: str, *params: Tensor) -> Tensor:
+        """bias(es) concatenated, fp32 (GEMM epilogues are fp32 in both modes)"""
+        def build():
+            b = params[0] if len(params) == 1 else torch.cat(list(params), dim=0)
+            return b.detach().float().contiguous()
+        return self._derived("b:" + name, params, build)
+
+    def _row(self, name: str, param: Tensor) -> Tensor:
+        """a bias used as the K/V row of zero-padded window slots: compute dtype"""
+        return self._derived("row:" + name, [param], lambda: ops.convert(param.detach().contiguous(), self.compute_dtype))
+
+
+def _tokens(x: Tensor, dtype) -> Tensor:
+    """[B,H,W,C] fp32 -> [B*H*W, C] in the compute dtype"""
+    B, H, W, C = x.shape
+    return ops.convert(x.reshape(B * H * W, C).contiguous(), dtype)
+
+
+def _image(x2d: Tensor, B: int, H: int, W: int) -> Tensor:
+    return ops.convert(x2d, torch.float32).view(B, H, W, -1)
+
+
+def _make_mlp(dim: int, hidden: int, dropout: float) -> nn.Sequential:
+    """same children/keys as torchvision.ops.MLP: 0 Linear, 1 GELU, 2 Dropout, 3 Linear, 4 Dropout"""
+    return nn.Sequential(nn.Linear(dim, hidden), nn.GELU(), nn.Dropout(dropout), nn.Linear(hidden, dim), nn.Dropout(dropout))
+
+
+def _init_mlp(mlp: nn.Sequential):
+    for m in mlp.modules():                      # reference style_transformer.py:368-372
+        if isinstance(m, nn.Linear):
+            nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.normal_(m.bias, std=1e-6)
+
+
+def _mlp_fwd(owner: _HipModule, name: str, mlp: nn.Sequential, x: Tensor, residual: Optional[Tensor]) -> Tensor:
+    """residual + fc2(gelu(fc1(x)))   (torchvision MLP, call sites style_transformer.py:366,839-841,991)"""
+    h = ops.linear(x, owner._w(name + ".0", mlp[0].weight), owner._b(name + ".0", mlp[0].bias), act=ops.ACT_GELU)
+    return ops.linear(h, owner._w(name + ".3", mlp[3].weight), owner._b(name + ".3", mlp[3].bias), r2=residual)
+
+
+def _check_arch(dropout, attention_dropout, qkv_bias, proj_bias, act_layer, dim, heads):
+    if dropout != 0.0 or attention_dropout != 0.0:
+        raise NotImplementedError("dropout > 0 is not implemented on the HIP path (reference default 0.0)")
+    if not (qkv_bias and proj_bias):
+        raise NotImplementedError("bias-free projections are not implemented on the HIP path (reference default True)")
+    if act_layer is not nn.GELU:
+        raise NotImplementedError("only nn.GELU MLP activation is implemented on the HIP path (reference default)")
+    if dim % heads != 0 or dim // heads != HEAD_DIM:
+        raise NotImplementedError(f"head_dim must be {HEAD_DIM} (dim {dim}, heads {heads}); reference default is 256/8")
+
+
+class _WindowAttentionBase(_HipModule):
+    """relative-position table/index + window geometry shared by the three attention variants"""
+
+    def _init_rel_pos(self, num_heads: int):
+        ws = self.window_size
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * ws[0] - 1) * (2 * ws[1] - 1), num_heads))
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)        # style_transformer.py:220-225
+        self.register_buffer("relative_position_index", relative_position_index(ws))
+
+    def _bias64(self) -> Tensor:
+        """fp32 [heads,64,64] bias tile; key slots >= N hold -1e30 (they mask the tile padding)"""
+        def build():
+            N = self.window_size[0] * self.window_size[1]
+            t = self.relative_position_bias_table.detach().float()
+            b = t[self.relative_position_index].view(N, N, -1).permute(2, 0, 1)
+            out = torch.zeros((b.shape[0], 64, 64), dtype=torch.float32, device=t.device)
+            out[:, :, N:] = -1e30
+            out[:, :N, :N] = b
+            return out.contiguous()
+        return self._derived("bias64", [self.relative_position_bias_table, self.relative_position_index], build)
+
+    def _core(self, q, k, vs, k_pad, v_pads, B, H, W):
+        plan = window_plan(H, W, self.window_size, self.shift_size, q.device)
+        v1 = vs[1] if len(vs) > 1 else None
+        o0, o1 = ops.window_attn(q, k, vs[0], v1, k_pad, v_pads[0], v_pads[1] if v1 is not None else None,
+                                 self._bias64(), plan.src, plan.region, B, H * W, self.num_heads, plan.nW, plan.N,
+                                 HEAD_DIM ** -0.5)
+        return [o0] if v1 is None else [o0, o1]
+
+
+class ShiftedWindowAttention(_WindowAttentionBase):
+    """Reference codes/style_transformer.py:175-292: window attention whose Q, K, V come from three inputs."""
+
+    def __init__(self, dim: int, num_heads: int, window_size: List[int], shift_size: List[int], dropout: float = 0.0,
+                 attention_dropout: float = 0.0, qkv_bias: bool = True, proj_bias: bool = True):
+        super().__init__()
+        if len(window_size) != 2 or len(shift_size) != 2:
+            raise ValueError("window_size and shift_size must be of length 2")
+        _check_arch(dropout, attention_dropout, qkv_bias, proj_bias, nn.GELU, dim, num_heads)
+        self.window_size, self.shift_size, self.num_heads = list(window_size), list(shift_size), num_heads
+        self.attention_dropout, self.dropout = attention_dropout, dropout
+        self.Wq = nn.Linear(dim, dim, bias=qkv_bias)
+        self.Wk = nn.Linear(dim, dim, bias=qkv_bias)
+        self.Wv = nn.Linear(dim, dim, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim, bias=proj_bias)
+        self._init_rel_pos(num_heads)
+
+    def attend(self, xq: Tensor, xk: Tensor, xvs: Sequence[Tensor], residuals: Sequence[Optional[Tensor]],
+               B: int, H: int, W: int) -> List[Tensor]:
+        """token-matrix form: returns [residual_i + proj(attn(q, k, v_i))]; identical inputs (same tensor
+        object) share their projection, and identical value streams share everything."""
+        C = xq.shape[1]
+        if xq is xk and all(v is xq for v in xvs):
+            qkv = ops.linear(xq, self._w("qkv", self.Wq.weight, self.Wk.weight, self.Wv.weight),
+                             self._b("qkv", self.Wq.bias, self.Wk.bias, self.Wv.bias))
+            q, k, vs = qkv[:, :C], qkv[:, C:2 * C], [qkv[:, 2 * C:]]
+            uniq = [0] * len(xvs)
+        else:
+            if xq is xk:
+                qk = ops.linear(xq, self._w("qk", self.Wq.weight, self.Wk.weight), self._b("qk", self.Wq.bias, self.Wk.bias))
+                q, k = qk[:, :C], qk[:, C:]
+            else:
+                q = ops.linear(xq, self._w("q", self.Wq.weight), self._b("q", self.Wq.bias))
+                k = ops.linear(xk, self._w("k", self.Wk.weight), self._b("k", self.Wk.bias))
+            vs, uniq, seen = [], [], []
+            for v in xvs:
+                for i, s in enumerate(seen):
+                    if s is v:
+                        uniq.append(i)
+                        break
+                else:
+                    seen.append(v)
+                    uniq.append(len(vs))
+                    vs.append(ops.linear(v, self._w("v", self.Wv.weight), self._b("v", self.Wv.bias)))
+        if len(vs) > 2:
+            raise NotImplementedError("at most two value streams per attention call")
+        kp, vp = self._row("k", self.Wk.bias), self._row("v", self.Wv.bias)
+        cores = self._core(q, k, vs, kp, [vp, vp], B, H, W)
+        pw, pb = self._w("proj", self.proj.weight), self._b("proj", self.proj.bias)
+        outs, done = [], {}
+        for i, res in zip(uniq, residuals):
+            key = (i, None if res is None else id(res))
+            if key not in done:
+                done[key] = ops.linear(cores[i], pw, pb, r2=res)
+            outs.append(done[key])
+        return outs
+
+    def forward(self, input_q: Tensor, input_k: Tensor, input_v: Tensor) -> Tensor:
+        _inference_only(self)
+        B, H, W, C = input_q.shape
+        cache: Dict[int, Tensor] = {}
+
+        def tok(t):
+            if id(t) not in cache:
+                cache[id(t)] = _tokens(t, self.compute_dtype)
+            return cache[id(t)]
+        out = self.attend(tok(input_q), tok(input_k), [tok(input_v)], [None], B, H, W)[0]
+        return _image(out, B, H, W)
+
+
+class StyleSwinTransformerBlock(_HipModule):
+    """Reference codes/style_transformer.py:303-398."""
+
+    def __init__(self, dim: int, num_heads: int, window_size: List[int] = [8, 8], shift_size: List[int] = [4, 4],
+                 dropout: float = 0.0, attention_dropout: float = 0.0, qkv_bias: bool = True, proj_bias: bool = True,
+                 mlp_ratio: float = 4.0, stochastic_depth_prob: float = 0.0,
+                 norm_layer: Optional[Callable[..., nn.Module]] = nn.LayerNorm,
+                 MLP_activation_layer: Optional[Callable[..., nn.Module]] = nn.GELU, exclude_MLP_after: bool = False):
+        super().__init__()
+        if norm_layer is not None and norm_layer is not nn.LayerNorm:
+            raise NotImplementedError("only nn.LayerNorm / None norm layers are implemented on the HIP path")
+        _check_arch(dropout, attention_dropout, qkv_bias, proj_bias, MLP_activation_layer, dim, num_heads)
+        self.exclude_MLP_after = exclude_MLP_after
+        self.use_norm = norm_layer is not None
+        if self.use_norm:
+            self.norm1 = nn.LayerNorm(dim)
+            if not exclude_MLP_after:
+                self.norm2 = nn.LayerNorm(dim)
+        self.attn = ShiftedWindowAttention(dim, num_heads, window_size, shift_size, dropout, attention_dropout,
+                                           qkv_bias, proj_bias)
+        self.stochastic_depth_prob = stochastic_depth_prob       # identity in eval mode (torchvision StochasticDepth)
+        if not exclude_MLP_after:
+            self.mlp = _make_mlp(dim, int(dim * mlp_ratio), dropout)
+            _init_mlp(self.mlp)
+
+    def _ln(self, which: str, x: Tensor) -> Tensor:
+        n = getattr(self, which)
+        return ops.layernorm(x, self._b(which + ".w", n.weight), self._b(which + ".b", n.bias), n.eps)
+
+    def run(self, xq: Tensor, xk: Tensor, xvs: Sequence[Tensor], residuals: Sequence[Tensor], B, H, W) -> List[Tensor]:
+        """token-matrix form for one q/k pair and one or two value streams (shared softmax)"""
+        if self.use_norm:
+            memo: List[Tuple[Tensor, Tensor]] = []
+
+            def ln(t):
+                for s, o in memo:
+                    if s is t:
+                        return o
+                o = self._ln("norm1", t)
+                memo.append((t, o))
+                return o
+            xq, xk, xvs = ln(xq), ln(xk), [ln(v) for v in xvs]
+        outs = self.attn.attend(xq, xk, xvs, residuals, B, H, W)
+        if not self.exclude_MLP_after:
+            outs = [_mlp_fwd(self, "mlp", self.mlp, self._ln("norm2", o) if self.use_norm else o, o) for o in outs]
+        return outs
+
+    def forward(self, input_q: Tensor, input_k: Tensor, input_v: Tensor, calculating_Key_in_encoder: bool = None) -> Tensor:
+        _inference_only(self)
+        B, H, W, C = input_q.shape
+        cache: Dict[int, Tensor] = {}
+
+        def tok(t):
+            if id(t) not in cache:
+                cache[id(t)] = _tokens(t, self.compute_dtype)
+            return cache[id(t)]
+        # residual source, style_transformer.py:383-386
+        res = tok(input_q) if (calculating_Key_in_encoder is True or not self.exclude_MLP_after) else tok(input_v)
+        return _image(self.run(tok(input_q), tok(input_k), [tok(input_v)], [res], B, H, W)[0], B, H, W)
+
+
+class ShiftedWindowAttention_for_decoder_last_MHA(_WindowAttentionBase):
+    """Reference codes/style_transformer.py:414-764: sigma/mu cross attention (un-projected, instance-
+    normalised Query; Key instance-normalised after Wk over the zero-padded map; two value streams, one
+    softmax, shared proj)."""
+
+    def __init__(self, dim: int, num_heads: int, window_size: List[int], shift_size: List[int],
+                 instance_norm_q: Optional[nn.Module] = None, instance_norm_k: Optional[nn.Module] = None,
+                 dropout: float = 0.0, attention_dropout: float = 0.0, qkv_bias: bool = True, proj_bias: bool = True,
+                 use_q_proj: bool = False, use_Key_instance_norm_after_linear_transformation: bool = True):
+        super().__init__()
+        if len(window_size) != 2 or len(shift_size) != 2:
+            raise ValueError("window_size and shift_size must be of length 2")
+        _check_arch(dropout, attention_dropout, qkv_bias, proj_bias, nn.GELU, dim, num_heads)
+        if use_q_proj:
+            raise NotImplementedError("use_q_proj=True is not implemented on the HIP path (the reference never enables it)")
+        for n in (instance_norm_q, instance_norm_k):
+            if n is not None and getattr(n, "affine", False):
+                raise NotImplementedError("affine InstanceNorm is not implemented on the HIP path (reference default False)")
+        self.window_size, self.shift_size, self.num_heads = list(window_size), list(shift_size), num_heads
+        self.use_q_proj = use_q_proj
+        self.use_Key_instance_norm_after_linear_transformation = use_Key_instance_norm_after_linear_transformation
+        self.Wk = nn.Linear(dim, dim, bias=qkv_bias)
+        self.Wv_scale = nn.Linear(dim, dim, bias=qkv_bias)
+        self.Wv_shift = nn.Linear(dim, dim, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim, bias=proj_bias)
+        self._init_rel_pos(num_heads)
+
+    def sigma_mu(self, xq: Tensor, xk: Tensor, xs: Tensor, xsh: Tensor, B: int, H: int, W: int,
+                 fuse_query: Optional[Tensor] = None):
+        """token-matrix form.  Returns (sigma, mu), or Query*sigma+mu when fuse_query is given
+        (style_transformer.py:1123 folded into the second proj's epilogue)."""
+        T = H * W
+        q, _ = ops.instnorm(xq, B, T)                                               # :468
+        if not self.use_Key_instance_norm_after_linear_transformation:
+            xk, _ = ops.instnorm(xk, B, T)                                          # :470-472
+        k = ops.linear(xk, self._w("k", self.Wk.weight), self._b("k", self.Wk.bias))
+        k_pad = self._row("k", self.Wk.bias)
+        if self.use_Key_instance_norm_after_linear_transformation:
+            # :520-530  statistics over the zero-padded pH x pW map: its padded slots hold Wk.bias
+            plan = window_plan(H, W, self.window_size, self.shift_size, xq.device)
+            k, k_pad_b = ops.instnorm(k, B, T, pad_row=k_pad, n_pad=plan.n_pad)
+            if k_pad_b is not None:
+                k_pad = k_pad_b
+        vs = ops.linear(xs, self._w("vs", self.Wv_scale.weight), self._b("vs", self.Wv_scale.bias))
+        vsh = ops.linear(xsh, self._w("vsh", self.Wv_shift.weight), self._b("vsh", self.Wv_shift.bias))
+        o_s, o_sh = self._core(q, k, [vs, vsh], k_pad, [self._row("vs", self.Wv_scale.bias), self._row("vsh", self.Wv_shift.bias)], B, H, W)
+        pw, pb = self._w("proj", self.proj.weight), self._b("proj", self.proj.bias)
+        mu = ops.linear(o_sh, pw, pb)                                               # :594-595
+        if fuse_query is not None:
+            return ops.linear(o_s, pw, pb, r1=fuse_query, r2=mu)                    # Query * sigma + mu
+        return ops.linear(o_s, pw, pb), mu                                          # :575-576
+
+    def forward(self, input_q: Tensor, input_k: Tensor, input_v_scale: Tensor, input_v_shift: Tensor):
+        _inference_only(self)
+        B, H, W, C = input_q.shape
+        dt = self.compute_dtype
+        s, m = self.sigma_mu(_tokens(input_q, dt), _tokens(input_k, dt), _tokens(input_v_scale, dt),
+                             _tokens(input_v_shift, dt), B, H, W)
+        return _image(s, B, H, W), _image(m, B, H, W)
+
+
+class StyleEncoder(_HipModule):
+    """Reference codes/style_transformer.py:777-912."""
+
+    def __init__(self, encoder_dim: int, encoder_num_heads: int, encoder_window_size: List[int],
+                 encoder_shift_size: List[int], encoder_mlp_ratio: float = 4.0, encoder_dropout: float = 0.0,
+                 encoder_attention_dropout: float = 0.0, encoder_qkv_bias: bool = True, encoder_proj_bias: bool = True,
+                 encoder_stochastic_depth_prob: float = 0.1, encoder_norm_layer: Callable[..., nn.Module] = None,
+                 encoder_MLP_activation_layer: Optional[Callable[..., nn.Module]] = nn.GELU,
+                 encoder_if_use_processed_Key_in_Scale_and_Shift_calculation: bool = True):
+        super().__init__()
+        self.if_use_processed_Key_in_Scale_and_Shift_calculation = encoder_if_use_processed_Key_in_Scale_and_Shift_calculation
+        self.encoder_stochastic_depth_prob = encoder_stochastic_depth_prob
+        self.shared_MHA_without_MLP = StyleSwinTransformerBlock(
+            dim=encoder_dim, num_heads=encoder_num_heads, window_size=encoder_window_size, shift_size=encoder_shift_size,
+            dropout=encoder_dropout, attention_dropout=encoder_attention_dropout, qkv_bias=encoder_qkv_bias,
+            proj_bias=encoder_proj_bias, mlp_ratio=encoder_mlp_ratio, stochastic_depth_prob=encoder_stochastic_depth_prob,
+            norm_layer=encoder_norm_layer, MLP_activation_layer=encoder_MLP_activation_layer, exclude_MLP_after=True)
+        hid = int(encoder_dim * encoder_mlp_ratio)
+        self.encoder_MLP_Key = _make_mlp(encoder_dim, hid, encoder_dropout)
+        self.encoder_MLP_Scale = _make_mlp(encoder_dim, hid, encoder_dropout)
+        self.encoder_MLP_Shift = _make_mlp(encoder_dim, hid, encoder_dropout)
+        # (the reference's init loop at :847-851 never matches an nn.Linear, so these keep nn.Linear's default init)
+
+    def run(self, key: Tensor, scale: Tensor, shift: Tensor, B, H, W):
+        blk = self.shared_MHA_without_MLP
+
+        def do_key(key):
+            key = blk.run(key, key, [key], [key], B, H, W)[0]                                   # :859-864
+            return _mlp_fwd(self, "mlp_key", self.encoder_MLP_Key, key, key)                    # :865
+
+        def do_scale_shift(key, scale, shift):
+            # :867-882  both calls use q = k = Key -> one softmax, two value streams; when Scale and Shift
+            # are the same tensor (first layer: Scale = Shift = Fs) the attention output is shared too
+            s_att, sh_att = blk.run(key, key, [scale, shift], [scale, shift], B, H, W)
+            return (_mlp_fwd(self, "mlp_scale", self.encoder_MLP_Scale, s_att, s_att),
+                    _mlp_fwd(self, "mlp_shift", self.encoder_MLP_Shift, sh_att, sh_att))
+
+        if self.if_use_processed_Key_in_Scale_and_Shift_calculation:
+            key = do_key(key)
+            scale, shift = do_scale_shift(key, scale, shift)
+        else:
+            scale, shift = do_scale_shift(key, scale, shift)
+            key = do_key(key)
+        return key, scale, shift
+
+    def forward(self, Key: Tensor, Scale: Tensor, Shift: Tensor):
+        _inference_only(self)
+        B, H, W, C = Key.shape
+        dt = self.compute_dtype
+        k = _tokens(Key, dt)
+        s = k if Scale is Key else _tokens(Scale, dt)
+        sh = s if Shift is Scale else (k if Shift is Key else _tokens(Shift, dt))
+        return tuple(_image(t, B, H, W) for t in self.run(k, s, sh, B, H, W))
+
+
+class StyleDecoder(_HipModule):
+    """Reference codes/style_transformer.py:918-1128 (Swin sigma/mu branch)."""
+
+    def __init__(self, decoder_dim: int, decoder_num_heads: int, decoder_window_size: List[int],
+                 decoder_shift_size: List[int], decoder_mlp_ratio: float = 4.0, decoder_dropout: float = 0.0,
+                 decoder_attention_dropout: float = 0.0, decoder_qkv_bias: bool = True, decoder_proj_bias: bool = True,
+                 decoder_stochastic_depth_prob: float = 0.1, decoder_norm_layer: Callable[..., nn.Module] = nn.LayerNorm,
+                 decoder_MLP_activation_layer: Optional[Callable[..., nn.Module]] = nn.GELU,
+                 decoder_use_instance_norm_with_affine: bool = False,
+                 decoder_use_regular_MHA_instead_of_Swin_at_the_end: bool = False,
+                 decoder_use_Key_instance_norm_after_linear_transformation: bool = True,
+                 decoder_exclude_MLP_after_Fcs_self_MHA: bool = False):
+        super().__init__()
+        if decoder_use_regular_MHA_instead_of_Swin_at_the_end:
+            raise NotImplementedError("decoder_use_regular_MHA_instead_of_Swin_at_the_end=True (global O(N^2) attention, "
+                                      "reference style_transformer.py:1063-1119) is not implemented on the HIP path")
+        if decoder_use_instance_norm_with_affine:
+            raise NotImplementedError("affine InstanceNorm is not implemented on the HIP path (reference default False)")
+        self.decoder_dim, self.decoder_num_heads, self.decoder_mlp_ratio = decoder_dim, decoder_num_heads, decoder_mlp_ratio
+        self.decoder_use_instance_norm_with_affine = False
+        self.decoder_use_regular_MHA_instead_of_Swin_at_the_end = False
+        self.decoder_use_Key_instance_norm_after_linear_transformation = decoder_use_Key_instance_norm_after_linear_transformation
+        self.MHA_self_attn = StyleSwinTransformerBlock(
+            dim=decoder_dim, num_heads=decoder_num_heads, window_size=decoder_window_size, shift_size=decoder_shift_size,
+            dropout=decoder_dropout, attention_dropout=decoder_attention_dropout, qkv_bias=decoder_qkv_bias,
+            proj_bias=decoder_proj_bias, mlp_ratio=decoder_mlp_ratio, stochastic_depth_prob=decoder_stochastic_depth_prob,
+            norm_layer=decoder_norm_layer, MLP_activation_layer=decoder_MLP_activation_layer,
+            exclude_MLP_after=decoder_exclude_MLP_after_Fcs_self_MHA)
+        self.instance_norm = nn.InstanceNorm2d(decoder_dim, affine=False)          # parameter-free, kept for parity of the tree
+        self.last_MLP = _make_mlp(decoder_dim, int(decoder_dim * decoder_mlp_ratio), decoder_dropout)
+        self.decoder_MHA_for_sigma_and_mu = ShiftedWindowAttention_for_decoder_last_MHA(
+            dim=decoder_dim, num_heads=decoder_num_heads, window_size=decoder_window_size, shift_size=decoder_shift_size,
+            instance_norm_q=self.instance_norm, instance_norm_k=self.instance_norm, dropout=decoder_dropout,
+            attention_dropout=decoder_attention_dropout, qkv_bias=decoder_qkv_bias, proj_bias=decoder_proj_bias,
+            use_q_proj=False,
+            use_Key_instance_norm_after_linear_transformation=decoder_use_Key_instance_norm_after_linear_transformation)
+
+    def run(self, fcs: Tensor, key: Tensor, scale: Tensor, shift: Tensor, B, H, W) -> Tensor:
+        T = H * W
+        query = self.MHA_self_attn.run(fcs, fcs, [fcs], [fcs], B, H, W)[0]                     # :1047
+        q_in, _ = ops.instnorm(query, B, T)                                                    # :1056
+        k_in, _ = ops.instnorm(key, B, T)                                                      # :1057
+        query = self.decoder_MHA_for_sigma_and_mu.sigma_mu(q_in, k_in, scale, shift, B, H, W, fuse_query=query)  # :1059,:1123
+        return _mlp_fwd(self, "last_mlp", self.last_MLP, query, query)                         # :1125
+
+    def forward(self, Fcs: Tensor, Key: Tensor, Scale: Tensor, Shift: Tensor) -> Tensor:
+        _inference_only(self)
+        B, H, W, C = Fcs.shape
+        dt = self.compute_dtype
+        return _image(self.run(_tokens(Fcs, dt), _tokens(Key, dt), _tokens(Scale, dt), _tokens(Shift, dt), B, H, W), B, H, W)
+
+
+class StyleTransformer(_HipModule):
+    """Reference codes/style_transformer.py:1133-1245."""
+
+    def __init__(self, encoder_dim: int, decoder_dim: int, encoder_num_heads: int, decoder_num_heads: int,
+                 encoder_window_size: List[int], decoder_window_size: List[int], encoder_shift_size: List[int],
+                 decoder_shift_size: List[int], encoder_mlp_ratio: float = 4.0, decoder_mlp_ratio: float = 4.0,
+                 encoder_dropout: float = 0.0, decoder_dropout: float = 0.0, encoder_attention_dropout: float = 0.0,
+                 decoder_attention_dropout: float = 0.0, encoder_qkv_bias: bool = True, decoder_qkv_bias: bool = True,
+                 encoder_proj_bias: bool = True, decoder_proj_bias: bool = True, encoder_stochastic_depth_prob: float = 0.1,
+                 decoder_stochastic_depth_prob: float = 0.1, encoder_norm_layer: Callable[..., nn.Module] = None,
+                 decoder_norm_layer: Callable[..., nn.Module] = nn.LayerNorm,
+                 encoder_MLP_activation_layer: Optional[Callable[..., nn.Module]] = nn.GELU,
+                 decoder_MLP_activation_layer: Optional[Callable[..., nn.Module]] = nn.GELU,
+                 encoder_if_use_processed_Key_in_Scale_and_Shift_calculation: bool = True,
+                 decoder_use_instance_norm_with_affine: bool = False,
+                 decoder_use_regular_MHA_instead_of_Swin_at_the_end: bool = False,
+                 decoder_use_Key_instance_norm_after_linear_transformation: bool = True,
+                 decoder_exclude_MLP_after_Fcs_self_MHA: bool = False):
+        super().__init__()
+        self.encoder = StyleEncoder(
+            encoder_dim=encoder_dim, encoder_num_heads=encoder_num_heads, encoder_window_size=encoder_window_size,
+            encoder_shift_size=encoder_shift_size, encoder_mlp_ratio=encoder_mlp_ratio, encoder_dropout=encoder_dropout,
+            encoder_attention_dropout=encoder_attention_dropout, encoder_qkv_bias=encoder_qkv_bias,
+            encoder_proj_bias=encoder_proj_bias, encoder_stochastic_depth_prob=encoder_stochastic_depth_prob,
+            encoder_norm_layer=encoder_norm_layer, encoder_MLP_activation_layer=encoder_MLP_activation_layer,
+            encoder_if_use_processed_Key_in_Scale_and_Shift_calculation=encoder_if_use_processed_Key_in_Scale_and_Shift_calculation)
+        self.decoder = StyleDecoder(
+            decoder_dim=decoder_dim, decoder_num_heads=decoder_num_heads, decoder_window_size=decoder_window_size,
+            decoder_shift_size=decoder_shift_size, decoder_mlp_ratio=decoder_mlp_ratio, decoder_dropout=decoder_dropout,
+            decoder_attention_dropout=decoder_attention_dropout, decoder_qkv_bias=decoder_qkv_bias,
+            decoder_proj_bias=decoder_proj_bias, decoder_stochastic_depth_prob=decoder_stochastic_depth_prob,
+            decoder_norm_layer=decoder_norm_layer, decoder_MLP_activation_layer=decoder_MLP_activation_layer,
+            decoder_use_instance_norm_with_affine=decoder_use_instance_norm_with_affine,
+            decoder_use_regular_MHA_instead_of_Swin_at_the_end=decoder_use_regular_MHA_instead_of_Swin_at_the_end,
+            decoder_use_Key_instance_norm_after_linear_transformation=decoder_use_Key_instance_norm_after_linear_transformation,
+            decoder_exclude_MLP_after_Fcs_self_MHA=decoder_exclude_MLP_after_Fcs_self_MHA)
+
+    def run(self, fc: Tensor, fs: Tensor, k: int, B, H, W) -> Tensor:
+        scale = shift = fs                                                     # :1235-1236 (same tensor object)
+        for _ in range(k):                                                     # :1239, shared weights
+            fs, scale, shift = self.encoder.run(fs, scale, shift, B, H, W)
+            fc = self.decoder.run(fc, fs, scale, shift, B, H, W)
+        return fc
+
+    def forward(self, Fc: Tensor, Fs: Tensor, k: int = 1) -> Tensor:
+        _inference_only(self)
+        B, H, W, C = Fc.shape
+        dt = self.compute_dtype
+        return _image(self.run(_tokens(Fc, dt), _tokens(Fs, dt), k, B, H, W), B, H, W)
+
+
+# ---------------------------------------------------------------------------------------------------
+# image decoder (reference codes/decoder.py)
+# ---------------------------------------------------------------------------------------------------
+class Decoder(_HipModule):
+    CONV_IDX = (0, 3, 5, 7, 9, 12, 14, 17, 19)
+    UPSAMPLE_BEFORE = (3, 12, 17)
+
+    def __init__(self, channel_dim: int = 256, initializer: str = "kaiming_normal_"):
+        super().__init__()
+        assert initializer in ["default", "kaiming_normal_", "kaiming_uniform_", "xavier_normal_", "xavier_uniform_",
+                               "orthogonal_"], \
+            "Invalid initializer. Please choose one of the following: default, kaiming_normal_, kaiming_uniform_, xavier_normal_, xavier_uniform_, orthogonal_"
+        c = channel_dim
+
+        def conv(ci, co):
+            return nn.Conv2d(ci, co, (3, 3), padding=(1, 1), padding_mode="reflect")
+        up = lambda: nn.Upsample(scale_factor=2, mode="nearest")
+        self.decoder = nn.Sequential(                                    # same indices as decoder.py:23-55
+            conv(c, c // 2), nn.ReLU(), up(),
+            conv(c // 2, c // 2), nn.ReLU(), conv(c // 2, c // 2), nn.ReLU(), conv(c // 2, c // 2), nn.ReLU(),
+            conv(c // 2, c // 4), nn.ReLU(), up(),
+            conv(c // 4, c // 4), nn.ReLU(), conv(c // 4, c // 8), nn.ReLU(), up(),
+            conv(c // 8, c // 8), nn.ReLU(), conv(c // 8, 3))
+        init = {"kaiming_normal_": lambda w: nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu"),
+                "kaiming_uniform_": lambda w: nn.init.kaiming_uniform_(w, mode="fan_out", nonlinearity="relu"),
+                "xavier_normal_": nn.init.xavier_normal_, "xavier_uniform_": nn.init.xavier_uniform_,
+                "orthogonal_": nn.init.orthogonal_}.get(initializer)
+        for m in self.decoder.modules():                                 # decoder.py:58-73
+            if isinstance(m, nn.Conv2d):
+                if init is not None:
+                    init(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def run_nhwc(self, x: Tensor) -> Tensor:
+        """x: NHWC [B,H,W,C] in the compute dtype -> fp32 NCHW image [B,3,8H,8W]"""
+        last = self.CONV_IDX[-1]
+        for i in self.CONV_IDX:
+            conv = self.decoder[i]
+            w = self._derived(f"conv{i}", [conv.weight],
+                              lambda conv=conv: ops.convert(conv.weight.detach().permute(0, 2, 3, 1).contiguous(), self.compute_dtype))
+            x = ops.conv3x3_reflect(x, w, self._b(f"conv{i}", conv.bias), upsample=i in self.UPSAMPLE_BEFORE,
+                                    relu=i != last, out_nchw=i == last)
+        return x
+
+    def forward(self, x: Tensor) -> Tensor:
+        """NCHW in / NCHW out like the reference (decoder.py:75-76)"""
+        _inference_only(self)
+        return self.run_nhwc(ops.convert(x.permute(0, 2, 3, 1).contiguous(), self.compute_dtype))
+
+
+# ---------------------------------------------------------------------------------------------------
+# Swin-B features[:4] (torchvision key names: 0.0 conv, 0.2 LN, 1.{0,1} blocks, 2 merge, 3.{0,1} blocks)
+# ---------------------------------------------------------------------------------------------------
+class _SwinAttention(_WindowAttentionBase):
+    def __init__(self, dim: int, num_heads: int, window_size, shift_size):
+        super().__init__()
+        _check_arch(0.0, 0.0, True, True, nn.GELU, dim, num_heads)
+        self.window_size, self.shift_size, self.num_heads = list(window_size), list(shift_size), num_heads
+        self.qkv = nn.Linear(dim, dim * 3)
+        self.proj = nn.Linear(dim, dim)
+        self._init_rel_pos(num_heads)
+
+    def attend(self, x: Tensor, residual: Tensor, B, H, W) -> Tensor:
+        C = x.shape[1]
+        qkv = ops.linear(x, self._w("qkv", self.qkv.weight), self._b("qkv", self.qkv.bias))
+        rows = self._derived("rows", [self.qkv.bias], lambda: ops.convert(self.qkv.bias.detach().contiguous(), self.compute_dtype))
+        o = self._core(qkv[:, :C], qkv[:, C:2 * C], [qkv[:, 2 * C:]], rows[C:2 * C], [rows[2 * C:], None], B, H, W)[0]
+        return ops.linear(o, self._w("proj", self.proj.weight), self._b("proj", self.proj.bias), r2=residual)
+
+
+class SwinTransformerBlock(_HipModule):
+    def __init__(self, dim: int, num_heads: int, window_size, shift_size, mlp_ratio: float = 4.0):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=EPS)
+        self.attn = _SwinAttention(dim, num_heads, window_size, shift_size)
+        self.norm2 = nn.LayerNorm(dim, eps=EPS)
+        self.mlp = _make_mlp(dim, int(dim * mlp_ratio), 0.0)
+        _init_mlp(self.mlp)
+
+    def run(self, x: Tensor, B, H, W) -> Tensor:
+        n = ops.layernorm(x, self._b("n1w", self.norm1.weight), self._b("n1b", self.norm1.bias), self.norm1.eps)
+        x = self.attn.attend(n, x, B, H, W)
+        n = ops.layernorm(x, self._b("n2w", self.norm2.weight), self._b("n2b", self.norm2.bias), self.norm2.eps)
+        return _mlp_fwd(self, "mlp", self.mlp, n, x)
+
+
+class PatchMerging(_HipModule):
+    def __init__(self, dim: int):
+        super().__init__()
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = nn.LayerNorm(4 * dim, eps=EPS)
+
+    def run(self, x2d: Tensor, B, H, W) -> Tensor:
+        C = x2d.shape[1]
+        if H % 2 or W % 2:
+            raise NotImplementedError("odd feature maps need torchvision's pad-to-even; image sides must be multiples of 8")
+        g = ops.patch_merge_ln(x2d.view(B, H, W, C), self._b("nw", self.norm.weight), self._b("nb", self.norm.bias), self.norm.eps)
+        return ops.linear(g.view(B * (H // 2) * (W // 2), 4 * C), self._w("red", self.reduction.weight))
+
+
+class SwinEncoder(nn.Sequential):
+    """swin_b.features[:4] with torchvision's child indices, so `torch.load`-ed torchvision state dicts of
+    the reference's cut encoder (codes/utils.py:59-102) load by key.  NCHW image -> NHWC [B,H/8,W/8,2E]."""
+    compute_dtype = torch.float32
+
+    def __init__(self, embed_dim: int = 128, depths=(2, 2), num_heads=(4, 8), window_size=(7, 7), mlp_ratio: float = 4.0):
+        patch = nn.Sequential(nn.Conv2d(3, embed_dim, kernel_size=4, stride=4), nn.Identity(), nn.LayerNorm(embed_dim, eps=EPS))
+
+        def stage(dim, nh, depth):
+            return nn.Sequential(*[SwinTransformerBlock(dim, nh, window_size,
+                                                        [0, 0] if i % 2 == 0 else [w // 2 for w in window_size], mlp_ratio)
+                                   for i in range(depth)])
+        super().__init__(patch, stage(embed_dim, num_heads[0], depths[0]), PatchMerging(embed_dim),
+                         stage(2 * embed_dim, num_heads[1], depths[1]))
+        for m in self.modules():                                  # torchvision SwinTransformer init
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def run(self, img: Tensor) -> Tuple[Tensor, int, int, int]:
+        """fp32 NCHW image -> (token matrix [B*H/8*W/8, 2E] in the compute dtype, B, H/8, W/8)"""
+        B, _, H, W = img.shape
+        if H % 8 or W % 8:
+            raise ValueError("image sides must be multiples of 8 (patch 4 + one 2x2 merge)")
+        conv, ln = self[0][0], self[0][2]
+        x = ops.patch_embed(img.contiguous().float(), conv.weight.detach().reshape(conv.weight.shape[0], -1).float().contiguous(),
+                            conv.bias.detach().float(), ln.weight.detach().float(), ln.bias.detach().float(),
+                            self.compute_dtype, ln.eps)
+        h, w = H // 4, W // 4
+        x = x.view(B * h * w, -1)
+        for blk in self[1]:
+            x = blk.run(x, B, h, w)
+        x = self[2].run(x, B, h, w)
+        h, w = h // 2, w // 2
+        for blk in self[3]:
+            x = blk.run(x, B, h, w)
+        return x, B, h, w
+
+    def forward(self, img: Tensor) -> Tensor:
+        _inference_only(self)
+        x, B, h, w = self.run(img)
+        return _image(x, B, h, w)

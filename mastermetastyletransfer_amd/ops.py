@@ -1,0 +1,223 @@
+"""ctypes bindings of libmaster_hip.so (include/master_hip.h) on torch device tensors.
+
+PyTorch is plumbing here: it owns device memory and the stream; every function below hands raw device
+pointers and the current HIP stream to the C ABI.  There is NO CPU or torch fallback: a missing
+library or a non-GPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmaster_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+K_FAMILIES = ("linear", "conv3x3", "window_attn", "layernorm", "instnorm", "patch_embed", "patch_merge", "convert")
+
+EXPORTS = (
+    "master_version", "master_last_error_string", "master_linear_fwd", "master_conv3x3_reflect_fwd",
+    "master_window_attn_fwd", "master_layernorm_fwd", "master_instnorm_fwd", "master_patch_embed_fwd",
+    "master_patch_merge_ln_fwd", "master_convert", "master_prof_enable", "master_prof_reset", "master_prof_read",
+)
+
+_lib = None
+
+
+class MasterHipError(RuntimeError):
+    pass
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen the in-tree library; raise (never fall back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MasterHipError(
+            f"{LIB_PATH} not found: build it with `python -m mastermetastyletransfer_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback for the stylization path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise MasterHipError(f"{LIB_PATH} does not export {name}")
+    lib.master_last_error_string.restype = ctypes.c_char_p
+    vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    lib.master_linear_fwd.argtypes = [vp] * 6 + [ci] * 8 + [vp]
+    lib.master_conv3x3_reflect_fwd.argtypes = [vp] * 4 + [ci] * 9 + [vp]
+    lib.master_window_attn_fwd.argtypes = [vp] * 4 + [ci] * 3 + [vp] * 3 + [ci] * 2 + [vp] * 3 + [vp] * 2 + [ci] * 6 + [cf, ci, vp]
+    lib.master_layernorm_fwd.argtypes = [vp] * 4 + [ci, ci, cf, ci, vp]
+    lib.master_instnorm_fwd.argtypes = [vp] * 4 + [ci] * 4 + [cf, ci, vp]
+    lib.master_patch_embed_fwd.argtypes = [vp] * 6 + [ci] * 4 + [cf, ci, vp]
+    lib.master_patch_merge_ln_fwd.argtypes = [vp] * 4 + [ci] * 4 + [cf, ci, vp]
+    lib.master_convert.argtypes = [vp, vp, ctypes.c_size_t, ci, ci, vp]
+    lib.master_prof_read.argtypes = [ci, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load_library().master_last_error_string().decode()
+        if rc == -2:
+            raise NotImplementedError(f"{what}: {msg}")
+        raise MasterHipError(f"{what} failed (status {rc}): {msg}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise MasterHipError(f"unsupported element type {t.dtype}")
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise MasterHipError("the stylization path runs on the GPU only (got a CPU tensor); there is no CPU fallback")
+
+
+def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, r1: Optional[torch.Tensor] = None,
+           r2: Optional[torch.Tensor] = None, act: int = ACT_NONE, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M,N] = r1 * act(a @ w.T + bias) + r2 ; a is [M,K] (last dim contiguous, row stride free)."""
+    _dev(a, w)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.stride(1) == 1 and w.is_contiguous()
+    if out is None:
+        out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    ldr = 0
+    for r in (r1, r2):
+        if r is not None:
+            assert r.shape == (M, N) and r.stride(1) == 1 and r.dtype == a.dtype
+            ldr = r.stride(0)
+    if r1 is not None and r2 is not None:
+        assert r1.stride(0) == r2.stride(0)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N
+    _check(load_library().master_linear_fwd(_p(a), _p(w), _p(bias), _p(r1), _p(r2), _p(out), M, N, K, a.stride(0),
+                                             out.stride(0), ldr, act, _dt(a), _stream()), "master_linear_fwd")
+    return out
+
+
+def conv3x3_reflect(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, upsample: bool, relu: bool,
+                    out_nchw: bool = False) -> torch.Tensor:
+    """x NHWC [B,H,W,Cin]; w_packed [Cout,3,3,Cin]; returns NHWC, or fp32 NCHW when out_nchw."""
+    _dev(x, w_packed)
+    B, H, W, Cin = x.shape
+    Cout = w_packed.shape[0]
+    assert x.is_contiguous() and w_packed.is_contiguous() and bias.dtype == torch.float32
+    Ho, Wo = (H * 2, W * 2) if upsample else (H, W)
+    if out_nchw:
+        out = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    else:
+        out = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+    _check(load_library().master_conv3x3_reflect_fwd(_p(x), _p(w_packed), _p(bias), _p(out), B, H, W, Cin, Cout,
+                                                      int(upsample), int(relu), int(out_nchw), _dt(x), _stream()),
+           "master_conv3x3_reflect_fwd")
+    return out
+
+
+def window_attn(q, k, v0, v1, k_pad, v0_pad, v1_pad, bias64, src, region, B: int, T: int, heads: int, nW: int, N: int,
+                scale: float):
+    """q/k/v*: [B*T, heads*32] views (row stride free).  Returns out0 (and out1 when v1 is given), [B*T, heads*32]."""
+    _dev(q, k, v0)
+    C = heads * 32
+    out0 = torch.empty((B * T, C), dtype=q.dtype, device=q.device)
+    out1 = torch.empty_like(out0) if v1 is not None else None
+    assert v0.stride(0) == (v1.stride(0) if v1 is not None else v0.stride(0))
+    kbs = k_pad.stride(0) if k_pad.dim() == 2 else 0
+    vbs = v0_pad.stride(0) if v0_pad.dim() == 2 else 0
+    _check(load_library().master_window_attn_fwd(
+        _p(q), _p(k), _p(v0), _p(v1), q.stride(0), k.stride(0), v0.stride(0), _p(k_pad), _p(v0_pad), _p(v1_pad),
+        kbs, vbs, _p(bias64), _p(src), _p(region), _p(out0), _p(out1), C, B, T, heads, nW, N, float(scale), _dt(q),
+        _stream()), "master_window_attn_fwd")
+    return out0, out1
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    _dev(x)
+    M, C = x.shape
+    assert x.is_contiguous()
+    out = torch.empty_like(x)
+    _check(load_library().master_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(out), M, C, eps, _dt(x), _stream()),
+           "master_layernorm_fwd")
+    return out
+
+
+def instnorm(x: torch.Tensor, B: int, T: int, pad_row: Optional[torch.Tensor] = None, n_pad: int = 0, eps: float = 1e-5):
+    """x [B*T, C].  Returns (normalised x, normalised pad rows [B,C] or None)."""
+    _dev(x)
+    C = x.shape[1]
+    assert x.is_contiguous() and x.shape[0] == B * T
+    out = torch.empty_like(x)
+    pad_out = torch.empty((B, C), dtype=x.dtype, device=x.device) if n_pad > 0 else None
+    _check(load_library().master_instnorm_fwd(_p(x), _p(out), _p(pad_row), _p(pad_out), B, T, C, n_pad, eps, _dt(x),
+                                               _stream()), "master_instnorm_fwd")
+    return out, pad_out
+
+
+def patch_embed(img: torch.Tensor, w: torch.Tensor, bias, gamma, beta, dtype: torch.dtype, eps: float = 1e-5):
+    """img fp32 NCHW [B,3,H,W] -> NHWC [B,H/4,W/4,E] with LayerNorm(E) applied."""
+    _dev(img, w)
+    B, _, H, W = img.shape
+    E = w.shape[0]
+    assert img.dtype == torch.float32 and img.is_contiguous()
+    out = torch.empty((B, H // 4, W // 4, E), dtype=dtype, device=img.device)
+    _check(load_library().master_patch_embed_fwd(_p(img), _p(w), _p(bias), _p(gamma), _p(beta), _p(out), B, H, W, E, eps,
+                                                  F32 if dtype == torch.float32 else BF16, _stream()),
+           "master_patch_embed_fwd")
+    return out
+
+
+def patch_merge_ln(x: torch.Tensor, gamma, beta, eps: float = 1e-5) -> torch.Tensor:
+    _dev(x)
+    B, H, W, C = x.shape
+    assert x.is_contiguous()
+    out = torch.empty((B, H // 2, W // 2, 4 * C), dtype=x.dtype, device=x.device)
+    _check(load_library().master_patch_merge_ln_fwd(_p(x), _p(gamma), _p(beta), _p(out), B, H, W, C, eps, _dt(x),
+                                                     _stream()), "master_patch_merge_ln_fwd")
+    return out
+
+
+def convert(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    _dev(x)
+    if x.dtype == dtype:
+        return x
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _check(load_library().master_convert(_p(x), _p(out), x.numel(), _dt(x), F32 if dtype == torch.float32 else BF16,
+                                          _stream()), "master_convert")
+    return out
+
+
+# ---- profiling (bench.py roofline leg) ------------------------------------------------------------
+def prof_enable(on: bool):
+    _check(load_library().master_prof_enable(int(on)), "master_prof_enable")
+
+
+def prof_reset():
+    _check(load_library().master_prof_reset(), "master_prof_reset")
+
+
+def prof_read():
+    lib = load_library()
+    res = {}
+    for i, name in enumerate(K_FAMILIES):
+        n, ms = ctypes.c_int64(0), ctypes.c_double(0.0)
+        _check(lib.master_prof_read(i, ctypes.byref(n), ctypes.byref(ms)), "master_prof_read")
+        res[name] = (n.value, ms.value)
+    return res
