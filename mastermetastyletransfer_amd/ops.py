@@ -27,6 +27,29 @@ EXPORTS = (
 
 _lib = None
 
+# optional algorithmic work counters (bench.py roofline leg): flops / compulsory bytes per kernel family
+_COUNT_ON = False
+_COUNTS = {}
+
+
+def count_enable(on: bool):
+    global _COUNT_ON
+    _COUNT_ON = bool(on)
+
+
+def count_reset():
+    _COUNTS.clear()
+
+
+def count_read():
+    return {k: dict(v) for k, v in _COUNTS.items()}
+
+
+def _count(family: str, **kw):
+    d = _COUNTS.setdefault(family, {})
+    for k, v in kw.items():
+        d[k] = d.get(k, 0.0) + float(v)
+
 
 class MasterHipError(RuntimeError):
     pass
@@ -108,6 +131,10 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         assert r1.stride(0) == r2.stride(0)
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N
+    if _COUNT_ON:
+        es = a.element_size()
+        _count("linear", flops=2.0 * M * N * K,
+               bytes=es * (M * K + N * K + M * N * (1 + (r1 is not None) + (r2 is not None))))
     _check(load_library().master_linear_fwd(_p(a), _p(w), _p(bias), _p(r1), _p(r2), _p(out), M, N, K, a.stride(0),
                                              out.stride(0), ldr, act, _dt(a), _stream()), "master_linear_fwd")
     return out
@@ -125,6 +152,9 @@ def conv3x3_reflect(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor,
         out = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
     else:
         out = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+    if _COUNT_ON:
+        _count("conv3x3", flops=2.0 * B * Ho * Wo * Cout * 9 * Cin,
+               bytes=x.element_size() * (x.numel() + w_packed.numel()) + out.element_size() * out.numel())
     _check(load_library().master_conv3x3_reflect_fwd(_p(x), _p(w_packed), _p(bias), _p(out), B, H, W, Cin, Cout,
                                                       int(upsample), int(relu), int(out_nchw), _dt(x), _stream()),
            "master_conv3x3_reflect_fwd")
@@ -141,6 +171,10 @@ def window_attn(q, k, v0, v1, k_pad, v0_pad, v1_pad, bias64, src, region, B: int
     assert v0.stride(0) == (v1.stride(0) if v1 is not None else v0.stride(0))
     kbs = k_pad.stride(0) if k_pad.dim() == 2 else 0
     vbs = v0_pad.stride(0) if v0_pad.dim() == 2 else 0
+    if _COUNT_ON:
+        nv = 1 if v1 is None else 2
+        _count("window_attn", flops=2.0 * B * nW * heads * N * N * 32 * (1 + nv), qk_flops=2.0 * B * nW * heads * N * N * 32,
+               bytes=q.element_size() * B * T * C * (2 + 2 * nv))
     _check(load_library().master_window_attn_fwd(
         _p(q), _p(k), _p(v0), _p(v1), q.stride(0), k.stride(0), v0.stride(0), _p(k_pad), _p(v0_pad), _p(v1_pad),
         kbs, vbs, _p(bias64), _p(src), _p(region), _p(out0), _p(out1), C, B, T, heads, nW, N, float(scale), _dt(q),
@@ -153,6 +187,8 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     M, C = x.shape
     assert x.is_contiguous()
     out = torch.empty_like(x)
+    if _COUNT_ON:
+        _count("layernorm", bytes=2.0 * x.element_size() * x.numel())
     _check(load_library().master_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(out), M, C, eps, _dt(x), _stream()),
            "master_layernorm_fwd")
     return out
@@ -165,6 +201,8 @@ def instnorm(x: torch.Tensor, B: int, T: int, pad_row: Optional[torch.Tensor] = 
     assert x.is_contiguous() and x.shape[0] == B * T
     out = torch.empty_like(x)
     pad_out = torch.empty((B, C), dtype=x.dtype, device=x.device) if n_pad > 0 else None
+    if _COUNT_ON:
+        _count("instnorm", bytes=2.0 * x.element_size() * x.numel())
     _check(load_library().master_instnorm_fwd(_p(x), _p(out), _p(pad_row), _p(pad_out), B, T, C, n_pad, eps, _dt(x),
                                                _stream()), "master_instnorm_fwd")
     return out, pad_out
