@@ -1,0 +1,108 @@
+"""GPU, bf16 throughput mode: the same kernels with bf16 storage / bf16 MFMA / fp32 accumulation.
+bf16 carries 8 significant bits, so the 1e-3 parity bar does not apply (it is defined on fp32,
+BASELINE.json); these tests bound the error against the fp32 CPU oracle and report it."""
+import warnings
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import master_oracle as O
+from oracle.seeded import seeded_input, seeded_state_dict
+from tests import golden_cases as G
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rel_err(got, ref):
+    got, ref = got.detach().float().cpu(), ref.float()
+    assert got.shape == ref.shape and torch.isfinite(got).all()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-6)).item(), ((got - ref).norm() / ref.norm()).item()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 256), (1024, 768, 256), (257, 1024, 256), (512, 256, 1024),
+                                   (200, 64, 64), (130, 32, 128), (4096, 384, 128)])
+def test_linear_bf16(cuda, M, N, K):
+    from mastermetastyletransfer_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).to(BF); w = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
+    b = torch.randn(N, generator=g); r1 = torch.randn(M, N, generator=g).to(BF); r2 = torch.randn(M, N, generator=g).to(BF)
+    ref = F.linear(a.float(), w.float(), b)                      # exact product of the bf16-rounded operands
+    out = ops.linear(a.to(cuda), w.to(cuda), b.to(cuda))
+    assert out.dtype == BF
+    mx, l2 = rel_err(out, ref)
+    assert mx < 1e-2 and l2 < 4e-3, (mx, l2)                     # one bf16 rounding of the result
+    out = ops.linear(a.to(cuda), w.to(cuda), b.to(cuda), r1=r1.to(cuda), r2=r2.to(cuda), act=ops.ACT_GELU)
+    mx, l2 = rel_err(out, r1.float() * F.gelu(ref) + r2.float())
+    assert mx < 1e-2 and l2 < 4e-3, (mx, l2)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,up,relu,nchw", [(2, 8, 8, 256, 128, False, True, False), (1, 8, 8, 128, 128, True, True, False),
+                                                          (2, 5, 7, 64, 64, True, True, False), (1, 16, 16, 64, 32, False, True, False),
+                                                          (2, 12, 10, 32, 32, True, True, False), (2, 12, 10, 32, 3, False, False, True)])
+def test_conv3x3_bf16(cuda, B, H, W, Cin, Cout, up, relu, nchw):
+    from mastermetastyletransfer_amd import ops
+    g = torch.Generator().manual_seed(H + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g).to(BF)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(BF)
+    b = torch.randn(Cout, generator=g)
+    xi = F.interpolate(x.float(), scale_factor=2, mode="nearest") if up else x.float()
+    ref = F.conv2d(F.pad(xi, (1, 1, 1, 1), mode="reflect"), w.float(), b)
+    ref = F.relu(ref) if relu else ref
+    out = ops.conv3x3_reflect(x.permute(0, 2, 3, 1).contiguous().to(cuda), w.permute(0, 2, 3, 1).contiguous().to(cuda),
+                              b.to(cuda), up, relu, out_nchw=nchw)
+    assert out.dtype == (torch.float32 if nchw else BF)
+    mx, l2 = rel_err(out if nchw else out.permute(0, 3, 1, 2), ref)
+    assert mx < 1e-2 and l2 < 4e-3, (mx, l2)
+
+
+def test_window_attention_bf16(cuda, golden):
+    from mastermetastyletransfer_amd import ShiftedWindowAttention
+    for H, W, shift in G.SWA_CASES:
+        tag, sd, (q, k, v) = G.swa_case(H, W, shift)
+        m = ShiftedWindowAttention(G.DIM, G.NH, [7, 7], list(shift))
+        m.load_state_dict(sd); m = m.to(cuda).eval(); m.compute_dtype = BF
+        mx, l2 = rel_err(m(q.to(cuda), k.to(cuda), v.to(cuda)), torch.from_numpy(golden[tag]))
+        assert mx < 5e-2 and l2 < 2e-2, (tag, mx, l2)
+
+
+def test_sigma_mu_and_style_transformer_bf16(cuda, golden):
+    from mastermetastyletransfer_amd import StyleTransformer
+    sd, abcd, fc, fs, cfg = G.st_small()
+    m = StyleTransformer(G.DIM, G.DIM, G.NH, G.NH, [7, 7], [7, 7], [4, 4], [4, 4])
+    m.load_state_dict(sd); m = m.to(cuda).eval()
+    for mod in m.modules():
+        mod.compute_dtype = BF
+    a, b, c, d = (t.to(cuda) for t in abcd)
+    s, mu = m.decoder.decoder_MHA_for_sigma_and_mu(a, b, c, d)
+    for got, name in ((s, "sigma_mu_sigma"), (mu, "sigma_mu_mu")):
+        mx, l2 = rel_err(got, torch.from_numpy(golden[name]))
+        assert mx < 5e-2 and l2 < 2e-2, (name, mx, l2)
+    mx, l2 = rel_err(m(fc.to(cuda), fs.to(cuda), 1), torch.from_numpy(golden["style_transformer_small_k1"]))
+    assert mx < 8e-2 and l2 < 3e-2, (mx, l2)
+
+
+@pytest.mark.parametrize("B,S", [(1, 256), (2, 64)])
+def test_full_forward_bf16(cuda, B, S):
+    from mastermetastyletransfer_amd import MasterStyleTransferModel
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7])
+    sds = (seeded_state_dict(O.swin_shapes(), 31), seeded_state_dict(O.style_transformer_shapes(), 32),
+           seeded_state_dict(O.decoder_shapes(), 33))
+    m.swin_encoder.load_state_dict(sds[0]); m.style_transformer.load_state_dict(sds[1]); m.decoder.load_state_dict(sds[2])
+    m = m.to(cuda).eval().set_compute_dtype(BF)
+    c = seeded_input(f"c{S}", (B, 3, S, S), 8, kind="image")
+    s = seeded_input(f"s{S}", (B, 3, S, S), 9, kind="image")
+    with torch.no_grad():
+        got = m(c.to(cuda), s.to(cuda), 1)
+        ref = O.full_forward(c, s, 1, *sds)
+    assert got.dtype == torch.float32 and got.shape == ref.shape
+    mx, l2 = rel_err(got, ref)
+    print(f"bf16 full forward B={B} S={S}: max|d|/max|ref| = {mx:.3e}, relative L2 = {l2:.3e}, max|d| = {(got.cpu()-ref).abs().max():.3e}")
+    assert l2 < 5e-2 and mx < 0.25, (mx, l2)
+    # switching back to fp32 restores the parity-mode result (derived-weight caches are keyed by dtype)
+    m.set_compute_dtype(torch.float32)
+    with torch.no_grad():
+        assert (m(c.to(cuda), s.to(cuda), 1).cpu() - ref).abs().max() < 1e-3
