@@ -49,12 +49,12 @@ double g_ms[MASTER_K_COUNT];
 
 ProfScope::ProfScope(int f, hipStream_t st) : family(f), s(st), e0(nullptr), e1(nullptr), on(g_prof_on) {
     if (!on) return;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    hipEventRecord(e0, s);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, s);
 }
 ProfScope::~ProfScope() {
     if (!on) return;
-    hipEventRecord(e1, s);
+    (void)hipEventRecord(e1, s);
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof.push_back({family, e0, e1});
 }
@@ -62,10 +62,10 @@ ProfScope::~ProfScope() {
 static void prof_drain() {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_prof) {
-        hipEventSynchronize(r.e1);
+        (void)hipEventSynchronize(r.e1);
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { g_launches[r.family]++; g_ms[r.family] += ms; }
-        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
     }
     g_prof.clear();
 }

@@ -18,7 +18,19 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return (bf16_t)(u >> 16);
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7): one v_rcp, one v_exp, six FMAs.  libm's erff costs
+// ~40 VALU instructions per value, which made the GELU epilogue of the MLP's first GEMM VALU-bound.
+__device__ __forceinline__ float fast_erf(float z) {
+    const float az = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-az * az * 1.4426950408889634f);
+    return copysignf(fmaf(-p * t, e, 1.0f), z);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 
 template <int ACT>
 __device__ __forceinline__ float apply_act(float x) {

@@ -25,52 +25,93 @@ template <> struct Vec4<bf16_t> {
     }
 };
 
-// ---- LayerNorm: one wave per output row of C <= 1024 channels; MERGE gathers the row from the four
-//      2x2 neighbours of an NHWC map (Swin PatchMerging order: (0,0) (1,0) (0,1) (1,1)). ------------
-template <typename T, bool MERGE>
+// ---- LayerNorm: a row of C channels is C/VEC 16-byte chunks (VEC = 4 fp32 or 8 bf16); LPR = min(64, chunks)
+//      lanes share a row, so one wave instruction covers 64/LPR rows, and each wave walks RG row groups
+//      with all their loads issued before the first reduction.  MERGE gathers the row from the four 2x2
+//      neighbours of an NHWC map (Swin PatchMerging order (0,0) (1,0) (0,1) (1,1)). -------------------
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const float* p, float* v) { const f32x4 t = *(const f32x4*)p; v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+    static __device__ __forceinline__ void store(float* p, const float* v) { f32x4 t; t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3]; *(f32x4*)p = t; }
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const bf16_t* p, float* v) {
+        const uint4 u = *(const uint4*)p;
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float* v) {
+        uint4 u;
+        u.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+        u.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        u.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+        u.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+        *(uint4*)p = u;
+    }
+};
+
+template <typename T, bool MERGE, int CH>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ out, int M, int C,
-                                                        float eps, int H, int W, int Cin) {
+                                                        float eps, int H, int W, int Cin, int lpr) {
+    constexpr int VEC = Vec16<T>::N;
+    constexpr int RG = CH == 1 ? 4 : 1;               // row groups per wave
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    const int nch = C >> 2;                   // float4 chunks in the row
-    size_t base[4];
-    if (MERGE) {
-        const int W2 = W >> 1, H2 = H >> 1;
-        const int b = row / (H2 * W2), rem = row - b * (H2 * W2), y2 = rem / W2, x2 = rem - y2 * W2;
+    const int sub = lane & (lpr - 1), rsel = lane / lpr, rpw = 64 / lpr;
+    const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+    float v[RG][CH][VEC];
+    int rows[RG];
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            base[s] = (((size_t)b * H + 2 * y2 + (s & 1)) * W + 2 * x2 + (s >> 1)) * Cin;
-    }
-    f32x4 v[4];
-    float sum = 0.0f;
+    for (int g = 0; g < RG; ++g) {
+        const int row = (wave_id * RG + g) * rpw + rsel;
+        rows[g] = row;
+        const int rr = row < M ? row : M - 1;
+        size_t base[4];
+        if (MERGE) {
+            const int W2 = W >> 1, H2 = H >> 1;
+            const int b = rr / (H2 * W2), rem = rr - b * (H2 * W2), y2 = rem / W2, x2 = rem - y2 * W2;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (lane + 64 * i < nch) {
-            const T* src = MERGE ? x + base[c / Cin] + (c % Cin) : x + (size_t)row * C + c;
-            v[i] = Vec4<T>::load(src);
-            sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+            for (int s = 0; s < 4; ++s) base[s] = (((size_t)b * H + 2 * y2 + (s & 1)) * W + 2 * x2 + (s >> 1)) * Cin;
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = (sub + lpr * i) * VEC;
+            const T* src = MERGE ? x + base[c / Cin] + (c % Cin) : x + (size_t)rr * C + c;
+            Vec16<T>::load(src, v[g][i]);
         }
     }
-    const float mean = wave_sum(sum) / (float)C;
-    float sq = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (lane + 64 * i < nch)
+    for (int g = 0; g < RG; ++g) {
+        float sum = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; sq += d * d; }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+        for (int i = 0; i < CH; ++i)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (lane + 64 * i < nch) {
-            const f32x4 g = *(const f32x4*)(gamma + c), bt = *(const f32x4*)(beta + c);
-            f32x4 o;
+            for (int e = 0; e < VEC; ++e) sum += v[g][i][e];
+        for (int o = lpr >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float mean = sum / (float)C;
+        float sq = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + bt[e];
-            Vec4<T>::store(out + (size_t)row * C + c, o);
+        for (int i = 0; i < CH; ++i)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { const float d = v[g][i][e] - mean; sq += d * d; }
+        for (int o = lpr >> 1; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        const float rstd = rsqrtf(sq / (float)C + eps);
+        if (rows[g] < M) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int c = (sub + lpr * i) * VEC;
+                float o_[VEC];
+#pragma unroll
+                for (int e4 = 0; e4 < VEC / 4; ++e4) {
+                    const f32x4 gm = *(const f32x4*)(gamma + c + 4 * e4), bt = *(const f32x4*)(beta + c + 4 * e4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o_[4 * e4 + e] = (v[g][i][4 * e4 + e] - mean) * rstd * gm[e] + bt[e];
+                }
+                Vec16<T>::store(out + (size_t)rows[g] * C + c, o_);
+            }
         }
     }
 }
@@ -206,16 +247,36 @@ __global__ __launch_bounds__(256) void convert_kernel(const S* __restrict__ src,
 
 }  // namespace
 
+template <typename T, bool MERGE>
+static void layernorm_dispatch(const void* x, const void* g, const void* b, void* out, int M, int C, float eps, int H,
+                               int W, int Cin, hipStream_t s) {
+    constexpr int VEC = Vec16<T>::N;
+    const int chunks = C / VEC;
+    const int lpr = chunks >= 64 ? 64 : chunks;            // power of two (checked by the caller)
+    const int ch = chunks / lpr;
+    const int rpw = 64 / lpr;
+#define LN_LAUNCH(CHV)                                                                                               \
+    {                                                                                                                \
+        const int rg = CHV == 1 ? 4 : 1;                                                                             \
+        const int waves = (M + rpw * rg - 1) / (rpw * rg);                                                           \
+        hipLaunchKernelGGL((layernorm_kernel<T, MERGE, CHV>), dim3((waves + 3) / 4), dim3(256), 0, s, (const T*)x,   \
+                           (const float*)g, (const float*)b, (T*)out, M, C, eps, H, W, Cin, lpr);                    \
+    }
+    if (ch == 1) LN_LAUNCH(1) else if (ch == 2) LN_LAUNCH(2) else LN_LAUNCH(4)
+#undef LN_LAUNCH
+}
+
 template <typename T>
 int layernorm_launch(const void* x, const void* g, const void* b, void* out, int M, int C, float eps, int merge, int H,
                      int W, int Cin, hipStream_t s) {
-    const int grid = (M + 3) / 4;
-    if (merge)
-        hipLaunchKernelGGL((layernorm_kernel<T, true>), dim3(grid), dim3(256), 0, s, (const T*)x, (const float*)g,
-                           (const float*)b, (T*)out, M, C, eps, H, W, Cin);
-    else
-        hipLaunchKernelGGL((layernorm_kernel<T, false>), dim3(grid), dim3(256), 0, s, (const T*)x, (const float*)g,
-                           (const float*)b, (T*)out, M, C, eps, 0, 0, C);
+    constexpr int VEC = Vec16<T>::N;
+    const int chunks = C / VEC;
+    if (C % VEC != 0 || (chunks & (chunks - 1)) != 0 || chunks > 256 || (merge && Cin % VEC != 0)) {
+        master_set_error("layernorm: C/%d must be a power of two <= 256 (C=%d)", VEC, C);
+        return MASTER_ERR_INVALID;
+    }
+    if (merge) layernorm_dispatch<T, true>(x, g, b, out, M, C, eps, H, W, Cin, s);
+    else layernorm_dispatch<T, false>(x, g, b, out, M, C, eps, 0, 0, C, s);
     return master_check_launch("layernorm");
 }
 template int layernorm_launch<float>(const void*, const void*, const void*, void*, int, int, float, int, int, int, int, hipStream_t);
