@@ -53,6 +53,16 @@ int master_linear_fwd(const void* a, const void* w, const void* bias, const void
                       void* out, int M, int N, int K, int lda, int ldo, int ldr, int act, int dtype,
                       master_stream_t stream);
 
+/* Fused MLP block:  out[M,C] = res + W2 . gelu(W1 . LN?(x) + b1) + b2   in ONE launch; the hidden
+ * activations stay in registers.  x, res, out: [M,C] token matrices (row strides ldx/ldr/ldo); w1 [HID,C],
+ * w2 [C,HID] as nn.Linear stores them; b1, b2, ln_gamma, ln_beta fp32; ln_gamma == NULL skips the LayerNorm;
+ * res == NULL skips the residual.  Replaces torchvision MLP + residual (+ the preceding norm2):
+ * style_transformer.py:366,:392,:839-841,:865-882,:991,:1125.  MASTER_BF16 only, C in {128,256}, HID % 128 == 0
+ * (MASTER_ERR_UNSUPPORTED otherwise: callers then use two master_linear_fwd calls). */
+int master_mlp_fwd(const void* x, const float* ln_gamma, const float* ln_beta, const void* w1, const float* b1,
+                   const void* w2, const float* b2, const void* res, void* out, int M, int C, int HID, int ldx,
+                   int ldr, int ldo, float eps, int dtype, master_stream_t stream);
+
 /* 3x3 convolution, reflect padding 1, optional nearest x2 upsample of the input fused into the
  * gather, optional ReLU.  x is NHWC [B,Hin,Win,Cin]; w is repacked [Cout][3][3][Cin] (= weight
  * .permute(0,2,3,1)); out is NHWC [B,Hout,Wout,Cout] or, with out_nchw, NCHW [B,Cout,Hout,Wout]
@@ -119,7 +129,7 @@ int master_convert(const void* src, void* dst, size_t n, int src_dtype, int dst_
 enum master_kernel_family {
     MASTER_K_LINEAR = 0, MASTER_K_CONV = 1, MASTER_K_ATTN = 2, MASTER_K_LAYERNORM = 3,
     MASTER_K_INSTNORM = 4, MASTER_K_PATCH_EMBED = 5, MASTER_K_PATCH_MERGE = 6, MASTER_K_CONVERT = 7,
-    MASTER_K_COUNT = 8
+    MASTER_K_MLP = 8, MASTER_K_COUNT = 9
 };
 int master_prof_enable(int on);
 int master_prof_reset(void);

@@ -25,6 +25,8 @@ template <typename T> int layernorm_launch(const void*, const void*, const void*
 template <typename T> int instnorm_launch(const void*, void*, const void*, void*, int, int, int, int, float, hipStream_t);
 template <typename T> int patch_embed_launch(const float*, const void*, const void*, const void*, const void*, void*, int, int, int, float, hipStream_t);
 int convert_launch(const void*, void*, size_t, int, int, hipStream_t);
+int mlp_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const float*,
+             const bf16_t*, bf16_t*, int, int, int, int, int, int, float, hipStream_t);
 
 // ---- error string -------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -110,6 +112,20 @@ int master_linear_fwd(const void* a, const void* w, const void* bias, const void
                                 (const bf16_t*)r2, (bf16_t*)out, M, N, K, lda, ldo, ldr, act, s);
     master_set_error("linear: bad dtype %d", dtype);
     return MASTER_ERR_INVALID;
+}
+
+int master_mlp_fwd(const void* x, const float* ln_gamma, const float* ln_beta, const void* w1, const float* b1,
+                   const void* w2, const float* b2, const void* res, void* out, int M, int C, int HID, int ldx, int ldr,
+                   int ldo, float eps, int dtype, master_stream_t stream) {
+    REQUIRE(x && w1 && b1 && w2 && b2 && out, "mlp: null operand");
+    REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), "mlp: ln_gamma and ln_beta come together");
+    REQUIRE(M > 0 && C > 0 && HID > 0 && ldx >= C && ldo >= C && (res == nullptr || ldr >= C), "mlp: bad dims");
+    if (dtype != MASTER_BF16) { master_set_error("mlp: fused kernel is bf16-only; use two master_linear_fwd calls in fp32 mode"); return MASTER_ERR_UNSUPPORTED; }
+    REQUIRE(al16(x) && al16(w1) && al16(w2) && ldx % 8 == 0 && ldo % 4 == 0 && ldr % 4 == 0, "mlp: alignment (x/w 16 B, ldx%%8, ldo%%4, ldr%%4)");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_MLP, s);
+    return mlp_bf16((const bf16_t*)x, ln_gamma, ln_beta, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, (const bf16_t*)res,
+                    (bf16_t*)out, M, C, HID, ldx, ldr, ldo, eps, s);
 }
 
 int master_conv3x3_reflect_fwd(const void* x, const void* w, const void* bias, void* out, int B, int Hin, int Win,

@@ -9,14 +9,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));   // 8 bf16 bit patterns = one MFMA A/B fragment
 typedef unsigned short bf16_t;                               // raw bf16 bits
 
-__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
-// round-to-nearest-even; NaN handling left to the hardware convert the compiler picks for this cast
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // keep NaN a NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+// two fp32 -> packed bf16x2 (round-to-nearest-even, NaN preserved): one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    bf16x2_hw v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
 }
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.0f) & 0xffffu); }
 
 // erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7): one v_rcp, one v_exp, six FMAs.  libm's erff costs
 // ~40 VALU instructions per value, which made the GELU epilogue of the MLP's first GEMM VALU-bound.

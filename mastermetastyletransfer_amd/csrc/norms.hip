@@ -19,8 +19,8 @@ template <> struct Vec4<bf16_t> {
     }
     static __device__ __forceinline__ void store(bf16_t* p, f32x4 v) {
         uint2 u;
-        u.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-        u.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        u.x = pack_bf16x2(v[0], v[1]);
+        u.y = pack_bf16x2(v[2], v[3]);
         *(uint2*)p = u;
     }
 };
@@ -45,10 +45,8 @@ template <> struct Vec16<bf16_t> {
     }
     static __device__ __forceinline__ void store(bf16_t* p, const float* v) {
         uint4 u;
-        u.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-        u.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-        u.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
-        u.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+        u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]);
+        u.z = pack_bf16x2(v[4], v[5]); u.w = pack_bf16x2(v[6], v[7]);
         *(uint4*)p = u;
     }
 };

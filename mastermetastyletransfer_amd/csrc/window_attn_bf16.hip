@@ -30,9 +30,7 @@ struct AttnArgsB {
 
 constexpr float LOG2E = 1.4426950408889634f;
 
-__device__ __forceinline__ unsigned pack2(float lo, float hi) {
-    return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
-}
+__device__ __forceinline__ unsigned pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
 
 union Frag { u32x4 u; bf16x8_t b; };
 
@@ -143,19 +141,15 @@ __global__ __launch_bounds__(256) void window_attn_bf16_kernel(AttnArgsB p) {
         float sum = 0.0f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            float pe[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                // round first, then sum the rounded values: the normaliser matches what the MFMA multiplies
-                pe[e] = bf16_to_f32(f32_to_bf16(exp2f(st[kt][qt][e] - m)));
-                sum += pe[e];
-            }
+            // round to bf16 first, then sum the rounded values: the normaliser matches what the MFMA multiplies
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
-                    pf[qt][kt][s].u[jj] = (__float_as_uint(pe[8 * s + 2 * jj]) >> 16) |
-                                          (__float_as_uint(pe[8 * s + 2 * jj + 1]) & 0xffff0000u);
+                for (int jj = 0; jj < 4; ++jj) {
+                    const unsigned pk = pack_bf16x2(exp2f(st[kt][qt][8 * s + 2 * jj] - m), exp2f(st[kt][qt][8 * s + 2 * jj + 1] - m));
+                    pf[qt][kt][s].u[jj] = pk;
+                    sum += __uint_as_float(pk << 16) + __uint_as_float(pk & 0xffff0000u);
+                }
         }
         sum += __shfl_xor(sum, 32, 64);
         inv[qt] = 1.0f / sum;

@@ -88,10 +88,21 @@ def _init_mlp(mlp: nn.Sequential):
                 nn.init.normal_(m.bias, std=1e-6)
 
 
-def _mlp_fwd(owner: _HipModule, name: str, mlp: nn.Sequential, x: Tensor, residual: Optional[Tensor]) -> Tensor:
-    """residual + fc2(gelu(fc1(x)))   (torchvision MLP, call sites style_transformer.py:366,839-841,991)"""
-    h = ops.linear(x, owner._w(name + ".0", mlp[0].weight), owner._b(name + ".0", mlp[0].bias), act=ops.ACT_GELU)
-    return ops.linear(h, owner._w(name + ".3", mlp[3].weight), owner._b(name + ".3", mlp[3].bias), r2=residual)
+def _mlp_fwd(owner: _HipModule, name: str, mlp: nn.Sequential, x: Tensor, residual: Optional[Tensor],
+             norm: Optional[nn.LayerNorm] = None) -> Tensor:
+    """residual + fc2(gelu(fc1(norm?(x))))   (torchvision MLP, call sites style_transformer.py:366,839-841,991).
+    bf16 mode: one fused launch (hidden activations stay in registers, LayerNorm folded in);
+    fp32 mode: LayerNorm, GEMM+GELU, GEMM+residual."""
+    w1, b1 = owner._w(name + ".0", mlp[0].weight), owner._b(name + ".0", mlp[0].bias)
+    w2, b2 = owner._w(name + ".3", mlp[3].weight), owner._b(name + ".3", mlp[3].bias)
+    g = owner._b(name + ".ln_w", norm.weight) if norm is not None else None
+    b = owner._b(name + ".ln_b", norm.bias) if norm is not None else None
+    if ops.mlp_fused_supported(x, w1.shape[0]):
+        return ops.mlp(x, w1, b1, w2, b2, res=residual, ln_gamma=g, ln_beta=b, eps=norm.eps if norm is not None else EPS)
+    if norm is not None:
+        x = ops.layernorm(x, g, b, norm.eps)
+    h = ops.linear(x, w1, b1, act=ops.ACT_GELU)
+    return ops.linear(h, w2, b2, r2=residual)
 
 
 def _check_arch(dropout, attention_dropout, qkv_bias, proj_bias, act_layer, dim, heads):
@@ -249,7 +260,7 @@ class StyleSwinTransformerBlock(_HipModule):
             xq, xk, xvs = ln(xq), ln(xk), [ln(v) for v in xvs]
         outs = self.attn.attend(xq, xk, xvs, residuals, B, H, W)
         if not self.exclude_MLP_after:
-            outs = [_mlp_fwd(self, "mlp", self.mlp, self._ln("norm2", o) if self.use_norm else o, o) for o in outs]
+            outs = [_mlp_fwd(self, "mlp", self.mlp, o, o, norm=self.norm2 if self.use_norm else None) for o in outs]
         return outs
 
     def forward(self, input_q: Tensor, input_k: Tensor, input_v: Tensor, calculating_Key_in_encoder: bool = None) -> Tensor:
@@ -568,8 +579,7 @@ class SwinTransformerBlock(_HipModule):
     def run(self, x: Tensor, B, H, W) -> Tensor:
         n = ops.layernorm(x, self._b("n1w", self.norm1.weight), self._b("n1b", self.norm1.bias), self.norm1.eps)
         x = self.attn.attend(n, x, B, H, W)
-        n = ops.layernorm(x, self._b("n2w", self.norm2.weight), self._b("n2b", self.norm2.bias), self.norm2.eps)
-        return _mlp_fwd(self, "mlp", self.mlp, n, x)
+        return _mlp_fwd(self, "mlp", self.mlp, x, x, norm=self.norm2)
 
 
 class PatchMerging(_HipModule):

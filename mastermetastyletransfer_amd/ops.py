@@ -17,12 +17,12 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmaster_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
-K_FAMILIES = ("linear", "conv3x3", "window_attn", "layernorm", "instnorm", "patch_embed", "patch_merge", "convert")
+K_FAMILIES = ("linear", "conv3x3", "window_attn", "layernorm", "instnorm", "patch_embed", "patch_merge", "convert", "mlp")
 
 EXPORTS = (
     "master_version", "master_last_error_string", "master_linear_fwd", "master_conv3x3_reflect_fwd",
     "master_window_attn_fwd", "master_layernorm_fwd", "master_instnorm_fwd", "master_patch_embed_fwd",
-    "master_patch_merge_ln_fwd", "master_convert", "master_prof_enable", "master_prof_reset", "master_prof_read",
+    "master_patch_merge_ln_fwd", "master_convert", "master_mlp_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
 )
 
 _lib = None
@@ -78,6 +78,7 @@ def load_library() -> ctypes.CDLL:
     lib.master_patch_embed_fwd.argtypes = [vp] * 6 + [ci] * 4 + [cf, ci, vp]
     lib.master_patch_merge_ln_fwd.argtypes = [vp] * 4 + [ci] * 4 + [cf, ci, vp]
     lib.master_convert.argtypes = [vp, vp, ctypes.c_size_t, ci, ci, vp]
+    lib.master_mlp_fwd.argtypes = [vp] * 9 + [ci] * 6 + [cf, ci, vp]
     lib.master_prof_read.argtypes = [ci, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]
     _lib = lib
     return lib
@@ -137,6 +138,27 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
                bytes=es * (M * K + N * K + M * N * (1 + (r1 is not None) + (r2 is not None))))
     _check(load_library().master_linear_fwd(_p(a), _p(w), _p(bias), _p(r1), _p(r2), _p(out), M, N, K, a.stride(0),
                                              out.stride(0), ldr, act, _dt(a), _stream()), "master_linear_fwd")
+    return out
+
+
+def mlp_fused_supported(x: torch.Tensor, hidden: int) -> bool:
+    return x.dtype == torch.bfloat16 and x.shape[1] in (128, 256) and hidden % 128 == 0
+
+
+def mlp(x: torch.Tensor, w1, b1, w2, b2, res: Optional[torch.Tensor] = None, ln_gamma=None, ln_beta=None,
+        eps: float = 1e-5) -> torch.Tensor:
+    """res + fc2(gelu(fc1(LN?(x)))) in one launch (bf16 mode)."""
+    _dev(x, w1, w2)
+    M, C = x.shape
+    HID = w1.shape[0]
+    assert x.stride(1) == 1 and w1.is_contiguous() and w2.is_contiguous() and w1.shape == (HID, C) and w2.shape == (C, HID)
+    assert b1.dtype == torch.float32 and b2.dtype == torch.float32
+    out = torch.empty((M, C), dtype=x.dtype, device=x.device)
+    if _COUNT_ON:
+        _count("mlp", flops=4.0 * M * C * HID, bytes=x.element_size() * (M * C * (2 + (res is not None)) + 2 * C * HID))
+    _check(load_library().master_mlp_fwd(_p(x), _p(ln_gamma), _p(ln_beta), _p(w1), _p(b1), _p(w2), _p(b2), _p(res), _p(out),
+                                          M, C, HID, x.stride(0), res.stride(0) if res is not None else 0, out.stride(0),
+                                          eps, _dt(x), _stream()), "master_mlp_fwd")
     return out
 
 

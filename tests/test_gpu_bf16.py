@@ -106,3 +106,22 @@ def test_full_forward_bf16(cuda, B, S):
     m.set_compute_dtype(torch.float32)
     with torch.no_grad():
         assert (m(c.to(cuda), s.to(cuda), 1).cpu() - ref).abs().max() < 1e-3
+
+
+@pytest.mark.parametrize("M,C,HID,ln,res", [(128, 256, 1024, False, True), (1000, 256, 1024, True, True), (333, 128, 512, True, True),
+                                             (4096, 128, 512, False, False), (77, 256, 256, True, False)])
+def test_fused_mlp_bf16(cuda, M, C, HID, ln, res):
+    """one-launch LN -> fc1 -> GELU -> fc2 -> +residual against the same chain in fp32 on the bf16-rounded operands"""
+    from mastermetastyletransfer_amd import ops
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g).to(BF)
+    w1 = (torch.randn(HID, C, generator=g) / C ** 0.5).to(BF); b1 = torch.randn(HID, generator=g) * 0.5
+    w2 = (torch.randn(C, HID, generator=g) / HID ** 0.5).to(BF); b2 = torch.randn(C, generator=g) * 0.5
+    gw, gb = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    xin = F.layer_norm(x.float(), (C,), gw, gb, 1e-5) if ln else x.float()
+    ref = F.linear(F.gelu(F.linear(xin, w1.float(), b1)), w2.float(), b2) + (x.float() if res else 0)
+    xd = x.to(cuda)
+    out = ops.mlp(xd, w1.to(cuda), b1.to(cuda), w2.to(cuda), b2.to(cuda), res=xd if res else None,
+                  ln_gamma=gw.to(cuda) if ln else None, ln_beta=gb.to(cuda) if ln else None)
+    mx, l2 = rel_err(out, ref)
+    assert mx < 2e-2 and l2 < 6e-3, (mx, l2)       # hidden activations and the output are each rounded to bf16 once
