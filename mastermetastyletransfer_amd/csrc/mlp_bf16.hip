@@ -8,13 +8,18 @@
 //   phase 1   H^T[j][m] = sum_k W1[j][k] X[m][k]      A = W1 rows (LDS), B = X fragments (registers, loaded
 //                                                     once; LayerNorm applied in registers)
 //   phase 2   O^T[n][m] += sum_j W2[n][j] H^T[j][m]   A = W2 rows (LDS), B = the phase-1 accumulator tile
-//                                                     itself (bias+GELU, packed to bf16 in registers)
-// so the hidden activations never touch LDS or HBM: a 32x32 accumulator tile is a valid B operand whose
-// k order is j = 16s + 8(e>>2) + 4*half + (e&3); the W2 fragment is read in that order (two 8-byte LDS
-// reads).  Weights stream through a 2-slot LDS ring in 32-KB sub-chunks (global -> registers -> LDS, next
-// sub-chunk's loads in flight under 32 MFMAs per wave, one barrier per sub-chunk):
-//   W1 sub-chunk [128 j][128 k], rows padded to 272 B          -> conflict-free ds_read_b128
-//   W2 sub-chunk [C n][64 j], 128-B rows, 8-B units XOR-swizzled by (n>>1)&15 -> conflict-free ds_read_b64
+//                                                     (bias + GELU, packed to bf16 in registers)
+// so the hidden activations never touch LDS or HBM.  A 32x32 accumulator tile used as B operand has the k
+// order j = 16s + 8(e>>2) + 4*half + (e&3); two v_permlane32_swap per k-step exchange the middle quarters
+// between the half-waves and restore the natural order j = 16s + 8*half + e, so W2 is read exactly like W1.
+//
+// Weights stream through a 4-slot LDS ring in 32-KB steps by LDS-DMA (global_load_lds, 16 B per lane: no
+// VGPR destination, so the compiler cannot sink the prefetch below the MFMAs), issued three steps ahead and
+// retired with counted s_waitcnt vmcnt + a raw s_barrier (one barrier per step, 32 MFMAs per wave per step).
+// The DMA writes LDS linearly (wave-uniform base + lane*16), so bank conflicts are avoided by swizzling the
+// SOURCE: position p of a row holds source chunk p ^ f(row), and fragment reads apply the same XOR
+// (f = row&15 for 256-B rows, (row>>1)&7 for 128-B rows: every 16-lane ds_read_b128 group hits 16 distinct
+// 16-B slots).  The GELU of hidden chunk hc is sliced between the phase-1 MFMAs of chunk hc+1.
 #include "common.h"
 
 namespace {
@@ -30,29 +35,76 @@ struct MlpArgs {
     int M, HID, ldx, ldr, ldo; float eps;
 };
 
-union Frag { u32x4 u; bf16x8_t b; u32x2 h2[2]; };
+union Frag { u32x4 u; bf16x8_t b; };
 
-constexpr int SLOT_BYTES = 128 * 272;     // >= C*128 for C <= 256
-constexpr int W1_STRIDE = 272;            // bytes per padded W1 row (128 k)
+constexpr int SLOT = 32768;      // bytes per ring slot = one step of weights
+constexpr int RING = 4;          // slots
+constexpr int AHEAD = 3;         // steps of DMA in flight ahead of the one being consumed
+constexpr int DMA_PER_STEP = 8;  // global_load_lds instructions per wave per step (4 waves x 8 x 1 KB)
 
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) { return pack_bf16x2(lo, hi); }
+#define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
 template <int C>
 __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
-    constexpr int KS1 = C / 16;            // k-steps of phase 1 (all of K1 = C)
-    constexpr int KB = C / 128;            // W1 sub-chunks per hidden chunk
-    constexpr int NT2 = C / 32;            // output-channel tiles of phase 2
-    constexpr int W1_CH = 8;               // 16-B chunks per thread for a W1 sub-chunk (128 rows x 256 B)
-    constexpr int W2_CH = C * 128 / 16 / 256;   // 16-B chunks per thread for a W2 sub-chunk (C rows x 128 B)
-    constexpr int ST_CH = W1_CH > W2_CH ? W1_CH : W2_CH;
+    constexpr int KS1 = C / 16;                 // k-steps of phase 1 (K1 = C)
+    constexpr int KB = C / 128;                 // W1 steps per hidden chunk ([128 j][128 k] = 32 KB each)
+    constexpr int NT2 = C / 32;                 // output-channel tiles of phase 2
+    constexpr int S2 = C / 128;                 // W2 steps per hidden chunk: C=256 -> 2 x [256 n][64 j]; C=128 -> 1 x [128 n][128 j]
+    constexpr int JB2 = 128 / S2;               // hidden units per W2 step (64 or 128)
+    constexpr int ROW2 = JB2 * 2;               // bytes per W2 row in a slot (128 or 256)
+    constexpr int SPH = KB + S2;                // steps per hidden chunk
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];   // [2][SLOT_BYTES]
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [RING][SLOT] weights, then b1 as fp32[HID]
+    float* b1s = (float*)(lds + RING * SLOT);                              // [HID]
+    float* b2s = b1s + p.HID;                                              // [C]
+    float* lng = b2s + C;                                                  // [C] LayerNorm gamma
+    float* lnb = lng + C;                                                  // [C] LayerNorm beta
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int m = blockIdx.x * 128 + wave * 32 + r;
     const int mc = m < p.M ? m : p.M - 1;
     const int nhc = p.HID / 128;
+    const int T = KB + (nhc - 1) * SPH + S2;    // stream: W1(0) | W1(1) W2(0) | ... | W1(nhc-1) W2(nhc-2) | W2(nhc-1)
+
+    // ---- LDS-DMA of stream step t into ring slot t % RING ----------------------------------------------
+    auto issue = [&](int t) {
+        bool is_w1; int hc, idx;
+        if (t < KB) { is_w1 = true; hc = 0; idx = t; }
+        else {
+            const int u = t - KB, b = u / SPH, o = u - b * SPH;
+            if (b < nhc - 1 && o < KB) { is_w1 = true; hc = b + 1; idx = o; }
+            else { is_w1 = false; hc = b; idx = b < nhc - 1 ? o - KB : o; }
+        }
+        unsigned char* slot = lds + (t % RING) * SLOT;
+#pragma unroll
+        for (int i = 0; i < DMA_PER_STEP; ++i) {
+            const int I = wave * DMA_PER_STEP + i;                 // 1-KB piece of the slot
+            const bf16_t* src;
+            if (is_w1 || ROW2 == 256) {
+                const int row = 4 * I + (lane >> 4), q = (lane & 15) ^ (row & 15);
+                src = is_w1 ? p.w1 + (size_t)(hc * 128 + row) * C + idx * 128 + q * 8
+                            : p.w2 + (size_t)row * p.HID + hc * 128 + q * 8;
+            } else {
+                const int row = 8 * I + (lane >> 3), q = (lane & 7) ^ ((row >> 1) & 7);
+                src = p.w2 + (size_t)row * p.HID + hc * 128 + idx * 64 + q * 8;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(slot + I * 1024), 16, 0, 0);
+        }
+    };
+
+    int t_issue = 0;
+    for (; t_issue < AHEAD && t_issue < T; ++t_issue) issue(t_issue);
+
+    // small fp32 parameter vectors live in LDS: ordinary global loads inside the DMA pipeline would each be followed
+    // by a full vmcnt(0) drain
+    for (int i = tid; i < p.HID; i += 256) b1s[i] = p.b1[i];
+    if (tid < C) {
+        b2s[tid] = p.b2[tid];
+        if (p.ln_g) { lng[tid] = p.ln_g[tid]; lnb[tid] = p.ln_b[tid]; }
+    }
 
     // ---- X fragments (B operand of phase 1): lane (token m, half h) holds x[m][16s + 8h .. +8] ---------
     Frag xf[KS1];
@@ -60,6 +112,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
         const bf16_t* xp = p.x + (size_t)mc * p.ldx + 8 * h;
 #pragma unroll
         for (int s = 0; s < KS1; ++s) xf[s].u = *(const u32x4*)(xp + 16 * s);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                     // parameter vectors visible to every wave
         if (p.ln_g) {
             // LayerNorm over the C channels of token m: this lane holds half of them, lane^32 the rest
             float v[KS1][8];
@@ -83,7 +137,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
             const float rstd = rsqrtf(sq / (float)C + p.eps);
 #pragma unroll
             for (int s = 0; s < KS1; ++s) {
-                const float* gp = p.ln_g + 16 * s + 8 * h; const float* bp = p.ln_b + 16 * s + 8 * h;
+                const float* gp = lng + 16 * s + 8 * h; const float* bp = lnb + 16 * s + 8 * h;
                 const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4);
                 const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
                 float o[8];
@@ -93,160 +147,199 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
                     o[4 + e] = (v[s][4 + e] - mean) * rstd * g1[e] + b1[e];
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) xf[s].u[e] = pack_bf16(o[2 * e], o[2 * e + 1]);
+                for (int e = 0; e < 4; ++e) xf[s].u[e] = pack_bf16x2(o[2 * e], o[2 * e + 1]);
             }
         }
     }
 
-    // ---- weight streaming ------------------------------------------------------------------------------
-    u32x4 st[ST_CH];
-    auto load_w1 = [&](int hc, int kb) {          // rows j = hc*128 + c>>4, 16-B column c&15 of the 256-B k slice
-#pragma unroll
-        for (int i = 0; i < W1_CH; ++i) {
-            const int c = tid + 256 * i;
-            st[i] = *(const u32x4*)(p.w1 + (size_t)(hc * 128 + (c >> 4)) * C + kb * 128 + (c & 15) * 8);
-        }
-    };
-    auto store_w1 = [&](int slot) {
-#pragma unroll
-        for (int i = 0; i < W1_CH; ++i) {
-            const int c = tid + 256 * i;
-            *(u32x4*)(ring + slot * SLOT_BYTES + (c >> 4) * W1_STRIDE + (c & 15) * 16) = st[i];
-        }
-    };
-    auto load_w2 = [&](int hc, int sb) {          // rows n = c>>3, 16-B column c&7 of the 128-B j slice
-#pragma unroll
-        for (int i = 0; i < W2_CH; ++i) {
-            const int c = tid + 256 * i;
-            st[i] = *(const u32x4*)(p.w2 + (size_t)(c >> 3) * p.HID + hc * 128 + sb * 64 + (c & 7) * 8);
-        }
-    };
-    auto store_w2 = [&](int slot) {               // 8-B units swizzled: unit' = unit ^ ((n>>1)&15)
-#pragma unroll
-        for (int i = 0; i < W2_CH; ++i) {
-            const int c = tid + 256 * i;
-            const int n = c >> 3, u = (c & 7) * 2, f = (n >> 1) & 15;
-            unsigned char* rowp = ring + slot * SLOT_BYTES + n * 128;
-            u32x2 lo, hi; lo[0] = st[i][0]; lo[1] = st[i][1]; hi[0] = st[i][2]; hi[1] = st[i][3];
-            *(u32x2*)(rowp + ((u ^ f) * 8)) = lo;
-            *(u32x2*)(rowp + (((u + 1) ^ f) * 8)) = hi;
-        }
+    // ---- per-step synchronisation: my DMAs of step t have landed -> barrier -> everyone's have, and everyone
+    //      is done reading step t-1, whose slot is the one step t+AHEAD goes into -----------------------------
+    int t_cons = 0;
+    auto begin_step = [&]() {
+        const int ahead = t_issue - 1 - t_cons;             // steps issued beyond the one about to be consumed
+        if (ahead >= 2) WAIT_VMCNT(16); else if (ahead == 1) WAIT_VMCNT(8); else WAIT_VMCNT(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t_issue < T) { issue(t_issue); ++t_issue; }
+        const unsigned char* slot = lds + (t_cons % RING) * SLOT;
+        ++t_cons;
+        return slot;
     };
 
-    f32x16 oacc[NT2];
+    // GELU in the sigmoid form of the tanh approximation, x / (1 + exp(-2*sqrt(2/pi)*(x + 0.044715 x^3))):
+    // 7 VALU ops (one v_exp, one v_rcp).  |error| vs the exact erf form <= 5e-4, below bf16 resolution; the fp32
+    // parity mode keeps the erf form (common.h).
+    auto gelu_bf16 = [](float x) {
+        const float a = fmaf(x * x, -0.0713548163f * 1.4426950408889634f, -1.5957691216f * 1.4426950408889634f);
+        return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * a));
+    };
+
+    f32x16 hacc[4], hprev[4], oacc[NT2];
+    Frag hf[4][2];
 #pragma unroll
     for (int t = 0; t < NT2; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[t][e] = 0.f;
 
-    // phase-2 LDS byte offsets of this lane's two 8-B pieces per (jl, s): the swizzle term f = (n>>1)&15
-    // depends only on the row within a 32-row tile, so tile nt just adds nt*32*128 (an immediate)
-    int off0[2][2], off1[2][2];
+    // bias + GELU + pack of registers 8s..8s+7 of tile jt (one k-step of phase 2), then the half-wave exchange
+    // that turns the accumulator k order into the natural one
+    auto gelu_kstep = [&](int hc_prev, int jt, int s) {
+        unsigned u[4];
 #pragma unroll
-    for (int jl = 0; jl < 2; ++jl)
+        for (int g2 = 0; g2 < 2; ++g2) {
+            const int g = 2 * s + g2;
+            const f32x4 bv = *(const f32x4*)(b1s + hc_prev * 128 + jt * 32 + 8 * g + 4 * h);
+            float v[4];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int u0 = jl * 8 + 4 * s + h, f = (r >> 1) & 15;
-            off0[jl][s] = r * 128 + ((u0 ^ f) * 8);
-            off1[jl][s] = r * 128 + (((u0 + 2) ^ f) * 8);
+            for (int e = 0; e < 4; ++e) v[e] = gelu_bf16(hprev[jt][4 * g + e] + bv[e]);
+            u[2 * g2] = pack_bf16x2(v[0], v[1]);
+            u[2 * g2 + 1] = pack_bf16x2(v[2], v[3]);
         }
+        // half 0 keeps u0,u1 and takes the partner's u0,u1 as words 2,3; half 1 takes the partner's u2,u3 as words 0,1
+        auto sw0 = __builtin_amdgcn_permlane32_swap(u[0], u[2], false, false);
+        auto sw1 = __builtin_amdgcn_permlane32_swap(u[1], u[3], false, false);
+        hf[jt][s].u[0] = sw0[0]; hf[jt][s].u[2] = sw0[1];
+        hf[jt][s].u[1] = sw1[0]; hf[jt][s].u[3] = sw1[1];
+    };
 
-    int slot = 0;
-    load_w1(0, 0);
-    store_w1(0);
-    __syncthreads();
+    const int x256 = (h ^ (r & 15)) << 4;            // swizzle term for 256-B rows: chunk (2s+h) ^ (row&15)
+    const int x128 = (h ^ ((r >> 1) & 7)) << 4;      //                  128-B rows: chunk (2g+h) ^ ((row>>1)&7)
 
-    for (int hc = 0; hc < nhc; ++hc) {
-        // ================= phase 1: H^T chunk [128 j][32 m] =================
-        f32x16 hacc[4];
+    // Fragment reads are software-pipelined by hand.  With one wave per SIMD nothing else hides the LDS latency and
+    // hipcc collapses a source-level double buffer back into read -> wait -> MFMA, so the reads are inline asm (the
+    // compiler neither waits for nor moves them): the 4 (8) fragments of k-step s+1 are requested, a counted lgkmcnt
+    // retires exactly the fragments of k-step s (LDS returns in order), and a sched_barrier keeps the MFMAs below it.
+#define LDS_READ128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:" #imm : "=v"(dst) : "v"(addr))
+#define LGKM_WAIT(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    auto lds_off = [&](const unsigned char* ptr) { return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)ptr; };
+
+    auto phase1_step = [&](const unsigned char* slot, int kb, bool pipe, int hc_prev) {
+        const unsigned base = lds_off(slot) + r * 256;
+        u32x4 a[2][4];
+        auto rd = [&](int buf, int s) {
+            const unsigned ad = base + ((32 * s) ^ x256);
+            LDS_READ128(a[buf][0], ad, 0); LDS_READ128(a[buf][1], ad, 8192);
+            LDS_READ128(a[buf][2], ad, 16384); LDS_READ128(a[buf][3], ad, 24576);
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s + 1 < 8) { rd((s + 1) & 1, s + 1); LGKM_WAIT(4); } else { LGKM_WAIT(0); }
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                Frag f; f.u = a[s & 1][jt];
+                hacc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, xf[kb * 8 + s].b, hacc[jt], 0, 0, 0);
+            }
+            if (pipe) {
+                // 8 (tile, k-step) GELU slices per hidden chunk spread over the KB*8 MFMA groups of phase 1
+                const int i = kb * 8 + s;
+                if (KB == 2) { if ((i & 1) == 0) gelu_kstep(hc_prev, i >> 2, (i >> 1) & 1); }
+                else gelu_kstep(hc_prev, i >> 1, i & 1);
+            }
+        }
+    };
+    auto phase2_step = [&](const unsigned char* slot, int sb) {
+        constexpr int NG = ROW2 == 128 ? 4 : 8;                 // k-steps of 16 hidden units in this slot
+        const unsigned base = lds_off(slot) + r * ROW2;
+        const int xs = ROW2 == 128 ? x128 : x256;
+        u32x4 a[2][NT2];
+        auto rd = [&](int buf, int g) {
+            const unsigned ad = base + ((32 * g) ^ xs);
+            if (ROW2 == 128) {          // C = 256: 8 tiles of 32 rows x 128 B
+                LDS_READ128(a[buf][0], ad, 0); LDS_READ128(a[buf][1], ad, 4096); LDS_READ128(a[buf][2], ad, 8192);
+                LDS_READ128(a[buf][3], ad, 12288);
+                if (NT2 > 4) {
+                    LDS_READ128(a[buf][NT2 > 4 ? 4 : 0], ad, 16384); LDS_READ128(a[buf][NT2 > 4 ? 5 : 0], ad, 20480);
+                    LDS_READ128(a[buf][NT2 > 4 ? 6 : 0], ad, 24576); LDS_READ128(a[buf][NT2 > 4 ? 7 : 0], ad, 28672);
+                }
+            } else {                    // C = 128: 4 tiles of 32 rows x 256 B
+                LDS_READ128(a[buf][0], ad, 0); LDS_READ128(a[buf][1], ad, 8192);
+                LDS_READ128(a[buf][2], ad, 16384); LDS_READ128(a[buf][3], ad, 24576);
+            }
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) {
+                rd((g + 1) & 1, g + 1);
+                if (NT2 == 8) LGKM_WAIT(8); else LGKM_WAIT(4);
+            } else { LGKM_WAIT(0); }
+            const int jt = ROW2 == 128 ? sb * 2 + (g >> 1) : (g >> 1);
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt) {
+                Frag f; f.u = a[g & 1][nt];
+                oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, hf[jt][g & 1].b, oacc[nt], 0, 0, 0);
+            }
+        }
+    };
+    auto zero_hacc = [&]() {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) hacc[t][e] = 0.f;
+    };
+
+    // prologue: phase 1 of chunk 0
+    zero_hacc();
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            const bool next_is_w1 = kb + 1 < KB;
-            if (next_is_w1) load_w1(hc, kb + 1); else load_w2(hc, 0);
-            const unsigned char* base = ring + slot * SLOT_BYTES + r * W1_STRIDE + 16 * h;
+    for (int kb = 0; kb < KB; ++kb) phase1_step(begin_step(), kb, false, 0);
+
+    for (int hc = 0; hc < nhc; ++hc) {
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                Frag a[4];
+        for (int t = 0; t < 4; ++t) hprev[t] = hacc[t];
+        if (hc + 1 < nhc) {
+            zero_hacc();
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt) a[jt].u = *(const u32x4*)(base + jt * 32 * W1_STRIDE + 32 * s);
+            for (int kb = 0; kb < KB; ++kb) phase1_step(begin_step(), kb, true, hc);     // + GELU(hc) in the gaps
+        } else {
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt)
-                    hacc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[jt].b, xf[kb * 8 + s].b, hacc[jt], 0, 0, 0);
-            }
-            if (next_is_w1) store_w1(slot ^ 1); else store_w2(slot ^ 1);
-            __syncthreads();
-            slot ^= 1;
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) gelu_kstep(hc, jt, s);
         }
-        // bias + GELU, packed in place as the B fragments of phase 2: tile jt, k-step s <- registers 8s..8s+7
-        Frag hf[4][2];
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 bv = *(const f32x4*)(p.b1 + hc * 128 + jt * 32 + 8 * g + 4 * h);
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(hacc[jt][4 * g + e] + bv[e]);
-                hf[jt][g >> 1].u[(g & 1) * 2] = pack_bf16(v[0], v[1]);
-                hf[jt][g >> 1].u[(g & 1) * 2 + 1] = pack_bf16(v[2], v[3]);
-            }
-        // ================= phase 2: O^T[C n][32 m] += W2[:, chunk] H^T =================
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb) {
-            const bool last = (sb == 1) && (hc + 1 == nhc);
-            if (sb == 0) load_w2(hc, 1); else if (!last) load_w1(hc + 1, 0);
-            const unsigned char* base = ring + slot * SLOT_BYTES;
-#pragma unroll
-            for (int jl = 0; jl < 2; ++jl)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-#pragma unroll
-                    for (int nt = 0; nt < NT2; ++nt) {
-                        Frag a;
-                        a.h2[0] = *(const u32x2*)(base + nt * 4096 + off0[jl][s]);
-                        a.h2[1] = *(const u32x2*)(base + nt * 4096 + off1[jl][s]);
-                        oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b, hf[sb * 2 + jl][s].b, oacc[nt], 0, 0, 0);
-                    }
-                }
-            if (sb == 0) store_w2(slot ^ 1); else if (!last) store_w1(slot ^ 1);
-            __syncthreads();
-            slot ^= 1;
-        }
+        for (int sb = 0; sb < S2; ++sb) phase2_step(begin_step(), sb);
     }
 
-    // ---- epilogue: O^T tile: lane = token m, registers = channels n = nt*32 + (e&3) + 8(e>>2) + 4h -----
+    // ---- epilogue: O^T tile: lane = token m, registers = channels n = nt*32 + (e&3) + 8(e>>2) + 4h.  All residual
+    //      loads are issued before the first store (out may alias res, so the compiler would otherwise serialise
+    //      load -> wait -> store 32 times).
     if (m < p.M) {
+        u32x2 rr[NT2][4];
+        if (p.res) {
+            const bf16_t* rp = p.res + (size_t)m * p.ldr + 4 * h;
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rr[nt][g] = *(const u32x2*)(rp + nt * 32 + 8 * g);
+        }
+        bf16_t* op = p.out + (size_t)m * p.ldo + 4 * h;
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = nt * 32 + 8 * g + 4 * h;
-                const f32x4 bv = *(const f32x4*)(p.b2 + n);
+                const f32x4 bv = *(const f32x4*)(b2s + nt * 32 + 8 * g + 4 * h);
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = oacc[nt][4 * g + e] + bv[e];
                 if (p.res) {
-                    const u32x2 rr = *(const u32x2*)(p.res + (size_t)m * p.ldr + n);
-                    v[0] += __uint_as_float(rr[0] << 16); v[1] += __uint_as_float(rr[0] & 0xffff0000u);
-                    v[2] += __uint_as_float(rr[1] << 16); v[3] += __uint_as_float(rr[1] & 0xffff0000u);
+                    v[0] += __uint_as_float(rr[nt][g][0] << 16); v[1] += __uint_as_float(rr[nt][g][0] & 0xffff0000u);
+                    v[2] += __uint_as_float(rr[nt][g][1] << 16); v[3] += __uint_as_float(rr[nt][g][1] & 0xffff0000u);
                 }
-                u32x2 o; o[0] = pack_bf16(v[0], v[1]); o[1] = pack_bf16(v[2], v[3]);
-                *(u32x2*)(p.out + (size_t)m * p.ldo + n) = o;
+                u32x2 o; o[0] = pack_bf16x2(v[0], v[1]); o[1] = pack_bf16x2(v[2], v[3]);
+                *(u32x2*)(op + nt * 32 + 8 * g) = o;
             }
     }
 }
 
 template <int C>
 int launch(const MlpArgs& p, hipStream_t s) {
-    const size_t lds = 2 * SLOT_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    const size_t lds = (size_t)RING * SLOT + (size_t)(p.HID + 3 * C) * sizeof(float);
+    if (lds > 160 * 1024) { master_set_error("mlp: hidden width %d needs %zu B of LDS", p.HID, lds); return MASTER_ERR_UNSUPPORTED; }
+    static size_t attr_set = 0;
+    if (attr_set < lds) {
         (void)hipFuncSetAttribute((const void*)mlp_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+        attr_set = lds;
     }
     hipLaunchKernelGGL((mlp_bf16_kernel<C>), dim3((p.M + 127) / 128), dim3(256), lds, s, p);
     return master_check_launch("mlp_bf16");
