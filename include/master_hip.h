@@ -73,6 +73,14 @@ int master_conv3x3_reflect_fwd(const void* x, const void* w, const void* bias, v
                                int Win, int Cin, int Cout, int upsample, int relu, int out_nchw, int dtype,
                                master_stream_t stream);
 
+/* Decoder tail in one launch: nearest x2 upsample -> Conv3x3(32->32, reflect) + ReLU -> Conv3x3(32->3, reflect).
+ * x: NHWC [B,Hs,Ws,32]; w8 [32][3][3][32], w9 [3][3][3][32] repacked like master_conv3x3_reflect_fwd; b8, b9 fp32;
+ * out: fp32 NCHW [B,3,2Hs,2Ws] (the model output).  The 32-channel full-resolution intermediate never leaves LDS.
+ * Replaces the last four layers of decoder.py:47-54.  MASTER_BF16 only, 2Hs % 16 == 0 and 2Ws % 32 == 0
+ * (MASTER_ERR_UNSUPPORTED otherwise: callers then use two master_conv3x3_reflect_fwd calls). */
+int master_decoder_tail_fwd(const void* x, const void* w8, const float* b8, const void* w9, const float* b9, float* out,
+                            int B, int Hs, int Ws, int dtype, master_stream_t stream);
+
 /* Windowed multi-head attention core for one or two value streams sharing one softmax.
  * For batch b, window w, head h:   S = scale * Q K^T + bias[h] + mask(w);  P = softmax(S);
  * out_s = P V_s  (s = 0, and 1 when v1 != NULL), written for real (non-padded) query tokens only.
@@ -129,7 +137,7 @@ int master_convert(const void* src, void* dst, size_t n, int src_dtype, int dst_
 enum master_kernel_family {
     MASTER_K_LINEAR = 0, MASTER_K_CONV = 1, MASTER_K_ATTN = 2, MASTER_K_LAYERNORM = 3,
     MASTER_K_INSTNORM = 4, MASTER_K_PATCH_EMBED = 5, MASTER_K_PATCH_MERGE = 6, MASTER_K_CONVERT = 7,
-    MASTER_K_MLP = 8, MASTER_K_COUNT = 9
+    MASTER_K_MLP = 8, MASTER_K_DECODER_TAIL = 9, MASTER_K_COUNT = 10
 };
 int master_prof_enable(int on);
 int master_prof_reset(void);

@@ -25,6 +25,7 @@ template <typename T> int layernorm_launch(const void*, const void*, const void*
 template <typename T> int instnorm_launch(const void*, void*, const void*, void*, int, int, int, int, float, hipStream_t);
 template <typename T> int patch_embed_launch(const float*, const void*, const void*, const void*, const void*, void*, int, int, int, float, hipStream_t);
 int convert_launch(const void*, void*, size_t, int, int, hipStream_t);
+int conv_tail_bf16(const bf16_t*, const bf16_t*, const float*, const bf16_t*, const float*, float*, int, int, int, hipStream_t);
 int mlp_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const float*,
              const bf16_t*, bf16_t*, int, int, int, int, int, int, float, hipStream_t);
 
@@ -146,6 +147,16 @@ int master_conv3x3_reflect_fwd(const void* x, const void* w, const void* bias, v
                                  upsample, relu, out_nchw, s);
     master_set_error("conv3x3: bad dtype %d", dtype);
     return MASTER_ERR_INVALID;
+}
+
+int master_decoder_tail_fwd(const void* x, const void* w8, const float* b8, const void* w9, const float* b9, float* out,
+                            int B, int Hs, int Ws, int dtype, master_stream_t stream) {
+    REQUIRE(x && w8 && b8 && w9 && b9 && out, "decoder_tail: null operand");
+    REQUIRE(B > 0 && Hs > 0 && Ws > 0 && al16(x) && al16(w8) && al16(w9), "decoder_tail: bad dims/alignment");
+    if (dtype != MASTER_BF16) { master_set_error("decoder_tail: fused kernel is bf16-only; use master_conv3x3_reflect_fwd in fp32 mode"); return MASTER_ERR_UNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_DECODER_TAIL, s);
+    return conv_tail_bf16((const bf16_t*)x, (const bf16_t*)w8, b8, (const bf16_t*)w9, b9, out, B, Hs, Ws, s);
 }
 
 int master_window_attn_fwd(const void* q, const void* k, const void* v0, const void* v1, int ldq, int ldk, int ldv,

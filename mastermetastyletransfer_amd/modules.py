@@ -532,12 +532,19 @@ class Decoder(_HipModule):
 
     def run_nhwc(self, x: Tensor) -> Tensor:
         """x: NHWC [B,H,W,C] in the compute dtype -> fp32 NCHW image [B,3,8H,8W]"""
-        last = self.CONV_IDX[-1]
+        last, prev = self.CONV_IDX[-1], self.CONV_IDX[-2]
+
+        def packed(i):
+            conv = self.decoder[i]
+            return self._derived(f"conv{i}", [conv.weight],
+                                 lambda: ops.convert(conv.weight.detach().permute(0, 2, 3, 1).contiguous(), self.compute_dtype))
         for i in self.CONV_IDX:
             conv = self.decoder[i]
-            w = self._derived(f"conv{i}", [conv.weight],
-                              lambda conv=conv: ops.convert(conv.weight.detach().permute(0, 2, 3, 1).contiguous(), self.compute_dtype))
-            x = ops.conv3x3_reflect(x, w, self._b(f"conv{i}", conv.bias), upsample=i in self.UPSAMPLE_BEFORE,
+            if i == prev and prev in self.UPSAMPLE_BEFORE and ops.decoder_tail_supported(x, conv.out_channels):
+                # bf16 mode: Upsample + Conv(32->32) + ReLU + Conv(32->3) in one launch, intermediate kept in LDS
+                return ops.decoder_tail(x, packed(prev), self._b(f"conv{prev}", conv.bias), packed(last),
+                                        self._b(f"conv{last}", self.decoder[last].bias))
+            x = ops.conv3x3_reflect(x, packed(i), self._b(f"conv{i}", conv.bias), upsample=i in self.UPSAMPLE_BEFORE,
                                     relu=i != last, out_nchw=i == last)
         return x
 

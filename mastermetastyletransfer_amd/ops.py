@@ -17,12 +17,12 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmaster_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
-K_FAMILIES = ("linear", "conv3x3", "window_attn", "layernorm", "instnorm", "patch_embed", "patch_merge", "convert", "mlp")
+K_FAMILIES = ("linear", "conv3x3", "window_attn", "layernorm", "instnorm", "patch_embed", "patch_merge", "convert", "mlp", "decoder_tail")
 
 EXPORTS = (
     "master_version", "master_last_error_string", "master_linear_fwd", "master_conv3x3_reflect_fwd",
     "master_window_attn_fwd", "master_layernorm_fwd", "master_instnorm_fwd", "master_patch_embed_fwd",
-    "master_patch_merge_ln_fwd", "master_convert", "master_mlp_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
+    "master_patch_merge_ln_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
 )
 
 _lib = None
@@ -79,6 +79,7 @@ def load_library() -> ctypes.CDLL:
     lib.master_patch_merge_ln_fwd.argtypes = [vp] * 4 + [ci] * 4 + [cf, ci, vp]
     lib.master_convert.argtypes = [vp, vp, ctypes.c_size_t, ci, ci, vp]
     lib.master_mlp_fwd.argtypes = [vp] * 9 + [ci] * 6 + [cf, ci, vp]
+    lib.master_decoder_tail_fwd.argtypes = [vp] * 6 + [ci] * 4 + [vp]
     lib.master_prof_read.argtypes = [ci, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]
     _lib = lib
     return lib
@@ -180,6 +181,24 @@ def conv3x3_reflect(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor,
     _check(load_library().master_conv3x3_reflect_fwd(_p(x), _p(w_packed), _p(bias), _p(out), B, H, W, Cin, Cout,
                                                       int(upsample), int(relu), int(out_nchw), _dt(x), _stream()),
            "master_conv3x3_reflect_fwd")
+    return out
+
+
+def decoder_tail_supported(x: torch.Tensor, cout_mid: int) -> bool:
+    B, H, W, C = x.shape
+    return x.dtype == torch.bfloat16 and C == 32 and cout_mid == 32 and (2 * H) % 16 == 0 and (2 * W) % 32 == 0
+
+
+def decoder_tail(x: torch.Tensor, w8, b8, w9, b9) -> torch.Tensor:
+    """x NHWC [B,Hs,Ws,32] bf16 -> fp32 NCHW [B,3,2Hs,2Ws]: upsample, conv 32->32 + ReLU, conv 32->3 in one launch."""
+    _dev(x, w8, w9)
+    B, H, W, C = x.shape
+    assert x.is_contiguous() and w8.is_contiguous() and w9.is_contiguous() and w8.shape == (32, 3, 3, 32) and w9.shape == (3, 3, 3, 32)
+    out = torch.empty((B, 3, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    if _COUNT_ON:
+        _count("decoder_tail", flops=2.0 * B * 4 * H * W * 9 * 32 * (32 + 3), bytes=2.0 * x.numel() + 4.0 * out.numel())
+    _check(load_library().master_decoder_tail_fwd(_p(x), _p(w8), _p(b8), _p(w9), _p(b9), _p(out), B, H, W, _dt(x), _stream()),
+           "master_decoder_tail_fwd")
     return out
 
 

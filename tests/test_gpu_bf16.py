@@ -125,3 +125,21 @@ def test_fused_mlp_bf16(cuda, M, C, HID, ln, res):
                   ln_gamma=gw.to(cuda) if ln else None, ln_beta=gb.to(cuda) if ln else None)
     mx, l2 = rel_err(out, ref)
     assert mx < 2e-2 and l2 < 6e-3, (mx, l2)       # hidden activations and the output are each rounded to bf16 once
+
+
+@pytest.mark.parametrize("B,Hs,Ws", [(1, 8, 16), (2, 16, 16), (1, 64, 48)])
+def test_decoder_tail_bf16(cuda, B, Hs, Ws):
+    """Upsample + Conv(32->32, reflect) + ReLU + Conv(32->3, reflect) in one launch vs the torch chain (border tiles,
+    interior tiles, non-square images); the intermediate is rounded to bf16 like the two-kernel path does."""
+    from mastermetastyletransfer_amd import ops
+    g = torch.Generator().manual_seed(Hs * 3 + Ws)
+    x = torch.randn(B, 32, Hs, Ws, generator=g).to(BF)
+    w8 = (torch.randn(32, 32, 3, 3, generator=g) / 17).to(BF); b8 = torch.randn(32, generator=g) * 0.3
+    w9 = (torch.randn(3, 32, 3, 3, generator=g) / 17).to(BF); b9 = torch.randn(3, generator=g) * 0.3
+    y = F.relu(F.conv2d(F.pad(F.interpolate(x.float(), scale_factor=2, mode="nearest"), (1, 1, 1, 1), mode="reflect"), w8.float(), b8))
+    ref = F.conv2d(F.pad(y.to(BF).float(), (1, 1, 1, 1), mode="reflect"), w9.float(), b9)
+    out = ops.decoder_tail(x.permute(0, 2, 3, 1).contiguous().to(cuda), w8.permute(0, 2, 3, 1).contiguous().to(cuda), b8.to(cuda),
+                           w9.permute(0, 2, 3, 1).contiguous().to(cuda), b9.to(cuda))
+    assert out.shape == ref.shape and out.dtype == torch.float32
+    mx, l2 = rel_err(out, ref)
+    assert mx < 5e-3 and l2 < 2e-3, (mx, l2)
