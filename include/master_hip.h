@@ -53,6 +53,14 @@ int master_linear_fwd(const void* a, const void* w, const void* bias, const void
                       void* out, int M, int N, int K, int lda, int ldo, int ldr, int act, int dtype,
                       master_stream_t stream);
 
+/* master_linear_fwd with the block's LayerNorm folded in:  out = r1 (.) (LayerNorm(x) . w^T + bias) + r2, one launch
+ * (norm1 + the fused qkv projection of a Swin / StyleSwinTransformerBlock: style_transformer.py:390, :114-116).
+ * ln_gamma/ln_beta fp32 [K].  MASTER_BF16 only, K in {128,256,512}, N % 128 == 0, residuals only for N <= 256
+ * (MASTER_ERR_UNSUPPORTED otherwise: callers then run master_layernorm_fwd + master_linear_fwd). */
+int master_linear_ln_fwd(const void* x, const float* ln_gamma, const float* ln_beta, const void* w, const void* bias,
+                         const void* r1, const void* r2, void* out, int M, int N, int K, int ldx, int ldo, int ldr,
+                         float eps, int dtype, master_stream_t stream);
+
 /* Fused MLP block:  out[M,C] = res + W2 . gelu(W1 . LN?(x) + b1) + b2   in ONE launch; the hidden
  * activations stay in registers.  x, res, out: [M,C] token matrices (row strides ldx/ldr/ldo); w1 [HID,C],
  * w2 [C,HID] as nn.Linear stores them; b1, b2, ln_gamma, ln_beta fp32; ln_gamma == NULL skips the LayerNorm;

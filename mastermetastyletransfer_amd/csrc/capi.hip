@@ -25,6 +25,8 @@ template <typename T> int layernorm_launch(const void*, const void*, const void*
 template <typename T> int instnorm_launch(const void*, void*, const void*, void*, int, int, int, int, float, hipStream_t);
 template <typename T> int patch_embed_launch(const float*, const void*, const void*, const void*, const void*, void*, int, int, int, float, hipStream_t);
 int convert_launch(const void*, void*, size_t, int, int, hipStream_t);
+int linear_ts_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const bf16_t*, bf16_t*,
+                   int, int, int, int, int, int, float, hipStream_t);
 int conv_tail_bf16(const bf16_t*, const bf16_t*, const float*, const bf16_t*, const float*, float*, int, int, int, hipStream_t);
 int mlp_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const float*,
              const bf16_t*, bf16_t*, int, int, int, int, int, int, float, hipStream_t);
@@ -108,11 +110,33 @@ int master_linear_fwd(const void* a, const void* w, const void* bias, const void
     if (dtype == MASTER_F32)
         return gemm_f32_linear((const float*)a, (const float*)w, (const float*)bias, (const float*)r1,
                                (const float*)r2, (float*)out, M, N, K, lda, ldo, ldr, act, s);
-    if (dtype == MASTER_BF16)
+    if (dtype == MASTER_BF16) {
+        if (act == MASTER_ACT_NONE && ldo % 4 == 0 && (ldr % 4 == 0)) {
+            // token-stationary kernel (weights streamed by LDS-DMA) where it applies, tiled GEMM otherwise
+            const int rc = linear_ts_bf16((const bf16_t*)a, nullptr, nullptr, (const bf16_t*)w, (const float*)bias,
+                                          (const bf16_t*)r1, (const bf16_t*)r2, (bf16_t*)out, M, N, K, lda, ldr, ldo, 0.f, s);
+            if (rc != MASTER_ERR_UNSUPPORTED) return rc;
+        }
         return gemm_bf16_linear((const bf16_t*)a, (const bf16_t*)w, (const float*)bias, (const bf16_t*)r1,
                                 (const bf16_t*)r2, (bf16_t*)out, M, N, K, lda, ldo, ldr, act, s);
+    }
     master_set_error("linear: bad dtype %d", dtype);
     return MASTER_ERR_INVALID;
+}
+
+int master_linear_ln_fwd(const void* x, const float* ln_gamma, const float* ln_beta, const void* w, const void* bias,
+                         const void* r1, const void* r2, void* out, int M, int N, int K, int ldx, int ldo, int ldr,
+                         float eps, int dtype, master_stream_t stream) {
+    REQUIRE(x && ln_gamma && ln_beta && w && out, "linear_ln: null operand");
+    REQUIRE(M > 0 && N > 0 && K > 0 && ldx >= K && ldo >= N && ((r1 == nullptr && r2 == nullptr) || ldr >= N), "linear_ln: bad dims");
+    if (dtype != MASTER_BF16) { master_set_error("linear_ln: fused kernel is bf16-only; use master_layernorm_fwd + master_linear_fwd"); return MASTER_ERR_UNSUPPORTED; }
+    REQUIRE(al16(x) && al16(w) && ldx % 8 == 0 && ldo % 4 == 0 && ldr % 4 == 0, "linear_ln: alignment");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_LINEAR, s);
+    const int rc = linear_ts_bf16((const bf16_t*)x, ln_gamma, ln_beta, (const bf16_t*)w, (const float*)bias, (const bf16_t*)r1,
+                                  (const bf16_t*)r2, (bf16_t*)out, M, N, K, ldx, ldr, ldo, eps, s);
+    if (rc == MASTER_ERR_UNSUPPORTED) master_set_error("linear_ln: shape M=%d N=%d K=%d not covered by the fused kernel", M, N, K);
+    return rc;
 }
 
 int master_mlp_fwd(const void* x, const float* ln_gamma, const float* ln_beta, const void* w1, const float* b1,

@@ -1,0 +1,237 @@
+// Token-stationary Linear, bf16 throughput mode:   out[M,N] = r1 (.) (LN?(x) . W^T + bias) + r2
+// (the q/k/v/proj projections and PatchMerging's reduction: reference style_transformer.py:114-116,156,
+//  515-517,576,595 and the fused qkv of the Swin blocks; LayerNorm = norm1 of the block, folded in).
+//
+// Same machinery as the fused MLP (mlp_bf16.hip), minus its second phase.  One workgroup = 128 tokens, 4 waves,
+// wave w owns tokens [32w, 32w+32).  The product is computed transposed, O^T[n][m] = sum_k W[n][k] X[m][k]:
+// the token sits on the MFMA lane, the X fragments of the whole row (K <= 512) stay in registers for the entire
+// kernel (LayerNorm applied there), and the weight matrix is the only thing that streams - 32-KB steps
+// ([128 n][128 k]) through a 4-slot LDS ring by LDS-DMA, three steps ahead, counted vmcnt + one raw barrier per
+// step, source-swizzled so the fragment ds_read_b128 are conflict-free.  Output columns are produced in chunks of
+// 128; a chunk's epilogue (bias, r1, r2, bf16 stores) runs while the next chunks' weights are already in flight.
+// Residual operands (N <= 256) are fetched once up front, so the loop contains no ordinary global load.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+struct LinArgs {
+    const bf16_t* x; const float* ln_g; const float* ln_b; const bf16_t* w; const float* bias;
+    const bf16_t* r1; const bf16_t* r2; bf16_t* out;
+    int M, N, ldx, ldr, ldo; float eps;
+};
+
+union Frag { u32x4 u; bf16x8_t b; };
+
+constexpr int SLOT = 32768, RING = 4, AHEAD = 3, DMA_PER_STEP = 8;
+
+#define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define LDS_READ128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:" #imm : "=v"(dst) : "v"(addr))
+#define LGKM_WAIT(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+template <int K, bool RES>
+__global__ __launch_bounds__(256, 1) void linear_ts_bf16_kernel(LinArgs p) {
+    constexpr int KS = K / 16;                  // k-steps over the whole row
+    constexpr int KB = K / 128;                 // 32-KB weight steps per 128-column chunk
+    constexpr int RT = RES ? 8 : 1;             // residual tiles held in registers (N <= 256)
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [RING][SLOT] weights | bias[N] | ln_g[K] | ln_b[K]
+    float* bs = (float*)(lds + RING * SLOT);
+    float* lng = bs + p.N;
+    float* lnb = lng + K;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int m = blockIdx.x * 128 + wave * 32 + r;
+    const int mc = m < p.M ? m : p.M - 1;
+    const int nch = p.N / 128;
+    const int T = nch * KB;
+
+    auto issue = [&](int t) {
+        const int nc = t / KB, kb = t - nc * KB;
+        unsigned char* slot = lds + (t % RING) * SLOT;
+#pragma unroll
+        for (int i = 0; i < DMA_PER_STEP; ++i) {
+            const int I = wave * DMA_PER_STEP + i;
+            const int row = 4 * I + (lane >> 4), q = (lane & 15) ^ (row & 15);     // source swizzle (see mlp_bf16.hip)
+            const bf16_t* src = p.w + (size_t)(nc * 128 + row) * K + kb * 128 + q * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(slot + I * 1024), 16, 0, 0);
+        }
+    };
+    int t_issue = 0;
+    for (; t_issue < AHEAD && t_issue < T; ++t_issue) issue(t_issue);
+
+    for (int i = tid; i < p.N; i += 256) bs[i] = p.bias ? p.bias[i] : 0.f;
+    if (p.ln_g) for (int i = tid; i < K; i += 256) { lng[i] = p.ln_g[i]; lnb[i] = p.ln_b[i]; }
+
+    // residual operands of this lane: token m, channels nt*32 + 8g + 4h .. +3
+    u32x2 rr1[RT][4], rr2[RT][4];
+    if (RES) {
+#pragma unroll
+        for (int nt = 0; nt < RT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                rr1[nt][g] = u32x2{0u, 0u}; rr2[nt][g] = u32x2{0u, 0u};
+                if (nt * 32 < p.N) {
+                    const size_t off = (size_t)mc * p.ldr + nt * 32 + 8 * g + 4 * h;
+                    if (p.r1) rr1[nt][g] = *(const u32x2*)(p.r1 + off);
+                    if (p.r2) rr2[nt][g] = *(const u32x2*)(p.r2 + off);
+                }
+            }
+    }
+
+    Frag xf[KS];
+    {
+        const bf16_t* xp = p.x + (size_t)mc * p.ldx + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xf[s].u = *(const u32x4*)(xp + 16 * s);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (p.ln_g) {
+            float sum = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    sum += __uint_as_float(xf[s].u[e] << 16) + __uint_as_float(xf[s].u[e] & 0xffff0000u);
+            sum += __shfl_xor(sum, 32, 64);
+            const float mean = sum / (float)K;
+            float sq = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d0 = __uint_as_float(xf[s].u[e] << 16) - mean, d1 = __uint_as_float(xf[s].u[e] & 0xffff0000u) - mean;
+                    sq += d0 * d0 + d1 * d1;
+                }
+            sq += __shfl_xor(sq, 32, 64);
+            const float rstd = rsqrtf(sq / (float)K + p.eps);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const float* gp = lng + 16 * s + 8 * h; const float* bp = lnb + 16 * s + 8 * h;
+                const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4), b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    o[2 * e] = (__uint_as_float(xf[s].u[e] << 16) - mean) * rstd * g0[2 * e] + b0[2 * e];
+                    o[2 * e + 1] = (__uint_as_float(xf[s].u[e] & 0xffff0000u) - mean) * rstd * g0[2 * e + 1] + b0[2 * e + 1];
+                    o[4 + 2 * e] = (__uint_as_float(xf[s].u[2 + e] << 16) - mean) * rstd * g1[2 * e] + b1[2 * e];
+                    o[5 + 2 * e] = (__uint_as_float(xf[s].u[2 + e] & 0xffff0000u) - mean) * rstd * g1[2 * e + 1] + b1[2 * e + 1];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xf[s].u[e] = pack_bf16x2(o[2 * e], o[2 * e + 1]);
+            }
+        }
+    }
+
+    int t_cons = 0;
+    auto begin_step = [&]() {
+        // conservative count: stores of the previous chunk's epilogue are younger than every DMA, so "at most 16 (8)
+        // outstanding" still implies the DMAs of step t_cons have landed
+        const int ahead = t_issue - 1 - t_cons;
+        if (ahead >= 2) WAIT_VMCNT(16); else if (ahead == 1) WAIT_VMCNT(8); else WAIT_VMCNT(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t_issue < T) { issue(t_issue); ++t_issue; }
+        const unsigned char* slot = lds + (t_cons % RING) * SLOT;
+        ++t_cons;
+        return slot;
+    };
+    auto lds_off = [&](const unsigned char* ptr) { return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)ptr; };
+    const int x256 = (h ^ (r & 15)) << 4;
+
+    f32x16 acc[4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    };
+    auto step = [&](const unsigned char* slot, int kb) {
+        const unsigned base = lds_off(slot) + r * 256;
+        u32x4 a[2][4];
+        auto rd = [&](int buf, int s) {
+            const unsigned ad = base + ((32 * s) ^ x256);
+            LDS_READ128(a[buf][0], ad, 0); LDS_READ128(a[buf][1], ad, 8192);
+            LDS_READ128(a[buf][2], ad, 16384); LDS_READ128(a[buf][3], ad, 24576);
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s + 1 < 8) { rd((s + 1) & 1, s + 1); LGKM_WAIT(4); } else { LGKM_WAIT(0); }
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                Frag f; f.u = a[s & 1][jt];
+                acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, xf[kb * 8 + s].b, acc[jt], 0, 0, 0);
+            }
+        }
+    };
+    // epilogue of output columns [nc*128, nc*128+128): lane = token m, acc[jt][4g+e] = column nc*128 + jt*32 + 8g + 4h + e
+    const bool wave_live = (blockIdx.x * 128 + wave * 32) < p.M;          // wave-uniform
+    auto epilogue = [&](int nc) {
+        if (!wave_live) return;
+        bf16_t* op = p.out + (size_t)mc * p.ldo + nc * 128 + 4 * h;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *(const f32x4*)(bs + nc * 128 + jt * 32 + 8 * g + 4 * h);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[jt][4 * g + e] + bv[e];
+                if (RES) {
+                    // residual tile index nc*4 + jt is compile-time only per (nc in {0,1}): select with a uniform branch
+                    u32x2 a1, a2;
+                    if (nc == 0) { a1 = rr1[jt][g]; a2 = rr2[jt][g]; } else { a1 = rr1[(4 + jt) % RT][g]; a2 = rr2[(4 + jt) % RT][g]; }
+                    if (p.r1) {
+                        v[0] *= __uint_as_float(a1[0] << 16); v[1] *= __uint_as_float(a1[0] & 0xffff0000u);
+                        v[2] *= __uint_as_float(a1[1] << 16); v[3] *= __uint_as_float(a1[1] & 0xffff0000u);
+                    }
+                    if (p.r2) {
+                        v[0] += __uint_as_float(a2[0] << 16); v[1] += __uint_as_float(a2[0] & 0xffff0000u);
+                        v[2] += __uint_as_float(a2[1] << 16); v[3] += __uint_as_float(a2[1] & 0xffff0000u);
+                    }
+                }
+                u32x2 o; o[0] = pack_bf16x2(v[0], v[1]); o[1] = pack_bf16x2(v[2], v[3]);
+                if (m < p.M) *(u32x2*)(op + jt * 32 + 8 * g) = o;
+            }
+    };
+
+    for (int nc = 0; nc < nch; ++nc) {
+        zero_acc();
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) step(begin_step(), kb);
+        epilogue(nc);
+    }
+}
+
+template <int K, bool RES>
+int launch(const LinArgs& p, hipStream_t s) {
+    const size_t lds = (size_t)RING * SLOT + (size_t)(p.N + 2 * K) * sizeof(float);
+    static size_t attr_set = 0;
+    if (attr_set < lds) {
+        (void)hipFuncSetAttribute((const void*)linear_ts_bf16_kernel<K, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = lds;
+    }
+    hipLaunchKernelGGL((linear_ts_bf16_kernel<K, RES>), dim3((p.M + 127) / 128), dim3(256), lds, s, p);
+    return master_check_launch("linear_ts_bf16");
+}
+
+}  // namespace
+
+// returns MASTER_ERR_UNSUPPORTED when the shape is outside what this kernel covers (the caller then uses the tiled GEMM)
+int linear_ts_bf16(const bf16_t* x, const float* ln_g, const float* ln_b, const bf16_t* w, const float* bias,
+                   const bf16_t* r1, const bf16_t* r2, bf16_t* out, int M, int N, int K, int ldx, int ldr, int ldo, float eps,
+                   hipStream_t s) {
+    const bool res = r1 || r2;
+    if (N % 128 != 0 || N > 1024 || (res && N > 256) || (K != 128 && K != 256 && K != 512)) return MASTER_ERR_UNSUPPORTED;
+    LinArgs p{x, ln_g, ln_b, w, bias, r1, r2, out, M, N, ldx, ldr, ldo, eps};
+    if (K == 128) return res ? launch<128, true>(p, s) : launch<128, false>(p, s);
+    if (K == 256) return res ? launch<256, true>(p, s) : launch<256, false>(p, s);
+    return res ? launch<512, true>(p, s) : launch<512, false>(p, s);
+}

@@ -164,16 +164,32 @@ class ShiftedWindowAttention(_WindowAttentionBase):
         self._init_rel_pos(num_heads)
 
     def attend(self, xq: Tensor, xk: Tensor, xvs: Sequence[Tensor], residuals: Sequence[Optional[Tensor]],
-               B: int, H: int, W: int) -> List[Tensor]:
+               B: int, H: int, W: int, norm: Optional[nn.LayerNorm] = None) -> List[Tensor]:
         """token-matrix form: returns [residual_i + proj(attn(q, k, v_i))]; identical inputs (same tensor
-        object) share their projection, and identical value streams share everything."""
+        object) share their projection, and identical value streams share everything.  `norm` (the block's
+        norm1) is applied to q, k and v; for q = k = v it is folded into the fused qkv projection."""
         C = xq.shape[1]
         if xq is xk and all(v is xq for v in xvs):
-            qkv = ops.linear(xq, self._w("qkv", self.Wq.weight, self.Wk.weight, self.Wv.weight),
-                             self._b("qkv", self.Wq.bias, self.Wk.bias, self.Wv.bias))
+            wqkv = self._w("qkv", self.Wq.weight, self.Wk.weight, self.Wv.weight)
+            bqkv = self._b("qkv", self.Wq.bias, self.Wk.bias, self.Wv.bias)
+            if norm is not None:
+                qkv = ops.linear_ln(xq, self._b("n1w", norm.weight), self._b("n1b", norm.bias), wqkv, bqkv, eps=norm.eps)
+            else:
+                qkv = ops.linear(xq, wqkv, bqkv)
             q, k, vs = qkv[:, :C], qkv[:, C:2 * C], [qkv[:, 2 * C:]]
             uniq = [0] * len(xvs)
         else:
+            if norm is not None:
+                memo: List[Tuple[Tensor, Tensor]] = []
+
+                def ln(t):
+                    for src, o in memo:
+                        if src is t:
+                            return o
+                    o = ops.layernorm(t, self._b("n1w", norm.weight), self._b("n1b", norm.bias), norm.eps)
+                    memo.append((t, o))
+                    return o
+                xq, xk, xvs = ln(xq), ln(xk), [ln(v) for v in xvs]
             if xq is xk:
                 qk = ops.linear(xq, self._w("qk", self.Wq.weight, self.Wk.weight), self._b("qk", self.Wq.bias, self.Wk.bias))
                 q, k = qk[:, :C], qk[:, C:]
@@ -247,18 +263,7 @@ class StyleSwinTransformerBlock(_HipModule):
 
     def run(self, xq: Tensor, xk: Tensor, xvs: Sequence[Tensor], residuals: Sequence[Tensor], B, H, W) -> List[Tensor]:
         """token-matrix form for one q/k pair and one or two value streams (shared softmax)"""
-        if self.use_norm:
-            memo: List[Tuple[Tensor, Tensor]] = []
-
-            def ln(t):
-                for s, o in memo:
-                    if s is t:
-                        return o
-                o = self._ln("norm1", t)
-                memo.append((t, o))
-                return o
-            xq, xk, xvs = ln(xq), ln(xk), [ln(v) for v in xvs]
-        outs = self.attn.attend(xq, xk, xvs, residuals, B, H, W)
+        outs = self.attn.attend(xq, xk, xvs, residuals, B, H, W, norm=self.norm1 if self.use_norm else None)
         if not self.exclude_MLP_after:
             outs = [_mlp_fwd(self, "mlp", self.mlp, o, o, norm=self.norm2 if self.use_norm else None) for o in outs]
         return outs
@@ -566,9 +571,11 @@ class _SwinAttention(_WindowAttentionBase):
         self.proj = nn.Linear(dim, dim)
         self._init_rel_pos(num_heads)
 
-    def attend(self, x: Tensor, residual: Tensor, B, H, W) -> Tensor:
+    def attend(self, x: Tensor, residual: Tensor, B, H, W, norm: nn.LayerNorm) -> Tensor:
+        """residual + proj(attention(qkv(norm(x))))"""
         C = x.shape[1]
-        qkv = ops.linear(x, self._w("qkv", self.qkv.weight), self._b("qkv", self.qkv.bias))
+        qkv = ops.linear_ln(x, self._b("n1w", norm.weight), self._b("n1b", norm.bias), self._w("qkv", self.qkv.weight),
+                            self._b("qkv", self.qkv.bias), eps=norm.eps)
         rows = self._derived("rows", [self.qkv.bias], lambda: ops.convert(self.qkv.bias.detach().contiguous(), self.compute_dtype))
         o = self._core(qkv[:, :C], qkv[:, C:2 * C], [qkv[:, 2 * C:]], rows[C:2 * C], [rows[2 * C:], None], B, H, W)[0]
         return ops.linear(o, self._w("proj", self.proj.weight), self._b("proj", self.proj.bias), r2=residual)
@@ -584,8 +591,7 @@ class SwinTransformerBlock(_HipModule):
         _init_mlp(self.mlp)
 
     def run(self, x: Tensor, B, H, W) -> Tensor:
-        n = ops.layernorm(x, self._b("n1w", self.norm1.weight), self._b("n1b", self.norm1.bias), self.norm1.eps)
-        x = self.attn.attend(n, x, B, H, W)
+        x = self.attn.attend(x, x, B, H, W, self.norm1)
         return _mlp_fwd(self, "mlp", self.mlp, x, x, norm=self.norm2)
 
 

@@ -22,7 +22,7 @@ K_FAMILIES = ("linear", "conv3x3", "window_attn", "layernorm", "instnorm", "patc
 EXPORTS = (
     "master_version", "master_last_error_string", "master_linear_fwd", "master_conv3x3_reflect_fwd",
     "master_window_attn_fwd", "master_layernorm_fwd", "master_instnorm_fwd", "master_patch_embed_fwd",
-    "master_patch_merge_ln_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
+    "master_patch_merge_ln_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_linear_ln_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
 )
 
 _lib = None
@@ -79,6 +79,7 @@ def load_library() -> ctypes.CDLL:
     lib.master_patch_merge_ln_fwd.argtypes = [vp] * 4 + [ci] * 4 + [cf, ci, vp]
     lib.master_convert.argtypes = [vp, vp, ctypes.c_size_t, ci, ci, vp]
     lib.master_mlp_fwd.argtypes = [vp] * 9 + [ci] * 6 + [cf, ci, vp]
+    lib.master_linear_ln_fwd.argtypes = [vp] * 8 + [ci] * 6 + [cf, ci, vp]
     lib.master_decoder_tail_fwd.argtypes = [vp] * 6 + [ci] * 4 + [vp]
     lib.master_prof_read.argtypes = [ci, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]
     _lib = lib
@@ -140,6 +141,23 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     _check(load_library().master_linear_fwd(_p(a), _p(w), _p(bias), _p(r1), _p(r2), _p(out), M, N, K, a.stride(0),
                                              out.stride(0), ldr, act, _dt(a), _stream()), "master_linear_fwd")
     return out
+
+
+def linear_ln(x: torch.Tensor, ln_gamma: torch.Tensor, ln_beta: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
+              r2: Optional[torch.Tensor] = None, eps: float = 1e-5) -> torch.Tensor:
+    """(LayerNorm(x) @ w.T + bias) + r2.  bf16 mode: one launch when the shape is covered; otherwise LayerNorm, then Linear."""
+    M, K = x.shape
+    N = w.shape[0]
+    if x.dtype == torch.bfloat16 and K in (128, 256, 512) and N % 128 == 0 and N <= 1024 and (r2 is None or N <= 256) and x.stride(1) == 1:
+        _dev(x, w)
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+        if _COUNT_ON:
+            _count("linear", flops=2.0 * M * N * K, bytes=x.element_size() * (M * K + N * K + M * N * (1 + (r2 is not None))))
+        _check(load_library().master_linear_ln_fwd(_p(x), _p(ln_gamma), _p(ln_beta), _p(w), _p(bias), None, _p(r2), _p(out), M, N, K,
+                                                    x.stride(0), out.stride(0), r2.stride(0) if r2 is not None else 0, eps,
+                                                    _dt(x), _stream()), "master_linear_ln_fwd")
+        return out
+    return linear(layernorm(x, ln_gamma, ln_beta, eps), w, bias, r2=r2)
 
 
 def mlp_fused_supported(x: torch.Tensor, hidden: int) -> bool:

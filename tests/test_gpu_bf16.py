@@ -143,3 +143,29 @@ def test_decoder_tail_bf16(cuda, B, Hs, Ws):
     assert out.shape == ref.shape and out.dtype == torch.float32
     mx, l2 = rel_err(out, ref)
     assert mx < 5e-3 and l2 < 2e-3, (mx, l2)
+
+
+@pytest.mark.parametrize("M,N,K,res", [(300, 768, 256, False), (4096, 384, 128, False), (1000, 256, 512, False), (333, 256, 256, True),
+                                        (128, 128, 128, True), (2000, 512, 256, False)])
+def test_token_stationary_linear_and_ln_bf16(cuda, M, N, K, res):
+    """weights-streamed Linear (+ folded LayerNorm, + r1/r2 epilogue) against fp32 torch on the bf16-rounded operands"""
+    from mastermetastyletransfer_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * 1.5 + 0.3).to(BF); w = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
+    b = torch.randn(N, generator=g) * 0.5
+    gw, gb = 1 + 0.2 * torch.randn(K, generator=g), 0.2 * torch.randn(K, generator=g)
+    r1 = torch.randn(M, N, generator=g).to(BF); r2 = torch.randn(M, N, generator=g).to(BF)
+    xd, wd, bd = x.to(cuda), w.to(cuda), b.to(cuda)
+    ref = F.linear(x.float(), w.float(), b)
+    mx, l2 = rel_err(ops.linear(xd, wd, bd), ref)
+    assert mx < 1e-2 and l2 < 4e-3, ("plain", mx, l2)
+    if res:
+        mx, l2 = rel_err(ops.linear(xd, wd, bd, r1=r1.to(cuda), r2=r2.to(cuda)), r1.float() * ref + r2.float())
+        assert mx < 1e-2 and l2 < 4e-3, ("r1 r2", mx, l2)
+        mx, l2 = rel_err(ops.linear(xd, wd, bd, r2=r2.to(cuda)), ref + r2.float())
+        assert mx < 1e-2 and l2 < 4e-3, ("r2", mx, l2)
+    xn = F.layer_norm(x.float(), (K,), gw, gb, 1e-5)
+    refn = F.linear(xn.to(BF).float(), w.float(), b) + (r2.float() if res else 0)
+    out = ops.linear_ln(xd, gw.to(cuda), gb.to(cuda), wd, bd, r2=r2.to(cuda) if res else None)
+    mx, l2 = rel_err(out, refn)
+    assert mx < 1.5e-2 and l2 < 5e-3, ("ln", mx, l2)
