@@ -111,6 +111,18 @@ int master_window_attn_fwd(const void* q, const void* k, const void* v0, const v
                            const uint8_t* region, void* out0, void* out1, int ldo, int B, int T, int heads,
                            int nW, int N, float scale, int dtype, master_stream_t stream);
 
+/* Whole attention half of a (Style)SwinTransformerBlock with q = k = v in ONE launch:
+ *     out = x + proj( window_attention( qkv( LayerNorm?(x) ) ) )
+ * x, out: token matrices [B*T, C]; wqkv [3C, C] = rows of Wq | Wk | Wv (torchvision's fused qkv.weight), bqkv [3C] fp32;
+ * wproj [C, C], bproj fp32; bias64 / src / region as in master_window_attn_fwd; ln_gamma == NULL skips the LayerNorm.
+ * Q, K, V and the probabilities never leave the register file.  Replaces style_transformer.py:390 (norm1), :83-168.
+ * MASTER_BF16 with C == 128, heads == 4 (Swin-B stage 1) only; MASTER_ERR_UNSUPPORTED otherwise (callers then use
+ * master_linear_ln_fwd + master_window_attn_fwd + master_linear_fwd). */
+int master_attn_block_fwd(const void* x, const float* ln_gamma, const float* ln_beta, const void* wqkv, const float* bqkv,
+                          const void* wproj, const float* bproj, const float* bias64, const int32_t* src,
+                          const uint8_t* region, void* out, int B, int T, int C, int heads, int nW, int N, float eps,
+                          float scale, int dtype, master_stream_t stream);
+
 /* out[m,:] = LayerNorm(x[m,:]) * gamma + beta over C channels (nn.LayerNorm, eps inside the sqrt;
  * style_transformer.py:340-343,:390-392).  C % 4 == 0, C <= 1024. */
 int master_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* out, int M, int C,
@@ -145,7 +157,7 @@ int master_convert(const void* src, void* dst, size_t n, int src_dtype, int dst_
 enum master_kernel_family {
     MASTER_K_LINEAR = 0, MASTER_K_CONV = 1, MASTER_K_ATTN = 2, MASTER_K_LAYERNORM = 3,
     MASTER_K_INSTNORM = 4, MASTER_K_PATCH_EMBED = 5, MASTER_K_PATCH_MERGE = 6, MASTER_K_CONVERT = 7,
-    MASTER_K_MLP = 8, MASTER_K_DECODER_TAIL = 9, MASTER_K_COUNT = 10
+    MASTER_K_MLP = 8, MASTER_K_DECODER_TAIL = 9, MASTER_K_ATTN_BLOCK = 10, MASTER_K_COUNT = 11
 };
 int master_prof_enable(int on);
 int master_prof_reset(void);

@@ -1,0 +1,329 @@
+// Fused window-attention block, bf16 throughput mode, C = 128 channels / 4 heads (Swin-B stage 1):
+//
+//     out = x + proj( window_attention( qkv( LayerNorm?(x) ) ) )          one launch, one pass over x
+//
+// (torchvision SwinTransformerBlock first half = reference style_transformer.py:390 with q = k = v:
+//  norm1, pad/roll/partition :83-111, fused qkv :114-116, attention :120-155, proj :156, reverse :160-168, residual.)
+//
+// Persistent workgroups (one per CU) walk the windows; wave w IS head w.  Everything a wave needs besides the
+// window's tokens is lane-private and loaded once per workgroup: its head's rows of Wq/Wk/Wv and its 32 rows of
+// Wproj as MFMA fragments (128 VGPRs), the matching bias values, and its head's relative-position tile in LDS.
+// Per window only the 49(+15) token rows move:
+//   1. the NEXT window's rows are gathered by LDS-DMA (per-lane source address = the pad/roll/partition table)
+//      while the current window computes;
+//   2. LayerNorm in LDS (4 lanes per row); zero-padded slots stay exactly zero, so their q/k/v come out as the
+//      projection bias, as in the reference (it pads after norm1 and before the Linear);
+//   3. Q^T, K^T (channel x slot) and V (slot x channel) accumulate from the same X fragments;
+//   4. S^T = K Q^T, softmax, O^T = V^T P^T: every operand is an accumulator tile of the previous product, packed
+//      to bf16 in registers (k order 16s + 8(e>>2) + 4*half + (e&3) on both operands), no LDS traffic;
+//   5. the heads' O tiles meet in LDS, each wave projects its 32 output channels and adds the residual.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int C = 128, HEADS = 4, KS = C / 16;
+constexpr int ROWB = C * 2;                     // bytes per token row (256)
+constexpr int XRAW = 0, XS = 64 * ROWB, BIAS = 2 * 64 * ROWB;          // LDS offsets
+constexpr int LDS_BYTES = BIAS + HEADS * 64 * 64 * 4;                  // 32 KB tiles + 64 KB rel-pos bias
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct BlockArgs {
+    const bf16_t* x; const float* ln_g; const float* ln_b;
+    const bf16_t* wqkv; const float* bqkv; const bf16_t* wproj; const float* bproj;
+    const float* bias64; const int32_t* src; const uint8_t* region;
+    bf16_t* out;
+    int B, T, nW, N; float eps, scale;
+};
+
+union Frag { u32x4 u; bf16x8_t b; };
+
+// registers 8s..8s+7 of an accumulator tile, scaled, packed to one bf16 fragment
+__device__ __forceinline__ Frag pack_tile(const f32x16& t, int s, float mul) {
+    Frag f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f.u[i] = pack_bf16x2(t[8 * s + 2 * i] * mul, t[8 * s + 2 * i + 1] * mul);
+    return f;
+}
+
+__global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // = head
+    const int r = lane & 31, h = lane >> 5;
+    const int nwin = p.B * p.nW;
+
+    // ---- once per workgroup: lane-private weight fragments and bias values -------------------------------
+    Frag wq[KS], wk[KS], wv[KS], wp[KS];
+    {
+        const bf16_t* base = p.wqkv + (size_t)(wave * 32 + r) * C + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            wq[s].u = *(const u32x4*)(base + 16 * s);
+            wk[s].u = *(const u32x4*)(base + (size_t)C * C + 16 * s);
+            wv[s].u = *(const u32x4*)(base + (size_t)2 * C * C + 16 * s);
+            wp[s].u = *(const u32x4*)(p.wproj + (size_t)(wave * 32 + r) * C + 8 * h + 16 * s);
+        }
+    }
+    float bq[16], bk[16], bp[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int ch = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;        // channel of accumulator register e
+        bq[e] = p.bqkv[ch]; bk[e] = p.bqkv[C + ch]; bp[e] = p.bproj[ch];
+    }
+    const float bvl = p.bqkv[2 * C + wave * 32 + r];                      // V tiles have the channel on the lane
+    for (int i = tid; i < HEADS * 64 * 64; i += 256) ((float*)(lds + BIAS))[i] = p.bias64[i];
+    // LayerNorm parameters of this thread's 32 channels (thread = (row t>>2, quarter t&3) in the LN phase)
+    const int lrow = tid >> 2, lq = tid & 3;
+    float lg[32], lb[32];
+    if (p.ln_g) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { lg[i] = p.ln_g[lq * 32 + i]; lb[i] = p.ln_b[lq * 32 + i]; }
+    }
+
+    // ---- gather of a window's token rows by LDS-DMA: piece I of 1 KB = slots 4I..4I+3 ----------------------------
+    auto gather = [&](int win) {
+        const int b = win / p.nW, w = win - b * p.nW;
+        const int32_t* src = p.src + w * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int I = wave * 4 + i;
+            const int slot = 4 * I + (lane >> 4);
+            int idx = src[slot];
+            idx = idx < 0 ? 0 : idx;                                       // padded slots are zeroed in the LN phase
+            const bf16_t* sp = p.x + ((size_t)b * p.T + idx) * C + (lane & 15) * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                             (__attribute__((address_space(3))) void*)(lds + XRAW + I * 1024), 16, 0, 0);
+        }
+    };
+
+    int win = blockIdx.x;
+    if (win < nwin) gather(win);
+
+    for (; win < nwin; win += gridDim.x) {
+        const int b = win / p.nW, w = win - b * p.nW;
+        const int32_t* src = p.src + w * 64;
+        const size_t tok0 = (size_t)b * p.T;
+
+        // ---- 1. LayerNorm: raw rows (LDS, linear) -> normalised bf16 rows (LDS, 16-B chunks swizzled by row&15) ------
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                      // raw tile landed; previous window's proj reads of XS done
+        {
+            const int sidx = lrow < p.N ? src[lrow] : -1;
+            float v[32];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const u32x4 u = *(const u32x4*)(lds + XRAW + lrow * ROWB + lq * 64 + c4 * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[c4 * 8 + 2 * e] = __uint_as_float(u[e] << 16); v[c4 * 8 + 2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); }
+            }
+            if (p.ln_g) {
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) sum += v[i];
+                sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64);
+                const float mean = sum * (1.0f / C);
+                float sq = 0.f;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) { const float d = v[i] - mean; sq += d * d; }
+                sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64);
+                const float rstd = rsqrtf(sq * (1.0f / C) + p.eps);
+#pragma unroll
+                for (int i = 0; i < 32; ++i) v[i] = (v[i] - mean) * rstd * lg[i] + lb[i];
+            }
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                u32x4 o = {0u, 0u, 0u, 0u};
+                if (sidx >= 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(v[c4 * 8 + 2 * e], v[c4 * 8 + 2 * e + 1]);
+                }
+                *(u32x4*)(lds + XS + lrow * ROWB + (((lq * 4 + c4) ^ (lrow & 15)) << 4)) = o;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                      // XS complete, XRAW free
+        if (win + gridDim.x < nwin) gather(win + gridDim.x);               // next window's rows fly under this window's math
+
+        // ---- 2. Q^T, K^T [channel][slot] and V [slot][channel] of this wave's head --------------------------------------
+        f32x16 qt[2], kt[2], vt[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { qt[t][e] = bq[e]; kt[t][e] = bk[e]; vt[t][e] = bvl; }
+        {
+            const unsigned char* xb = lds + XS + r * ROWB;
+            const int xsw = (h ^ (r & 15)) << 4;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                Frag x0, x1;
+                x0.u = *(const u32x4*)(xb + ((32 * s) ^ xsw));
+                x1.u = *(const u32x4*)(xb + 32 * ROWB + ((32 * s) ^ xsw));
+                qt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s].b, x0.b, qt[0], 0, 0, 0);
+                qt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s].b, x1.b, qt[1], 0, 0, 0);
+                kt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[s].b, x0.b, kt[0], 0, 0, 0);
+                kt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[s].b, x1.b, kt[1], 0, 0, 0);
+                vt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0.b, wv[s].b, vt[0], 0, 0, 0);
+                vt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1.b, wv[s].b, vt[1], 0, 0, 0);
+            }
+        }
+
+        // ---- 3. S^T[key][query] = K Q^T from packed accumulator tiles; bias, mask, softmax -------------------------------------
+        f32x16 st[2][2];
+        {
+            Frag qf[2][2], kf[2][2];
+            const float qmul = p.scale * LOG2E;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) { qf[t][s] = pack_tile(qt[t], s, qmul); kf[t][s] = pack_tile(kt[t], s, 1.0f); }
+            const float* bias = (const float*)(lds + BIAS) + wave * 64 * 64;
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+                const float* brow = bias + (q2 * 32 + r) * 64;
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 bv = *(const f32x4*)(brow + k2 * 32 + 8 * g + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) st[k2][q2][4 * g + e] = bv[e] * LOG2E;
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+                        st[k2][q2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[k2][s].b, qf[q2][s].b, st[k2][q2], 0, 0, 0);
+                }
+            }
+        }
+        if (p.region) {
+            const uint8_t* reg = p.region + w * 64;
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+                const unsigned rq = reg[q2 * 32 + r];
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const unsigned rk4 = *(const unsigned*)(reg + k2 * 32 + 8 * g + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (((rk4 >> (8 * e)) & 0xffu) != rq) st[k2][q2][4 * g + e] += -100.0f * LOG2E;
+                    }
+            }
+        }
+        float inv[2];
+        Frag pf[2][2][2];                                                  // [query tile][key tile][k-step]
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {
+            float mx = st[0][q2][0];
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[k2][q2][e]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned pk = pack_bf16x2(__builtin_amdgcn_exp2f(st[k2][q2][8 * s + 2 * j] - mx),
+                                                        __builtin_amdgcn_exp2f(st[k2][q2][8 * s + 2 * j + 1] - mx));
+                        pf[q2][k2][s].u[j] = pk;
+                        sum += __uint_as_float(pk << 16) + __uint_as_float(pk & 0xffff0000u);
+                    }
+            sum += __shfl_xor(sum, 32, 64);
+            inv[q2] = __builtin_amdgcn_rcpf(sum);
+        }
+
+        // ---- 4. O^T[d][query] = V^T P^T (V tiles as the A operand: X^T B with X = V[key][d]) ------------------------------------
+        f32x16 ot[2];
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ot[q2][e] = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const Frag vf = pack_tile(vt[k2], s, 1.0f);
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2)
+                    ot[q2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.b, pf[q2][k2][s].b, ot[q2], 0, 0, 0);
+            }
+
+        __builtin_amdgcn_s_barrier();                                      // every head is done reading XS (its X fragments)
+        // O[slot][head*32 + d] -> LDS (the XS tile is reused), 8-B pieces: d = 8g + 4h + e
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {
+            const int slot = q2 * 32 + r;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 o;
+                o[0] = pack_bf16x2(ot[q2][4 * g] * inv[q2], ot[q2][4 * g + 1] * inv[q2]);
+                o[1] = pack_bf16x2(ot[q2][4 * g + 2] * inv[q2], ot[q2][4 * g + 3] * inv[q2]);
+                *(u32x2*)(lds + XS + slot * ROWB + (((wave * 4 + g) ^ (slot & 15)) << 4) + 8 * h) = o;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                      // all heads' O in LDS
+
+        // ---- 5. proj: out^T[n][slot] for this wave's 32 output channels, + bias + residual -------------------------------------------
+        f32x16 pt[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) pt[t][e] = bp[e];
+        {
+            const unsigned char* ob = lds + XS + r * ROWB;
+            const int xsw = (h ^ (r & 15)) << 4;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                Frag o0, o1;
+                o0.u = *(const u32x4*)(ob + ((32 * s) ^ xsw));
+                o1.u = *(const u32x4*)(ob + 32 * ROWB + ((32 * s) ^ xsw));
+                pt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[s].b, o0.b, pt[0], 0, 0, 0);
+                pt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[s].b, o1.b, pt[1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int slot = t * 32 + r;
+            const int idx = slot < p.N ? src[slot] : -1;
+            if (idx < 0) continue;
+            const size_t off = (tok0 + idx) * C + wave * 32 + 4 * h;
+            u32x2 res[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) res[g] = *(const u32x2*)(p.x + off + 8 * g);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 o;
+                o[0] = pack_bf16x2(pt[t][4 * g] + __uint_as_float(res[g][0] << 16), pt[t][4 * g + 1] + __uint_as_float(res[g][0] & 0xffff0000u));
+                o[1] = pack_bf16x2(pt[t][4 * g + 2] + __uint_as_float(res[g][1] << 16), pt[t][4 * g + 3] + __uint_as_float(res[g][1] & 0xffff0000u));
+                *(u32x2*)(p.out + off + 8 * g) = o;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int attn_block_bf16(const bf16_t* x, const float* ln_g, const float* ln_b, const bf16_t* wqkv, const float* bqkv,
+                    const bf16_t* wproj, const float* bproj, const float* bias64, const int32_t* src, const uint8_t* region,
+                    bf16_t* out, int B, int T, int Cc, int heads, int nW, int N, float eps, float scale, hipStream_t s) {
+    if (Cc != C || heads != HEADS) return MASTER_ERR_UNSUPPORTED;
+    BlockArgs p{x, ln_g, ln_b, wqkv, bqkv, wproj, bproj, bias64, src, region, out, B, T, nW, N, eps, scale};
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_block_c128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    int grid = B * nW;
+    if (grid > 256) grid = 256;                      // persistent: one workgroup per CU walks the windows
+    hipLaunchKernelGGL(attn_block_c128_kernel, dim3(grid), dim3(256), LDS_BYTES, s, p);
+    return master_check_launch("attn_block_bf16");
+}

@@ -27,6 +27,8 @@ template <typename T> int patch_embed_launch(const float*, const void*, const vo
 int convert_launch(const void*, void*, size_t, int, int, hipStream_t);
 int linear_ts_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const bf16_t*, bf16_t*,
                    int, int, int, int, int, int, float, hipStream_t);
+int attn_block_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const float*, const float*,
+                    const int32_t*, const uint8_t*, bf16_t*, int, int, int, int, int, int, float, float, hipStream_t);
 int conv_tail_bf16(const bf16_t*, const bf16_t*, const float*, const bf16_t*, const float*, float*, int, int, int, hipStream_t);
 int mlp_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const float*,
              const bf16_t*, bf16_t*, int, int, int, int, int, int, float, hipStream_t);
@@ -209,6 +211,23 @@ int master_window_attn_fwd(const void* q, const void* k, const void* v0, const v
                                 N, scale, s);
     master_set_error("window_attn: bad dtype %d", dtype);
     return MASTER_ERR_INVALID;
+}
+
+int master_attn_block_fwd(const void* x, const float* ln_gamma, const float* ln_beta, const void* wqkv, const float* bqkv,
+                          const void* wproj, const float* bproj, const float* bias64, const int32_t* src,
+                          const uint8_t* region, void* out, int B, int T, int C, int heads, int nW, int N, float eps,
+                          float scale, int dtype, master_stream_t stream) {
+    REQUIRE(x && wqkv && bqkv && wproj && bproj && bias64 && src && out, "attn_block: null operand");
+    REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), "attn_block: ln_gamma and ln_beta come together");
+    REQUIRE(B > 0 && T > 0 && nW > 0 && N > 0 && N <= 64 && x != out, "attn_block: bad dims (or in-place call)");
+    if (dtype != MASTER_BF16) { master_set_error("attn_block: fused kernel is bf16-only"); return MASTER_ERR_UNSUPPORTED; }
+    REQUIRE(al16(x) && al16(wqkv) && al16(wproj) && al16(out) && al16(bias64), "attn_block: operands must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_ATTN_BLOCK, s);
+    const int rc = attn_block_bf16((const bf16_t*)x, ln_gamma, ln_beta, (const bf16_t*)wqkv, bqkv, (const bf16_t*)wproj, bproj,
+                                   bias64, src, region, (bf16_t*)out, B, T, C, heads, nW, N, eps, scale, s);
+    if (rc == MASTER_ERR_UNSUPPORTED) master_set_error("attn_block: C=%d heads=%d not built (128 / 4)", C, heads);
+    return rc;
 }
 
 int master_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* out, int M, int C, float eps,

@@ -574,6 +574,12 @@ class _SwinAttention(_WindowAttentionBase):
     def attend(self, x: Tensor, residual: Tensor, B, H, W, norm: nn.LayerNorm) -> Tensor:
         """residual + proj(attention(qkv(norm(x))))"""
         C = x.shape[1]
+        if residual is x and ops.attn_block_supported(x, self.num_heads):
+            plan = window_plan(H, W, self.window_size, self.shift_size, x.device)
+            return ops.attn_block(x, self._b("n1w", norm.weight), self._b("n1b", norm.bias), self._w("qkv", self.qkv.weight),
+                                  self._b("qkv", self.qkv.bias), self._w("proj", self.proj.weight), self._b("proj", self.proj.bias),
+                                  self._bias64(), plan.src, plan.region, B, H * W, self.num_heads, plan.nW, plan.N,
+                                  HEAD_DIM ** -0.5, norm.eps)
         qkv = ops.linear_ln(x, self._b("n1w", norm.weight), self._b("n1b", norm.bias), self._w("qkv", self.qkv.weight),
                             self._b("qkv", self.qkv.bias), eps=norm.eps)
         rows = self._derived("rows", [self.qkv.bias], lambda: ops.convert(self.qkv.bias.detach().contiguous(), self.compute_dtype))

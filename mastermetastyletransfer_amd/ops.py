@@ -17,12 +17,12 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmaster_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
-K_FAMILIES = ("linear", "conv3x3", "window_attn", "layernorm", "instnorm", "patch_embed", "patch_merge", "convert", "mlp", "decoder_tail")
+K_FAMILIES = ("linear", "conv3x3", "window_attn", "layernorm", "instnorm", "patch_embed", "patch_merge", "convert", "mlp", "decoder_tail", "attn_block")
 
 EXPORTS = (
     "master_version", "master_last_error_string", "master_linear_fwd", "master_conv3x3_reflect_fwd",
     "master_window_attn_fwd", "master_layernorm_fwd", "master_instnorm_fwd", "master_patch_embed_fwd",
-    "master_patch_merge_ln_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_linear_ln_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
+    "master_patch_merge_ln_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_linear_ln_fwd", "master_attn_block_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
 )
 
 _lib = None
@@ -80,6 +80,7 @@ def load_library() -> ctypes.CDLL:
     lib.master_convert.argtypes = [vp, vp, ctypes.c_size_t, ci, ci, vp]
     lib.master_mlp_fwd.argtypes = [vp] * 9 + [ci] * 6 + [cf, ci, vp]
     lib.master_linear_ln_fwd.argtypes = [vp] * 8 + [ci] * 6 + [cf, ci, vp]
+    lib.master_attn_block_fwd.argtypes = [vp] * 11 + [ci] * 6 + [cf, cf, ci, vp]
     lib.master_decoder_tail_fwd.argtypes = [vp] * 6 + [ci] * 4 + [vp]
     lib.master_prof_read.argtypes = [ci, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]
     _lib = lib
@@ -199,6 +200,25 @@ def conv3x3_reflect(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor,
     _check(load_library().master_conv3x3_reflect_fwd(_p(x), _p(w_packed), _p(bias), _p(out), B, H, W, Cin, Cout,
                                                       int(upsample), int(relu), int(out_nchw), _dt(x), _stream()),
            "master_conv3x3_reflect_fwd")
+    return out
+
+
+def attn_block_supported(x: torch.Tensor, heads: int) -> bool:
+    return x.dtype == torch.bfloat16 and x.shape[1] == 128 and heads == 4 and x.is_contiguous()
+
+
+def attn_block(x, ln_gamma, ln_beta, wqkv, bqkv, wproj, bproj, bias64, src, region, B: int, T: int, heads: int, nW: int, N: int,
+               scale: float, eps: float = 1e-5) -> torch.Tensor:
+    """x + proj(window_attention(qkv(LN?(x)))) in one launch (bf16, C = 128, 4 heads)."""
+    _dev(x, wqkv, wproj)
+    M, C = x.shape
+    assert M == B * T and wqkv.shape == (3 * C, C) and wproj.shape == (C, C) and wqkv.is_contiguous() and wproj.is_contiguous()
+    out = torch.empty_like(x)
+    if _COUNT_ON:
+        _count("attn_block", flops=2.0 * B * nW * 64 * C * 4 * C + 4.0 * B * nW * heads * N * N * 32, bytes=4.0 * x.numel())
+    _check(load_library().master_attn_block_fwd(_p(x), _p(ln_gamma), _p(ln_beta), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj),
+                                                 _p(bias64), _p(src), _p(region), _p(out), B, T, C, heads, nW, N, eps,
+                                                 float(scale), _dt(x), _stream()), "master_attn_block_fwd")
     return out
 
 

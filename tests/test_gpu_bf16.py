@@ -169,3 +169,26 @@ def test_token_stationary_linear_and_ln_bf16(cuda, M, N, K, res):
     out = ops.linear_ln(xd, gw.to(cuda), gb.to(cuda), wd, bd, r2=r2.to(cuda) if res else None)
     mx, l2 = rel_err(out, refn)
     assert mx < 1.5e-2 and l2 < 5e-3, ("ln", mx, l2)
+
+
+@pytest.mark.parametrize("B,H,W,shift", [(2, 14, 14, 3), (1, 14, 14, 0), (3, 10, 17, 3), (1, 64, 64, 3), (2, 7, 7, 0)])
+def test_fused_attention_block_c128_bf16(cuda, B, H, W, shift):
+    """x + proj(window_attention(qkv(LN(x)))) in one persistent launch (Swin stage-1 geometry: C=128, 4 heads) against
+    the fp32 oracle (torchvision-style block half) on bf16-rounded weights/inputs."""
+    from mastermetastyletransfer_amd import ops
+    from mastermetastyletransfer_amd.modules import SwinTransformerBlock
+    C, nh = 128, 4
+    blk = SwinTransformerBlock(C, nh, [7, 7], [shift, shift])
+    sd = seeded_state_dict({k: tuple(v.shape) for k, v in blk.state_dict().items()}, seed=77)
+    sd = {k: (v.to(BF).float() if v.is_floating_point() else v) for k, v in sd.items()}      # bf16-representable weights
+    blk.load_state_dict(sd); blk = blk.to(cuda).eval(); blk.compute_dtype = BF
+    for m in blk.modules():
+        m.compute_dtype = BF
+    x = seeded_input(f"ab{H}{W}{shift}", (B, H, W, C), 5).to(BF)
+    n = F.layer_norm(x.float(), (C,), sd["norm1.weight"], sd["norm1.bias"], 1e-5)
+    ref = x.float() + O.swin_window_attention(n, sd, "attn.", (7, 7), (shift, shift), nh)
+    xd = x.to(cuda).reshape(B * H * W, C)
+    got = blk.attn.attend(xd, xd, B, H, W, blk.norm1)
+    assert got.data_ptr() != xd.data_ptr()
+    mx, l2 = rel_err(got.view(B, H, W, C), ref)
+    assert mx < 4e-2 and l2 < 1e-2, (mx, l2)
