@@ -27,8 +27,10 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int C = 128, HEADS = 4, KS = C / 16;
 constexpr int ROWB = C * 2;                     // bytes per token row (256)
-constexpr int XRAW = 0, XS = 64 * ROWB, BIAS = 2 * 64 * ROWB;          // LDS offsets
-constexpr int LDS_BYTES = BIAS + HEADS * 64 * 64 * 4;                  // 32 KB tiles + 64 KB rel-pos bias
+constexpr int XRAW = 0, XS = 2 * 64 * ROWB, BIAS = 3 * 64 * ROWB;      // LDS offsets: 2 raw tiles (ping-pong), 1 working tile
+constexpr int BSTR = 68;                                               // floats per rel-pos bias row in LDS (272 B: conflict-free column reads)
+constexpr int TABLES = BIAS + HEADS * 64 * BSTR * 4;                   // then rel-pos bias (68 KB), then src[nW][64] i32, region[nW][64] u8
+constexpr int LDS_MAX = 160 * 1024;
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct BlockArgs {
@@ -40,6 +42,11 @@ struct BlockArgs {
 };
 
 union Frag { u32x4 u; bf16x8_t b; };
+
+// hand-pipelined LDS fragment reads (see mlp_bf16.hip): the compiler neither waits for nor moves these
+#define LDS_READ128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:" #imm : "=v"(dst) : "v"(addr))
+#define LGKM_WAIT(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+__device__ __forceinline__ unsigned lds_addr(const unsigned char* ptr) { return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)ptr; }
 
 // registers 8s..8s+7 of an accumulator tile, scaled, packed to one bf16 fragment
 __device__ __forceinline__ Frag pack_tile(const f32x16& t, int s, float mul) {
@@ -75,7 +82,13 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
         bq[e] = p.bqkv[ch]; bk[e] = p.bqkv[C + ch]; bp[e] = p.bproj[ch];
     }
     const float bvl = p.bqkv[2 * C + wave * 32 + r];                      // V tiles have the channel on the lane
-    for (int i = tid; i < HEADS * 64 * 64; i += 256) ((float*)(lds + BIAS))[i] = p.bias64[i];
+    for (int i = tid; i < HEADS * 64 * 64; i += 256) ((float*)(lds + BIAS))[(i >> 6) * BSTR + (i & 63)] = p.bias64[i];
+    // the pad/roll/partition tables of every window of the geometry: the loop below then has no ordinary global load
+    int32_t* srcs = (int32_t*)(lds + TABLES);
+    uint8_t* regs = (uint8_t*)(srcs + p.nW * 64);
+    for (int i = tid; i < p.nW * 64; i += 256) { srcs[i] = p.src[i]; regs[i] = p.region ? p.region[i] : 0; }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     // LayerNorm parameters of this thread's 32 channels (thread = (row t>>2, quarter t&3) in the LN phase)
     const int lrow = tid >> 2, lq = tid & 3;
     float lg[32], lb[32];
@@ -85,9 +98,9 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
     }
 
     // ---- gather of a window's token rows by LDS-DMA: piece I of 1 KB = slots 4I..4I+3 ----------------------------
-    auto gather = [&](int win) {
+    auto gather = [&](int win, int buf) {
         const int b = win / p.nW, w = win - b * p.nW;
-        const int32_t* src = p.src + w * 64;
+        const int32_t* src = srcs + w * 64;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int I = wave * 4 + i;
@@ -96,17 +109,18 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
             idx = idx < 0 ? 0 : idx;                                       // padded slots are zeroed in the LN phase
             const bf16_t* sp = p.x + ((size_t)b * p.T + idx) * C + (lane & 15) * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
-                                             (__attribute__((address_space(3))) void*)(lds + XRAW + I * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(lds + XRAW + buf * 64 * ROWB + I * 1024), 16, 0, 0);
         }
     };
 
-    int win = blockIdx.x;
-    if (win < nwin) gather(win);
+    int win = blockIdx.x, buf = 0;
+    if (win < nwin) gather(win, 0);
 
-    for (; win < nwin; win += gridDim.x) {
+    for (; win < nwin; win += gridDim.x, buf ^= 1) {
         const int b = win / p.nW, w = win - b * p.nW;
-        const int32_t* src = p.src + w * 64;
+        const int32_t* src = srcs + w * 64;
         const size_t tok0 = (size_t)b * p.T;
+        const unsigned char* raw = lds + XRAW + buf * 64 * ROWB;           // this window's un-normalised rows (also the residual)
 
         // ---- 1. LayerNorm: raw rows (LDS, linear) -> normalised bf16 rows (LDS, 16-B chunks swizzled by row&15) ------
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -116,7 +130,7 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
             float v[32];
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
-                const u32x4 u = *(const u32x4*)(lds + XRAW + lrow * ROWB + lq * 64 + c4 * 16);
+                const u32x4 u = *(const u32x4*)(raw + lrow * ROWB + lq * 64 + c4 * 16);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[c4 * 8 + 2 * e] = __uint_as_float(u[e] << 16); v[c4 * 8 + 2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); }
             }
@@ -145,8 +159,8 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                      // XS complete, XRAW free
-        if (win + gridDim.x < nwin) gather(win + gridDim.x);               // next window's rows fly under this window's math
+        __builtin_amdgcn_s_barrier();                                      // XS complete
+        if (win + gridDim.x < nwin) gather(win + gridDim.x, buf ^ 1);      // next window's rows fly under this window's math
 
         // ---- 2. Q^T, K^T [channel][slot] and V [slot][channel] of this wave's head --------------------------------------
         f32x16 qt[2], kt[2], vt[2];
@@ -155,13 +169,18 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) { qt[t][e] = bq[e]; kt[t][e] = bk[e]; vt[t][e] = bvl; }
         {
-            const unsigned char* xb = lds + XS + r * ROWB;
+            const unsigned xb = lds_addr(lds + XS + r * ROWB);
             const int xsw = (h ^ (r & 15)) << 4;
+            u32x4 xa[2][2];
+            LDS_READ128(xa[0][0], xb + (0 ^ xsw), 0); LDS_READ128(xa[0][1], xb + (0 ^ xsw), 8192);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                Frag x0, x1;
-                x0.u = *(const u32x4*)(xb + ((32 * s) ^ xsw));
-                x1.u = *(const u32x4*)(xb + 32 * ROWB + ((32 * s) ^ xsw));
+                if (s + 1 < KS) {
+                    const unsigned ad = xb + ((32 * (s + 1)) ^ xsw);
+                    LDS_READ128(xa[(s + 1) & 1][0], ad, 0); LDS_READ128(xa[(s + 1) & 1][1], ad, 8192);
+                    LGKM_WAIT(2);
+                } else { LGKM_WAIT(0); }
+                Frag x0, x1; x0.u = xa[s & 1][0]; x1.u = xa[s & 1][1];
                 qt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s].b, x0.b, qt[0], 0, 0, 0);
                 qt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s].b, x1.b, qt[1], 0, 0, 0);
                 kt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[s].b, x0.b, kt[0], 0, 0, 0);
@@ -180,10 +199,10 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) { qf[t][s] = pack_tile(qt[t], s, qmul); kf[t][s] = pack_tile(kt[t], s, 1.0f); }
-            const float* bias = (const float*)(lds + BIAS) + wave * 64 * 64;
+            const float* bias = (const float*)(lds + BIAS) + wave * 64 * BSTR;
 #pragma unroll
             for (int q2 = 0; q2 < 2; ++q2) {
-                const float* brow = bias + (q2 * 32 + r) * 64;
+                const float* brow = bias + (q2 * 32 + r) * BSTR;
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) {
 #pragma unroll
@@ -199,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
             }
         }
         if (p.region) {
-            const uint8_t* reg = p.region + w * 64;
+            const uint8_t* reg = regs + w * 64;
 #pragma unroll
             for (int q2 = 0; q2 < 2; ++q2) {
                 const unsigned rq = reg[q2 * 32 + r];
@@ -279,13 +298,18 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) pt[t][e] = bp[e];
         {
-            const unsigned char* ob = lds + XS + r * ROWB;
+            const unsigned ob = lds_addr(lds + XS + r * ROWB);
             const int xsw = (h ^ (r & 15)) << 4;
+            u32x4 oa[2][2];
+            LDS_READ128(oa[0][0], ob + (0 ^ xsw), 0); LDS_READ128(oa[0][1], ob + (0 ^ xsw), 8192);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                Frag o0, o1;
-                o0.u = *(const u32x4*)(ob + ((32 * s) ^ xsw));
-                o1.u = *(const u32x4*)(ob + 32 * ROWB + ((32 * s) ^ xsw));
+                if (s + 1 < KS) {
+                    const unsigned ad = ob + ((32 * (s + 1)) ^ xsw);
+                    LDS_READ128(oa[(s + 1) & 1][0], ad, 0); LDS_READ128(oa[(s + 1) & 1][1], ad, 8192);
+                    LGKM_WAIT(2);
+                } else { LGKM_WAIT(0); }
+                Frag o0, o1; o0.u = oa[s & 1][0]; o1.u = oa[s & 1][1];
                 pt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[s].b, o0.b, pt[0], 0, 0, 0);
                 pt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[s].b, o1.b, pt[1], 0, 0, 0);
             }
@@ -296,9 +320,9 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
             const int idx = slot < p.N ? src[slot] : -1;
             if (idx < 0) continue;
             const size_t off = (tok0 + idx) * C + wave * 32 + 4 * h;
-            u32x2 res[4];
+            u32x2 res[4];                                                  // residual = the raw row still sitting in LDS
 #pragma unroll
-            for (int g = 0; g < 4; ++g) res[g] = *(const u32x2*)(p.x + off + 8 * g);
+            for (int g = 0; g < 4; ++g) res[g] = *(const u32x2*)(raw + slot * ROWB + (wave * 32 + 4 * h + 8 * g) * 2);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 u32x2 o;
@@ -316,11 +340,13 @@ int attn_block_bf16(const bf16_t* x, const float* ln_g, const float* ln_b, const
                     const bf16_t* wproj, const float* bproj, const float* bias64, const int32_t* src, const uint8_t* region,
                     bf16_t* out, int B, int T, int Cc, int heads, int nW, int N, float eps, float scale, hipStream_t s) {
     if (Cc != C || heads != HEADS) return MASTER_ERR_UNSUPPORTED;
+    const int LDS_BYTES = TABLES + nW * 64 * 5;
+    if (LDS_BYTES > LDS_MAX) return MASTER_ERR_UNSUPPORTED;           // too many windows per image for the in-LDS tables
     BlockArgs p{x, ln_g, ln_b, wqkv, bqkv, wproj, bproj, bias64, src, region, out, B, T, nW, N, eps, scale};
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int attr_set = 0;
+    if (attr_set < LDS_BYTES) {
         (void)hipFuncSetAttribute((const void*)attn_block_c128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
+        attr_set = LDS_BYTES;
     }
     int grid = B * nW;
     if (grid > 256) grid = 256;                      // persistent: one workgroup per CU walks the windows
