@@ -123,6 +123,26 @@ def main():
         dist.destroy_process_group()
 
 
+PMC_KERNELS = {"mlp": ("mlp_bf16_kernel",), "linear": ("linear_ts_bf16_kernel", "gemm_bf16_kernel<128, 128, 64, 64, false>"),
+               "attn_block": ("attn_block_c128_kernel",), "window_attn": ("window_attn_bf16_kernel",),
+               "conv3x3": ("gemm_bf16_kernel<128, 128, 64, 64, true>", "gemm_bf16_kernel<128, 64, 64, 32, true>", "gemm_bf16_kernel<256, 32, 64, 32, true>"),
+               "decoder_tail": ("conv_tail_bf16_kernel",), "instnorm": ("instnorm_kernel",), "patch_embed": ("patch_embed_kernel",)}
+
+
+def pmc_traffic(family, args):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes of THIS command line
+    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/pmc_traffic.py); None when no matching profile exists."""
+    path = os.path.join(ROOT, "profiles", "r01_bf16_bs32_pmc_traffic.json")
+    if args.dtype != "bf16" or args.batch != 32 or args.size != 256 or args.layers != 1 or not os.path.exists(path):
+        return None, None
+    prof = json.load(open(path))
+    tot_b = tot_n = 0.0
+    for name, v in prof.items():
+        if any(name.startswith(pfx) for pfx in PMC_KERNELS.get(family, ())):
+            tot_b += v["hbm_bytes_per_launch"] * v["launches"]; tot_n += v["launches"]
+    return (round(tot_b / tot_n) if tot_n else None), "profiles/r01_bf16_bs32_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+
+
 def extras(model, content, style, k, args, ops):
     """roofline of the dominant kernel (HIP events per launch), cross-attn QK^T rate, parity, CPU baseline"""
     B, S = content.shape[0], content.shape[-1]
@@ -152,18 +172,20 @@ def extras(model, content, style, k, args, ops):
     kernel_names = {"linear": "linear_ts_bf16_kernel / gemm_*_kernel (q/k/v/proj projections)", "mlp": "mlp_bf16_kernel (fused LN+fc1+GELU+fc2+residual)",
                     "conv3x3": "gemm_*_kernel<..., CONV> (decoder 3x3 convolutions)", "window_attn": "window_attn_*_kernel",
                     "decoder_tail": "conv_tail_bf16_kernel"}
+    traffic, traffic_src = pmc_traffic(dom, args)
     if dom in mfma_fams:
         flops = counts[dom]["flops"]
         achieved = flops / (ms * 1e-3) / 1e12
         out["roofline"] = {"kernel": kernel_names.get(dom, dom), "family": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                           "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None, "launches_per_step": n // reps,
+                           "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                           "alg_bytes_per_launch": counts[dom].get("bytes", 0.0) / n, "launches_per_step": n // reps,
                            "avg_launch_us": round(ms / n * 1e3, 2), "alg_flop_per_launch": flops / n,
                            "share_of_step_kernel_time": round(ms / sum(v[1] for v in prof.values()), 3)}
     else:
         by = counts[dom]["bytes"]
         achieved = by / (ms * 1e-3) / 1e9
         out["roofline"] = {"kernel": dom, "family": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches_per_step": n // reps,
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": n // reps,
                            "avg_launch_us": round(ms / n * 1e3, 2), "alg_bytes_per_launch": by / n}
     # ---- the metric's named GEMM: cross-attention QK^T (49x49x32 per window/head) inside the fused attention kernel
     an, ams = prof["window_attn"]
