@@ -62,6 +62,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef MLP_CLOCK_PROBE   // diagnostic build only (profiles/probes/clock_probe.hip)
+    const unsigned long long probe_t0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int r = lane & 31, h = lane >> 5;
     const int m = blockIdx.x * 128 + wave * 32 + r;
     const int mc = m < p.M ? m : p.M - 1;
@@ -69,7 +72,13 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
     const int T = KB + (nhc - 1) * SPH + S2;    // stream: W1(0) | W1(1) W2(0) | ... | W1(nhc-1) W2(nhc-2) | W2(nhc-1)
 
     // ---- LDS-DMA of stream step t into ring slot t % RING ----------------------------------------------
-    auto issue = [&](int t) {
+    // Per-lane source offsets (elements) of the 8 one-KB pieces this wave moves per step are computed once; a step
+    // then only adds a wave-uniform base.  256-B-row layout (W1, and W2 when C = 128): piece I = rows 4I..4I+3,
+    // source chunk q = (lane&15) ^ (row&15).  128-B-row layout (W2 when C = 256): piece I = rows 8I..8I+7,
+    // q = (lane&7) ^ ((row>>1)&7).
+    const int row0 = wave * (DMA_PER_STEP * 4) + (lane >> 4), l15 = lane & 15;        // 256-B-row layout
+    const int row0b = wave * (DMA_PER_STEP * 8) + (lane >> 3), l7 = lane & 7;         // 128-B-row layout
+    auto issue = [&](int t) __attribute__((always_inline)) {
         bool is_w1; int hc, idx;
         if (t < KB) { is_w1 = true; hc = 0; idx = t; }
         else {
@@ -77,21 +86,36 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
             if (b < nhc - 1 && o < KB) { is_w1 = true; hc = b + 1; idx = o; }
             else { is_w1 = false; hc = b; idx = b < nhc - 1 ? o - KB : o; }
         }
-        unsigned char* slot = lds + (t % RING) * SLOT;
+        unsigned char* slot = lds + (t % RING) * SLOT + wave * DMA_PER_STEP * 1024;
+        if (is_w1) {
+            const bf16_t* base = p.w1 + (size_t)hc * 128 * C + idx * 128;                 // wave-uniform
 #pragma unroll
-        for (int i = 0; i < DMA_PER_STEP; ++i) {
-            const int I = wave * DMA_PER_STEP + i;                 // 1-KB piece of the slot
-            const bf16_t* src;
-            if (is_w1 || ROW2 == 256) {
-                const int row = 4 * I + (lane >> 4), q = (lane & 15) ^ (row & 15);
-                src = is_w1 ? p.w1 + (size_t)(hc * 128 + row) * C + idx * 128 + q * 8
-                            : p.w2 + (size_t)row * p.HID + hc * 128 + q * 8;
-            } else {
-                const int row = 8 * I + (lane >> 3), q = (lane & 7) ^ ((row >> 1) & 7);
-                src = p.w2 + (size_t)row * p.HID + hc * 128 + idx * 64 + q * 8;
+            for (int i = 0; i < DMA_PER_STEP; ++i) {
+                const int row = row0 + 4 * i;
+                const int off = row * C + ((l15 ^ (row & 15)) << 3);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
+                                                 (__attribute__((address_space(3))) void*)(slot + i * 1024), 16, 0, 0);
             }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(slot + I * 1024), 16, 0, 0);
+        } else if (ROW2 == 256) {
+            const bf16_t* base = p.w2 + hc * 128;
+            const int hid = p.HID;
+#pragma unroll
+            for (int i = 0; i < DMA_PER_STEP; ++i) {
+                const int row = row0 + 4 * i;
+                const int off = row0 * hid + (4 * i) * hid + ((l15 ^ (row & 15)) << 3);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
+                                                 (__attribute__((address_space(3))) void*)(slot + i * 1024), 16, 0, 0);
+            }
+        } else {
+            const bf16_t* base = p.w2 + hc * 128 + idx * JB2;
+            const int hid = p.HID;
+#pragma unroll
+            for (int i = 0; i < DMA_PER_STEP; ++i) {
+                const int row = row0b + 8 * i;
+                const int off = row0b * hid + (8 * i) * hid + ((l7 ^ ((row >> 1) & 7)) << 3);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
+                                                 (__attribute__((address_space(3))) void*)(slot + i * 1024), 16, 0, 0);
+            }
         }
     };
 
@@ -154,13 +178,24 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
 
     // ---- per-step synchronisation: my DMAs of step t have landed -> barrier -> everyone's have, and everyone
     //      is done reading step t-1, whose slot is the one step t+AHEAD goes into -----------------------------
+#ifdef MLP_CLOCK_PROBE
+    unsigned long long probe_sec[6] = {0, 0, 0, 0, 0, 0}, probe_last = 0;     // wait+barrier, DMA issue, phase 1, phase 2, prologue, epilogue
+#define PROBE_MARK() do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); probe_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PROBE_ADD(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); probe_sec[i] += t_ - probe_last; probe_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PROBE_MARK() do {} while (0)
+#define PROBE_ADD(i) do {} while (0)
+#endif
     int t_cons = 0;
-    auto begin_step = [&]() {
+    auto begin_step = [&]() __attribute__((always_inline)) {
+        PROBE_MARK();
         const int ahead = t_issue - 1 - t_cons;             // steps issued beyond the one about to be consumed
         if (ahead >= 2) WAIT_VMCNT(16); else if (ahead == 1) WAIT_VMCNT(8); else WAIT_VMCNT(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        PROBE_ADD(0);
         if (t_issue < T) { issue(t_issue); ++t_issue; }
+        PROBE_ADD(1);
         const unsigned char* slot = lds + (t_cons % RING) * SLOT;
         ++t_cons;
         return slot;
@@ -183,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
 
     // bias + GELU + pack of registers 8s..8s+7 of tile jt (one k-step of phase 2), then the half-wave exchange
     // that turns the accumulator k order into the natural one
-    auto gelu_kstep = [&](int hc_prev, int jt, int s) {
+    auto gelu_kstep = [&](int hc_prev, int jt, int s) __attribute__((always_inline)) {
         unsigned u[4];
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2) {
@@ -213,7 +248,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
 #define LGKM_WAIT(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
     auto lds_off = [&](const unsigned char* ptr) { return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)ptr; };
 
-    auto phase1_step = [&](const unsigned char* slot, int kb, bool pipe, int hc_prev) {
+    auto phase1_step = [&](const unsigned char* slot, int kb, bool pipe, int hc_prev) __attribute__((always_inline)) {
         const unsigned base = lds_off(slot) + r * 256;
         u32x4 a[2][4];
         auto rd = [&](int buf, int s) {
@@ -238,7 +273,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
             }
         }
     };
-    auto phase2_step = [&](const unsigned char* slot, int sb) {
+    auto phase2_step = [&](const unsigned char* slot, int sb) __attribute__((always_inline)) {
         constexpr int NG = ROW2 == 128 ? 4 : 8;                 // k-steps of 16 hidden units in this slot
         const unsigned base = lds_off(slot) + r * ROW2;
         const int xs = ROW2 == 128 ? x128 : x256;
@@ -279,10 +314,13 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
             for (int e = 0; e < 16; ++e) hacc[t][e] = 0.f;
     };
 
+#ifdef MLP_CLOCK_PROBE
+    probe_sec[4] = __builtin_amdgcn_s_memtime() - probe_t0;
+#endif
     // prologue: phase 1 of chunk 0
     zero_hacc();
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) phase1_step(begin_step(), kb, false, 0);
+    for (int kb = 0; kb < KB; ++kb) { phase1_step(begin_step(), kb, false, 0); PROBE_ADD(2); }
 
     for (int hc = 0; hc < nhc; ++hc) {
 #pragma unroll
@@ -290,7 +328,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
         if (hc + 1 < nhc) {
             zero_hacc();
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) phase1_step(begin_step(), kb, true, hc);     // + GELU(hc) in the gaps
+            for (int kb = 0; kb < KB; ++kb) { phase1_step(begin_step(), kb, true, hc); PROBE_ADD(2); }    // + GELU(hc) in the gaps
         } else {
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt)
@@ -298,38 +336,65 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
                 for (int s = 0; s < 2; ++s) gelu_kstep(hc, jt, s);
         }
 #pragma unroll
-        for (int sb = 0; sb < S2; ++sb) phase2_step(begin_step(), sb);
+        for (int sb = 0; sb < S2; ++sb) { phase2_step(begin_step(), sb); PROBE_ADD(3); }
     }
 
-    // ---- epilogue: O^T tile: lane = token m, registers = channels n = nt*32 + (e&3) + 8(e>>2) + 4h.  All residual
-    //      loads are issued before the first store (out may alias res, so the compiler would otherwise serialise
-    //      load -> wait -> store 32 times).
-    if (m < p.M) {
-        u32x2 rr[NT2][4];
-        if (p.res) {
-            const bf16_t* rp = p.res + (size_t)m * p.ldr + 4 * h;
-#pragma unroll
-            for (int nt = 0; nt < NT2; ++nt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) rr[nt][g] = *(const u32x2*)(rp + nt * 32 + 8 * g);
-        }
-        bf16_t* op = p.out + (size_t)m * p.ldo + 4 * h;
+    // ---- epilogue.  O^T tile: lane = token, registers = channels, which would mean 8-byte stores strided by the row
+    //      pitch (64 per lane, each touching 32 rows).  Instead each wave transposes its [32 tokens][C] fp32 tile through
+    //      the now idle weight ring (own 32-KB region, 16-B chunks swizzled by token&15) and walks it row by row:
+    //      residual loads and bf16 stores are whole contiguous rows.
+    PROBE_MARK();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                   // every wave is done reading the last weight slot
+    {
+        float* stage = (float*)(lds + wave * 32768);               // [32][C] fp32, row pitch C*4 bytes (<= 1 KB)
+        constexpr int CHUNKS = C / 4;                               // 16-B chunks per row
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 bv = *(const f32x4*)(b2s + nt * 32 + 8 * g + 4 * h);
-                float v[4];
+                const int c = nt * 8 + 2 * g + h;                   // chunk of channels nt*32 + 8g + 4h .. +3
+                f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = oacc[nt][4 * g + e] + bv[e];
-                if (p.res) {
-                    v[0] += __uint_as_float(rr[nt][g][0] << 16); v[1] += __uint_as_float(rr[nt][g][0] & 0xffff0000u);
-                    v[2] += __uint_as_float(rr[nt][g][1] << 16); v[3] += __uint_as_float(rr[nt][g][1] & 0xffff0000u);
-                }
-                u32x2 o; o[0] = pack_bf16x2(v[0], v[1]); o[1] = pack_bf16x2(v[2], v[3]);
-                *(u32x2*)(op + nt * 32 + 8 * g) = o;
+                for (int e = 0; e < 4; ++e) v[e] = oacc[nt][4 * g + e];
+                *(f32x4*)(stage + r * C + ((c ^ (r & 15)) << 2)) = v;
             }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // wave-private tile: LDS ops of a wave complete in order
+        constexpr int RPI = 64 / CHUNKS;                            // rows per wave instruction (1 for C=256, 2 for C=128)
+        const int q = lane % CHUNKS, rsub = lane / CHUNKS;
+        const int m0w = blockIdx.x * 128 + wave * 32;
+        const f32x4 bv = *(const f32x4*)(b2s + 4 * q);
+        u32x2 rr[32 / RPI];
+        if (p.res) {
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) {
+                const int mm = m0w + it * RPI + rsub;
+                rr[it] = mm < p.M ? *(const u32x2*)(p.res + (size_t)mm * p.ldr + 4 * q) : u32x2{0u, 0u};
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int row = it * RPI + rsub, mm = m0w + row;
+            f32x4 v = *(const f32x4*)(stage + row * C + ((q ^ (row & 15)) << 2));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bv[e];
+            if (p.res) {
+                v[0] += __uint_as_float(rr[it][0] << 16); v[1] += __uint_as_float(rr[it][0] & 0xffff0000u);
+                v[2] += __uint_as_float(rr[it][1] << 16); v[3] += __uint_as_float(rr[it][1] & 0xffff0000u);
+            }
+            u32x2 o; o[0] = pack_bf16x2(v[0], v[1]); o[1] = pack_bf16x2(v[2], v[3]);
+            if (mm < p.M) *(u32x2*)(p.out + (size_t)mm * p.ldo + 4 * q) = o;
+        }
     }
+#ifdef MLP_CLOCK_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PROBE_ADD(5);
+    if (tid == 0 && g_probe) {
+        g_probe[blockIdx.x * 4] = probe_t0; g_probe[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+        g_probe[blockIdx.x * 4 + 2] = probe_r0; g_probe[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+        for (int i = 0; i < 6; ++i) g_probe[gridDim.x * 4 + blockIdx.x * 6 + i] = probe_sec[i];
+    }
+#endif
 }
 
 template <int C>
