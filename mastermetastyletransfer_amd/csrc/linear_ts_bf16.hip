@@ -6,10 +6,11 @@
 // wave w owns tokens [32w, 32w+32).  The product is computed transposed, O^T[n][m] = sum_k W[n][k] X[m][k]:
 // the token sits on the MFMA lane, the X fragments of the whole row (K <= 512) stay in registers for the entire
 // kernel (LayerNorm applied there), and the weight matrix is the only thing that streams - 32-KB steps
-// ([128 n][128 k]) through a 4-slot LDS ring by LDS-DMA, three steps ahead, counted vmcnt + one raw barrier per
+// ([128 n][128 k]) through a 3-slot LDS ring by LDS-DMA, two steps ahead, counted vmcnt + one raw barrier per
 // step, source-swizzled so the fragment ds_read_b128 are conflict-free.  Output columns are produced in chunks of
-// 128; a chunk's epilogue (bias, r1, r2, bf16 stores) runs while the next chunks' weights are already in flight.
-// Residual operands (N <= 256) are fetched once up front, so the loop contains no ordinary global load.
+// 128; a chunk's epilogue runs while the next chunks' weights are already in flight: each wave transposes its
+// O^T accumulators through a private fp32 LDS tile and emits contiguous row segments (bias, r1, r2, bf16 stores).
+// Residual operands (N <= 256) are fetched once up front in that row layout, so the loop has no ordinary global load.
 #include "common.h"
 
 namespace {
@@ -26,7 +27,8 @@ struct LinArgs {
 
 union Frag { u32x4 u; bf16x8_t b; };
 
-constexpr int SLOT = 32768, RING = 4, AHEAD = 3, DMA_PER_STEP = 8;
+constexpr int SLOT = 32768, RING = 3, AHEAD = 2, DMA_PER_STEP = 8;
+constexpr int STAGE = 32768;     // epilogue staging: 4 waves x [32 tokens][64 channels] fp32
 
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define LDS_READ128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:" #imm : "=v"(dst) : "v"(addr))
@@ -36,10 +38,9 @@ template <int K, bool RES>
 __global__ __launch_bounds__(256, 1) void linear_ts_bf16_kernel(LinArgs p) {
     constexpr int KS = K / 16;                  // k-steps over the whole row
     constexpr int KB = K / 128;                 // 32-KB weight steps per 128-column chunk
-    constexpr int RT = RES ? 8 : 1;             // residual tiles held in registers (N <= 256)
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [RING][SLOT] weights | bias[N] | ln_g[K] | ln_b[K]
-    float* bs = (float*)(lds + RING * SLOT);
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [RING][SLOT] weights | stage | bias[N] | ln_g[K] | ln_b[K]
+    float* bs = (float*)(lds + RING * SLOT + STAGE);
     float* lng = bs + p.N;
     float* lnb = lng + K;
 
@@ -51,16 +52,17 @@ __global__ __launch_bounds__(256, 1) void linear_ts_bf16_kernel(LinArgs p) {
     const int nch = p.N / 128;
     const int T = nch * KB;
 
-    auto issue = [&](int t) {
+    const int row0 = wave * (DMA_PER_STEP * 4) + (lane >> 4), l15 = lane & 15;
+    auto issue = [&](int t) __attribute__((always_inline)) {
         const int nc = t / KB, kb = t - nc * KB;
-        unsigned char* slot = lds + (t % RING) * SLOT;
+        unsigned char* slot = lds + (t % RING) * SLOT + wave * DMA_PER_STEP * 1024;
+        const bf16_t* base = p.w + (size_t)nc * 128 * K + kb * 128;               // wave-uniform
 #pragma unroll
         for (int i = 0; i < DMA_PER_STEP; ++i) {
-            const int I = wave * DMA_PER_STEP + i;
-            const int row = 4 * I + (lane >> 4), q = (lane & 15) ^ (row & 15);     // source swizzle (see mlp_bf16.hip)
-            const bf16_t* src = p.w + (size_t)(nc * 128 + row) * K + kb * 128 + q * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(slot + I * 1024), 16, 0, 0);
+            const int row = row0 + 4 * i;                                          // piece = 4 rows x 256 B, source-swizzled
+            const int off = row * K + ((l15 ^ (row & 15)) << 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
+                                             (__attribute__((address_space(3))) void*)(slot + i * 1024), 16, 0, 0);
         }
     };
     int t_issue = 0;
@@ -69,20 +71,22 @@ __global__ __launch_bounds__(256, 1) void linear_ts_bf16_kernel(LinArgs p) {
     for (int i = tid; i < p.N; i += 256) bs[i] = p.bias ? p.bias[i] : 0.f;
     if (p.ln_g) for (int i = tid; i < K; i += 256) { lng[i] = p.ln_g[i]; lnb[i] = p.ln_b[i]; }
 
-    // residual operands of this lane: token m, channels nt*32 + 8g + 4h .. +3
-    u32x2 rr1[RT][4], rr2[RT][4];
+    // residual operands, fetched once in the layout of the epilogue's row pass: iteration (nc, half, it) handles rows
+    // it*4 + (lane>>4) of this wave's 32 tokens, channels nc*128 + half*64 + (lane&15)*4 .. +3  (128-B row segments)
+    const int m0w = blockIdx.x * 128 + wave * 32;
+    u32x2 rq1[RES ? 32 : 1], rq2[RES ? 32 : 1];
     if (RES) {
 #pragma unroll
-        for (int nt = 0; nt < RT; ++nt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                rr1[nt][g] = u32x2{0u, 0u}; rr2[nt][g] = u32x2{0u, 0u};
-                if (nt * 32 < p.N) {
-                    const size_t off = (size_t)mc * p.ldr + nt * 32 + 8 * g + 4 * h;
-                    if (p.r1) rr1[nt][g] = *(const u32x2*)(p.r1 + off);
-                    if (p.r2) rr2[nt][g] = *(const u32x2*)(p.r2 + off);
-                }
+        for (int j = 0; j < 32; ++j) {
+            const int nc = j >> 4, half = (j >> 3) & 1, it = j & 7;
+            const int mm = m0w + it * 4 + (lane >> 4);
+            const int n = nc * 128 + half * 64 + (lane & 15) * 4;
+            rq1[j] = u32x2{0u, 0u}; rq2[j] = u32x2{0u, 0u};
+            if (n < p.N && mm < p.M) {
+                if (p.r1) rq1[j] = *(const u32x2*)(p.r1 + (size_t)mm * p.ldr + n);
+                if (p.r2) rq2[j] = *(const u32x2*)(p.r2 + (size_t)mm * p.ldr + n);
             }
+        }
     }
 
     Frag xf[KS];
@@ -130,11 +134,11 @@ __global__ __launch_bounds__(256, 1) void linear_ts_bf16_kernel(LinArgs p) {
     }
 
     int t_cons = 0;
-    auto begin_step = [&]() {
+    auto begin_step = [&]() __attribute__((always_inline)) {
         // conservative count: stores of the previous chunk's epilogue are younger than every DMA, so "at most 16 (8)
         // outstanding" still implies the DMAs of step t_cons have landed
         const int ahead = t_issue - 1 - t_cons;
-        if (ahead >= 2) WAIT_VMCNT(16); else if (ahead == 1) WAIT_VMCNT(8); else WAIT_VMCNT(0);
+        if (ahead >= 1) WAIT_VMCNT(8); else WAIT_VMCNT(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (t_issue < T) { issue(t_issue); ++t_issue; }
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void linear_ts_bf16_kernel(LinArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
     };
-    auto step = [&](const unsigned char* slot, int kb) {
+    auto step = [&](const unsigned char* slot, int kb) __attribute__((always_inline)) {
         const unsigned base = lds_off(slot) + r * 256;
         u32x4 a[2][4];
         auto rd = [&](int buf, int s) {
@@ -171,23 +175,35 @@ __global__ __launch_bounds__(256, 1) void linear_ts_bf16_kernel(LinArgs p) {
             }
         }
     };
-    // epilogue of output columns [nc*128, nc*128+128): lane = token m, acc[jt][4g+e] = column nc*128 + jt*32 + 8g + 4h + e
-    const bool wave_live = (blockIdx.x * 128 + wave * 32) < p.M;          // wave-uniform
-    auto epilogue = [&](int nc) {
-        if (!wave_live) return;
-        bf16_t* op = p.out + (size_t)mc * p.ldo + nc * 128 + 4 * h;
+    // epilogue of output columns [nc*128, nc*128+128).  The accumulators hold O^T (lane = token, registers = channels);
+    // storing that directly means 8-byte stores strided by the row pitch.  Each wave instead transposes half a chunk
+    // (2 tiles = 64 channels) at a time through its private fp32 staging tile and emits 128-B row segments.
+    auto epilogue = [&](int nc) __attribute__((always_inline)) {
+        float* stage = (float*)(lds + RING * SLOT + wave * 8192);              // [32 tokens][64 ch] fp32, 16-B chunks swizzled by token&15
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
+        for (int half = 0; half < 2; ++half) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 bv = *(const f32x4*)(bs + nc * 128 + jt * 32 + 8 * g + 4 * h);
-                float v[4];
+            for (int j2 = 0; j2 < 2; ++j2)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[jt][4 * g + e] + bv[e];
+                for (int g = 0; g < 4; ++g) {
+                    const int jt = half * 2 + j2;
+                    const int c = j2 * 8 + 2 * g + h;                           // 16-B chunk of channels j2*32 + 8g + 4h .. +3 within the half
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[jt][4 * g + e];
+                    *(f32x4*)(stage + r * 64 + ((c ^ (r & 15)) << 2)) = v;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const f32x4 bv = *(const f32x4*)(bs + nc * 128 + half * 64 + (lane & 15) * 4);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 4 + (lane >> 4), mm = m0w + row;
+                f32x4 v = *(const f32x4*)(stage + row * 64 + (((lane & 15) ^ (row & 15)) << 2));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += bv[e];
                 if (RES) {
-                    // residual tile index nc*4 + jt is compile-time only per (nc in {0,1}): select with a uniform branch
-                    u32x2 a1, a2;
-                    if (nc == 0) { a1 = rr1[jt][g]; a2 = rr2[jt][g]; } else { a1 = rr1[(4 + jt) % RT][g]; a2 = rr2[(4 + jt) % RT][g]; }
+                    const u32x2 a1 = nc == 0 ? rq1[half * 8 + it] : rq1[(16 + half * 8 + it) % (RES ? 32 : 1)];
+                    const u32x2 a2 = nc == 0 ? rq2[half * 8 + it] : rq2[(16 + half * 8 + it) % (RES ? 32 : 1)];
                     if (p.r1) {
                         v[0] *= __uint_as_float(a1[0] << 16); v[1] *= __uint_as_float(a1[0] & 0xffff0000u);
                         v[2] *= __uint_as_float(a1[1] << 16); v[3] *= __uint_as_float(a1[1] & 0xffff0000u);
@@ -198,8 +214,10 @@ __global__ __launch_bounds__(256, 1) void linear_ts_bf16_kernel(LinArgs p) {
                     }
                 }
                 u32x2 o; o[0] = pack_bf16x2(v[0], v[1]); o[1] = pack_bf16x2(v[2], v[3]);
-                if (m < p.M) *(u32x2*)(op + jt * 32 + 8 * g) = o;
+                if (mm < p.M) *(u32x2*)(p.out + (size_t)mm * p.ldo + nc * 128 + half * 64 + (lane & 15) * 4) = o;
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // tile reads done before the next half overwrites it
+        }
     };
 
     for (int nc = 0; nc < nch; ++nc) {
@@ -212,7 +230,7 @@ __global__ __launch_bounds__(256, 1) void linear_ts_bf16_kernel(LinArgs p) {
 
 template <int K, bool RES>
 int launch(const LinArgs& p, hipStream_t s) {
-    const size_t lds = (size_t)RING * SLOT + (size_t)(p.N + 2 * K) * sizeof(float);
+    const size_t lds = (size_t)RING * SLOT + STAGE + (size_t)(p.N + 2 * K) * sizeof(float);
     static size_t attr_set = 0;
     if (attr_set < lds) {
         (void)hipFuncSetAttribute((const void*)linear_ts_bf16_kernel<K, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
