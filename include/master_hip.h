@@ -131,9 +131,11 @@ int master_layernorm_fwd(const void* x, const void* gamma, const void* beta, voi
 /* InstanceNorm2d(affine=False) on a token-major map: per (b, c) over the T tokens of image b, biased
  * variance.  When n_pad > 0 the statistics also include n_pad copies of pad_row_in[c] (the bias-only
  * rows of the zero-padded map, style_transformer.py:520-530) and pad_row_out[b, c] receives the
- * normalised pad row.  Replaces style_transformer.py:468, :1056-1057, :526. */
+ * normalised pad row.  repeat = 2 applies the norm twice in one launch (Query is instance-normalised at :1056 and
+ * again at :468; the second pass of a mean-0 map only rescales by rsqrt(v/(v+eps) + eps)); repeat = 1 otherwise.
+ * Replaces style_transformer.py:468, :1056-1057, :526. */
 int master_instnorm_fwd(const void* x, void* out, const void* pad_row_in, void* pad_row_out, int B, int T,
-                        int C, int n_pad, float eps, int dtype, master_stream_t stream);
+                        int C, int n_pad, float eps, int repeat, int dtype, master_stream_t stream);
 
 /* Swin patch embedding: Conv2d(3, E, 4, stride 4) on an fp32 NCHW image, NHWC output, LayerNorm(E)
  * fused.  w is the conv weight [E, 3, 4, 4] flattened to [E, 48].  (torchvision swin_b.features[0];

@@ -22,7 +22,7 @@ int window_attn_bf16(const bf16_t*, const bf16_t*, const bf16_t*, const bf16_t*,
                      const bf16_t*, const bf16_t*, int, int, const float*, const int32_t*, const uint8_t*, bf16_t*,
                      bf16_t*, int, int, int, int, int, int, float, hipStream_t);
 template <typename T> int layernorm_launch(const void*, const void*, const void*, void*, int, int, float, int, int, int, int, hipStream_t);
-template <typename T> int instnorm_launch(const void*, void*, const void*, void*, int, int, int, int, float, hipStream_t);
+template <typename T> int instnorm_launch(const void*, void*, const void*, void*, int, int, int, int, float, int, hipStream_t);
 template <typename T> int patch_embed_launch(const float*, const void*, const void*, const void*, const void*, void*, int, int, int, float, hipStream_t);
 int convert_launch(const void*, void*, size_t, int, int, hipStream_t);
 int linear_ts_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const bf16_t*, bf16_t*,
@@ -243,14 +243,15 @@ int master_layernorm_fwd(const void* x, const void* gamma, const void* beta, voi
 }
 
 int master_instnorm_fwd(const void* x, void* out, const void* pad_row_in, void* pad_row_out, int B, int T, int C,
-                        int n_pad, float eps, int dtype, master_stream_t stream) {
+                        int n_pad, float eps, int repeat, int dtype, master_stream_t stream) {
     REQUIRE(x && out, "instnorm: null operand");
     REQUIRE(B > 0 && T > 0 && C > 0 && C % 32 == 0, "instnorm: need C%%32==0 (C=%d)", C);
     REQUIRE(n_pad >= 0 && (n_pad == 0 || pad_row_in), "instnorm: n_pad>0 needs pad_row_in");
+    REQUIRE(repeat == 1 || (repeat == 2 && n_pad == 0), "instnorm: repeat must be 1, or 2 without pad rows");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_INSTNORM, s);
-    if (dtype == MASTER_F32) return instnorm_launch<float>(x, out, pad_row_in, pad_row_out, B, T, C, n_pad, eps, s);
-    if (dtype == MASTER_BF16) return instnorm_launch<bf16_t>(x, out, pad_row_in, pad_row_out, B, T, C, n_pad, eps, s);
+    if (dtype == MASTER_F32) return instnorm_launch<float>(x, out, pad_row_in, pad_row_out, B, T, C, n_pad, eps, repeat, s);
+    if (dtype == MASTER_BF16) return instnorm_launch<bf16_t>(x, out, pad_row_in, pad_row_out, B, T, C, n_pad, eps, repeat, s);
     master_set_error("instnorm: bad dtype %d", dtype);
     return MASTER_ERR_INVALID;
 }

@@ -114,12 +114,96 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
 }
 
-// ---- InstanceNorm over tokens: block = (image b, 32-channel strip); 256 threads = 32 token groups x
-//      8 float4 channel chunks, so a wave reads 8 rows x 128 B.  Three sweeps of a 128-KB strip (L2). --
+// ---- InstanceNorm over tokens: block = (image b, 32-channel strip); a wave reads 8 (fp32) or 16 (bf16) rows x 128/64 B.
+//      REG variant (T <= 256*ROWS/chunks-per-row): the whole strip lives in registers - one HBM read, one write, statistics
+//      two-pass on the registers.  Generic variant: three sweeps of the strip (the 2nd and 3rd from L2). -----------------
+template <typename T, int ROWS>
+__global__ __launch_bounds__(256) void instnorm_reg_kernel(const T* __restrict__ x, T* __restrict__ out,
+                                                           const T* __restrict__ pad_in, T* __restrict__ pad_out, int Tn,
+                                                           int C, int n_pad, float eps, int repeat) {
+    constexpr int VEC = Vec16<T>::N;                 // elements per 16-B chunk
+    constexpr int CPR = 32 / VEC;                    // chunks per 32-channel row segment (8 fp32, 4 bf16)
+    constexpr int TG = 256 / CPR;                    // token groups
+    __shared__ float red[4][33];
+    const int strips = C >> 5;
+    const int b = blockIdx.x / strips, c0 = (blockIdx.x % strips) * 32;
+    const int cq = threadIdx.x % CPR, tg = threadIdx.x / CPR;
+    const T* xb = x + (size_t)b * Tn * C + c0 + cq * VEC;
+    T* ob = out + (size_t)b * Tn * C + c0 + cq * VEC;
+    float v[ROWS][VEC];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        const int t = tg + i * TG;
+        if (t < Tn) Vec16<T>::load(xb + (size_t)t * C, v[i]);
+        else
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[i][e] = 0.f;
+    }
+    float pr[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) pr[e] = 0.f;
+    if (n_pad > 0) Vec16<T>::load(pad_in + c0 + cq * VEC, pr);
+    const float cnt = (float)(Tn + n_pad);
+
+    auto block_sum = [&](float* a) {                 // a[VEC] summed over the TG token groups, result broadcast
+        // lanes of a wave that share cq differ by multiples of CPR: butterfly over those, then 4 partials through LDS
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+#pragma unroll
+            for (int o = CPR; o < 64; o <<= 1) a[e] += __shfl_xor(a[e], o, 64);
+        const int wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) < CPR)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) red[wv][cq * VEC + e] = a[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] = red[0][cq * VEC + e] + red[1][cq * VEC + e] + red[2][cq * VEC + e] + red[3][cq * VEC + e];
+        __syncthreads();
+    };
+    float mean[VEC], var[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { mean[e] = 0.f; for (int i = 0; i < ROWS; ++i) mean[e] += v[i][e]; }
+    block_sum(mean);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) mean[e] = (mean[e] + (float)n_pad * pr[e]) / cnt;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        var[e] = 0.f;
+        for (int i = 0; i < ROWS; ++i) { const float d = (tg + i * TG < Tn) ? v[i][e] - mean[e] : 0.f; var[e] += d * d; }
+    }
+    block_sum(var);
+    float rstd[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const float dp = pr[e] - mean[e];
+        const float vr = (var[e] + (float)n_pad * dp * dp) / cnt;
+        rstd[e] = rsqrtf(vr + eps);
+        // InstanceNorm applied twice (reference style_transformer.py:1056 then :468): the first output has mean 0 and
+        // variance vr/(vr+eps), so the second pass only rescales by rsqrt(vr/(vr+eps) + eps)
+        if (repeat == 2) rstd[e] *= rsqrtf(vr * rstd[e] * rstd[e] + eps);
+    }
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        const int t = tg + i * TG;
+        if (t < Tn) {
+            float o[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = (v[i][e] - mean[e]) * rstd[e];
+            Vec16<T>::store(ob + (size_t)t * C, o);
+        }
+    }
+    if (n_pad > 0 && pad_out && tg == 0) {
+        float o[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = (pr[e] - mean[e]) * rstd[e];
+        Vec16<T>::store(pad_out + (size_t)b * C + c0 + cq * VEC, o);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void instnorm_kernel(const T* __restrict__ x, T* __restrict__ out,
                                                        const T* __restrict__ pad_in, T* __restrict__ pad_out, int Tn,
-                                                       int C, int n_pad, float eps) {
+                                                       int C, int n_pad, float eps, int repeat) {
     __shared__ f32x4 red[32][8];
     const int strips = C >> 5;
     const int b = blockIdx.x / strips, c0 = (blockIdx.x % strips) * 32;
@@ -154,7 +238,9 @@ __global__ __launch_bounds__(256) void instnorm_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float dp = pr[e] - mean[e];
-        rstd[e] = rsqrtf((var[e] + (float)n_pad * dp * dp) / cnt + eps);
+        const float vr = (var[e] + (float)n_pad * dp * dp) / cnt;
+        rstd[e] = rsqrtf(vr + eps);
+        if (repeat == 2) rstd[e] *= rsqrtf(vr * rstd[e] * rstd[e] + eps);
     }
     for (int t = tg; t < Tn; t += 32)
         Vec4<T>::store(ob + (size_t)t * C, (Vec4<T>::load(xb + (size_t)t * C) - mean) * rstd);
@@ -282,13 +368,21 @@ template int layernorm_launch<bf16_t>(const void*, const void*, const void*, voi
 
 template <typename T>
 int instnorm_launch(const void* x, void* out, const void* pad_in, void* pad_out, int B, int Tn, int C, int n_pad,
-                    float eps, hipStream_t s) {
-    hipLaunchKernelGGL((instnorm_kernel<T>), dim3(B * (C / 32)), dim3(256), 0, s, (const T*)x, (T*)out,
-                       (const T*)pad_in, (T*)pad_out, Tn, C, n_pad, eps);
+                    float eps, int repeat, hipStream_t s) {
+    constexpr int TG = 256 / (32 / Vec16<T>::N);
+    if (Tn <= TG * 16)         // whole strip in registers: one read, one write
+        hipLaunchKernelGGL((instnorm_reg_kernel<T, 16>), dim3(B * (C / 32)), dim3(256), 0, s, (const T*)x, (T*)out,
+                           (const T*)pad_in, (T*)pad_out, Tn, C, n_pad, eps, repeat);
+    else if (Tn <= TG * 32 && sizeof(T) == 4)      // fp32: 32 rows x 4 values per thread
+        hipLaunchKernelGGL((instnorm_reg_kernel<T, 32>), dim3(B * (C / 32)), dim3(256), 0, s, (const T*)x, (T*)out,
+                           (const T*)pad_in, (T*)pad_out, Tn, C, n_pad, eps, repeat);
+    else
+        hipLaunchKernelGGL((instnorm_kernel<T>), dim3(B * (C / 32)), dim3(256), 0, s, (const T*)x, (T*)out,
+                           (const T*)pad_in, (T*)pad_out, Tn, C, n_pad, eps, repeat);
     return master_check_launch("instnorm");
 }
-template int instnorm_launch<float>(const void*, void*, const void*, void*, int, int, int, int, float, hipStream_t);
-template int instnorm_launch<bf16_t>(const void*, void*, const void*, void*, int, int, int, int, float, hipStream_t);
+template int instnorm_launch<float>(const void*, void*, const void*, void*, int, int, int, int, float, int, hipStream_t);
+template int instnorm_launch<bf16_t>(const void*, void*, const void*, void*, int, int, int, int, float, int, hipStream_t);
 
 template <typename T>
 int patch_embed_launch(const float* img, const void* w, const void* bias, const void* g, const void* b, void* out,

@@ -310,11 +310,11 @@ class ShiftedWindowAttention_for_decoder_last_MHA(_WindowAttentionBase):
         self._init_rel_pos(num_heads)
 
     def sigma_mu(self, xq: Tensor, xk: Tensor, xs: Tensor, xsh: Tensor, B: int, H: int, W: int,
-                 fuse_query: Optional[Tensor] = None):
+                 fuse_query: Optional[Tensor] = None, q_norm_repeat: int = 1):
         """token-matrix form.  Returns (sigma, mu), or Query*sigma+mu when fuse_query is given
         (style_transformer.py:1123 folded into the second proj's epilogue)."""
         T = H * W
-        q, _ = ops.instnorm(xq, B, T)                                               # :468
+        q, _ = ops.instnorm(xq, B, T, repeat=q_norm_repeat)                         # :468 (repeat=2: also the caller's :1056)
         if not self.use_Key_instance_norm_after_linear_transformation:
             xk, _ = ops.instnorm(xk, B, T)                                          # :470-472
         k = ops.linear(xk, self._w("k", self.Wk.weight), self._b("k", self.Wk.bias))
@@ -438,9 +438,10 @@ class StyleDecoder(_HipModule):
     def run(self, fcs: Tensor, key: Tensor, scale: Tensor, shift: Tensor, B, H, W) -> Tensor:
         T = H * W
         query = self.MHA_self_attn.run(fcs, fcs, [fcs], [fcs], B, H, W)[0]                     # :1047
-        q_in, _ = ops.instnorm(query, B, T)                                                    # :1056
         k_in, _ = ops.instnorm(key, B, T)                                                      # :1057
-        query = self.decoder_MHA_for_sigma_and_mu.sigma_mu(q_in, k_in, scale, shift, B, H, W, fuse_query=query)  # :1059,:1123
+        # Query is instance-normalised here (:1056) and once more inside the sigma/mu attention (:468): one launch
+        query = self.decoder_MHA_for_sigma_and_mu.sigma_mu(query, k_in, scale, shift, B, H, W, fuse_query=query,
+                                                           q_norm_repeat=2)                    # :1056,:1059,:1123
         return _mlp_fwd(self, "last_mlp", self.last_MLP, query, query)                         # :1125
 
     def forward(self, Fcs: Tensor, Key: Tensor, Scale: Tensor, Shift: Tensor) -> Tensor:

@@ -74,7 +74,7 @@ def load_library() -> ctypes.CDLL:
     lib.master_conv3x3_reflect_fwd.argtypes = [vp] * 4 + [ci] * 9 + [vp]
     lib.master_window_attn_fwd.argtypes = [vp] * 4 + [ci] * 3 + [vp] * 3 + [ci] * 2 + [vp] * 3 + [vp] * 2 + [ci] * 6 + [cf, ci, vp]
     lib.master_layernorm_fwd.argtypes = [vp] * 4 + [ci, ci, cf, ci, vp]
-    lib.master_instnorm_fwd.argtypes = [vp] * 4 + [ci] * 4 + [cf, ci, vp]
+    lib.master_instnorm_fwd.argtypes = [vp] * 4 + [ci] * 4 + [cf, ci, ci, vp]
     lib.master_patch_embed_fwd.argtypes = [vp] * 6 + [ci] * 4 + [cf, ci, vp]
     lib.master_patch_merge_ln_fwd.argtypes = [vp] * 4 + [ci] * 4 + [cf, ci, vp]
     lib.master_convert.argtypes = [vp, vp, ctypes.c_size_t, ci, ci, vp]
@@ -273,8 +273,9 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     return out
 
 
-def instnorm(x: torch.Tensor, B: int, T: int, pad_row: Optional[torch.Tensor] = None, n_pad: int = 0, eps: float = 1e-5):
-    """x [B*T, C].  Returns (normalised x, normalised pad rows [B,C] or None)."""
+def instnorm(x: torch.Tensor, B: int, T: int, pad_row: Optional[torch.Tensor] = None, n_pad: int = 0, eps: float = 1e-5,
+             repeat: int = 1):
+    """x [B*T, C].  Returns (normalised x, normalised pad rows [B,C] or None).  repeat=2: InstanceNorm applied twice."""
     _dev(x)
     C = x.shape[1]
     assert x.is_contiguous() and x.shape[0] == B * T
@@ -282,7 +283,7 @@ def instnorm(x: torch.Tensor, B: int, T: int, pad_row: Optional[torch.Tensor] = 
     pad_out = torch.empty((B, C), dtype=x.dtype, device=x.device) if n_pad > 0 else None
     if _COUNT_ON:
         _count("instnorm", bytes=2.0 * x.element_size() * x.numel())
-    _check(load_library().master_instnorm_fwd(_p(x), _p(out), _p(pad_row), _p(pad_out), B, T, C, n_pad, eps, _dt(x),
+    _check(load_library().master_instnorm_fwd(_p(x), _p(out), _p(pad_row), _p(pad_out), B, T, C, n_pad, eps, repeat, _dt(x),
                                                _stream()), "master_instnorm_fwd")
     return out, pad_out
 

@@ -98,6 +98,11 @@ def test_instnorm(cuda, B, T, C, n_pad):
     assert_close(out.view(B, T, C), ref[:, :T], "instnorm", 1e-5)
     if n_pad:
         assert_close(pad, ref[:, T], "instnorm pad row", 1e-5)
+    else:
+        # InstanceNorm applied twice in one launch (reference :1056 then :468)
+        ref2 = F.instance_norm(ref.permute(0, 2, 1), eps=1e-5).permute(0, 2, 1)
+        out2, _ = ops.instnorm(x.reshape(B * T, C).to(cuda), B, T, repeat=2)
+        assert_close(out2.view(B, T, C), ref2, "instnorm x2", 1e-5)
 
 
 def test_patch_embed_and_merge(cuda):
