@@ -67,7 +67,7 @@ def main():
 
     import torch.distributed as dist
     from mastermetastyletransfer_amd import ops
-    from mastermetastyletransfer_amd.distributed import all_gather_images, init_from_env
+    from mastermetastyletransfer_amd.distributed import AsyncImageGather, init_from_env
 
     rank, world, device = init_from_env()
     if world != args.gpus:
@@ -79,11 +79,15 @@ def main():
     B, S, k = args.batch, args.size, args.layers
     content, style = synthetic_batch(B, S, device, seed=rank)      # each rank its own shard of the global batch
 
+    # the all-gather of step i overlaps the forward of step i+1 (RCCL on its own stream, at most 2 in flight);
+    # fence() drains every outstanding collective, so the timed region contains all K gathers in full
+    gather = AsyncImageGather(B * world, rank, world, depth=2)
+
     def step():
-        out = model(content, style, k)
-        return all_gather_images(out, B * world, rank, world)
+        return gather.submit(model(content, style, k))
 
     def fence():
+        gather.wait()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -62,6 +62,43 @@ def all_gather_images(local: torch.Tensor, batch: int, rank: int, world: int) ->
     return torch.cat(parts, dim=0)
 
 
+class AsyncImageGather:
+    """All-gather of the stylized images that overlaps with the next forward: the collective is enqueued
+    asynchronously (RCCL runs it on its own stream) and at most `depth` gathers are in flight; wait() drains them.
+    Results are identical to all_gather_images; only the point where the host/stream waits moves."""
+
+    def __init__(self, batch: int, rank: int, world: int, depth: int = 2):
+        if batch % max(world, 1) != 0:
+            raise ValueError("AsyncImageGather needs equal shards (batch % world == 0)")
+        self.batch, self.rank, self.world, self.depth = batch, rank, world, depth
+        self.pending = []          # (work, output buffer, local shard kept alive)
+        self.buffers = []
+
+    def submit(self, local: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return local
+        while len(self.pending) >= self.depth:
+            self._retire()
+        local = local.contiguous()
+        out = self.buffers.pop() if self.buffers else local.new_empty((self.batch,) + tuple(local.shape[1:]))
+        work = dist.all_gather_into_tensor(out, local, async_op=True)
+        self.pending.append((work, out, local))
+        return out                 # valid after wait() (or after `depth` further submits)
+
+    def _retire(self):
+        work, out, _ = self.pending.pop(0)
+        work.wait()
+        self.buffers.append(out)   # recycled: callers that keep results must copy them before `depth` more submits
+
+    def wait(self):
+        last = None
+        while self.pending:
+            work, out, _ = self.pending.pop(0)
+            work.wait()
+            last = out
+        return last
+
+
 class ShardedStylizer:
     """stylize(content[B], style[B], k) with the batch split over the ranks of the default group."""
 

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from mastermetastyletransfer_amd.distributed import ShardedStylizer, all_gather_images, shard_range
+from mastermetastyletransfer_amd.distributed import AsyncImageGather, ShardedStylizer, all_gather_images, shard_range
 
 
 def test_shard_ranges_cover_batch():
@@ -33,7 +33,16 @@ def _worker(rank, world, port, batch, q):
         g = torch.Generator().manual_seed(0)
         c, s = torch.randn(batch, 3, 8, 8, generator=g), torch.randn(batch, 3, 8, 8, generator=g)
         out = ShardedStylizer(_fake_forward, rank, world)(c, s, 3)
-        q.put((rank, torch.equal(out, _fake_forward(c, s, 3)), tuple(out.shape)))
+        ok = torch.equal(out, _fake_forward(c, s, 3))
+        if batch % world == 0:
+            # the asynchronous gather used by bench.py: several steps in flight, same result as the blocking one
+            from mastermetastyletransfer_amd.distributed import shard_range as sr
+            lo, hi = sr(batch, rank, world)
+            ag = AsyncImageGather(batch, rank, world, depth=2)
+            outs = [ag.submit(_fake_forward(c[lo:hi], s[lo:hi], kk)) for kk in (1, 2)]
+            last = ag.wait()
+            ok = ok and torch.equal(last, _fake_forward(c, s, 2)) and torch.equal(outs[0], _fake_forward(c, s, 1))
+        q.put((rank, ok, tuple(out.shape)))
     finally:
         dist.destroy_process_group()
 
