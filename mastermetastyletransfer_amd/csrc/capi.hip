@@ -18,6 +18,9 @@ int gemm_bf16_linear(const bf16_t*, const bf16_t*, const float*, const bf16_t*, 
                      int, int, int, int, hipStream_t);
 int gemm_bf16_conv3x3(const bf16_t*, const bf16_t*, const float*, void*, int, int, int, int, int, int, int, int,
                       hipStream_t);
+int window_attn_pw_bf16(const bf16_t*, const bf16_t*, const bf16_t*, const bf16_t*, int, int, int, const bf16_t*,
+                        const bf16_t*, const bf16_t*, int, int, const float*, const int32_t*, const uint8_t*, bf16_t*,
+                        bf16_t*, int, int, int, int, int, int, float, hipStream_t);
 int window_attn_bf16(const bf16_t*, const bf16_t*, const bf16_t*, const bf16_t*, int, int, int, const bf16_t*,
                      const bf16_t*, const bf16_t*, int, int, const float*, const int32_t*, const uint8_t*, bf16_t*,
                      bf16_t*, int, int, int, int, int, int, float, hipStream_t);
@@ -204,11 +207,17 @@ int master_window_attn_fwd(const void* q, const void* k, const void* v0, const v
                                (const float*)k_pad, (const float*)v0_pad, (const float*)v1_pad, k_pad_bstride,
                                v_pad_bstride, bias, src, region, (float*)out0, (float*)out1, ldo, B, T, heads, nW, N,
                                scale, s);
-    if (dtype == MASTER_BF16)
+    if (dtype == MASTER_BF16) {
+        // persistent window-per-workgroup kernel for 8-head maps (StyleTransformer, Swin stage 2); one-problem-per-wave otherwise
+        const int rc = window_attn_pw_bf16((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v0, (const bf16_t*)v1, ldq, ldk, ldv,
+                                           (const bf16_t*)k_pad, (const bf16_t*)v0_pad, (const bf16_t*)v1_pad, k_pad_bstride,
+                                           v_pad_bstride, bias, src, region, (bf16_t*)out0, (bf16_t*)out1, ldo, B, T, heads, nW, N, scale, s);
+        if (rc != MASTER_ERR_UNSUPPORTED) return rc;
         return window_attn_bf16((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v0, (const bf16_t*)v1, ldq, ldk,
                                 ldv, (const bf16_t*)k_pad, (const bf16_t*)v0_pad, (const bf16_t*)v1_pad, k_pad_bstride,
                                 v_pad_bstride, bias, src, region, (bf16_t*)out0, (bf16_t*)out1, ldo, B, T, heads, nW,
                                 N, scale, s);
+    }
     master_set_error("window_attn: bad dtype %d", dtype);
     return MASTER_ERR_INVALID;
 }

@@ -1,0 +1,264 @@
+// Persistent window-attention core, bf16, C = 256 / 8 heads (StyleTransformer and Swin stage 2; one or two value
+// streams sharing the softmax: the sigma/mu cross attention, reference style_transformer.py:536-607, and the
+// Scale/Shift calls of the StyleEncoder :867-882).
+//
+// The one-problem-per-wave kernel (window_attn_bf16.hip) is latency-bound: every wave walks a chain of dependent
+// global loads (table -> rows -> bias) with two waves per SIMD to hide it (3 % MFMA busy).  Here a workgroup is a
+// WINDOW and stays resident: 8 waves = 8 heads, and while window i computes, the 64-slot Q / K / V(/V1) tiles of
+// window i+1 (32 KB each, all heads) are gathered by LDS-DMA with the pad/roll/partition table as per-lane source
+// address (padded slots fetch the projection-bias row).  Per window a wave
+//   1. pulls its head's Q, K and V fragments out of LDS (16-B chunks source-swizzled by row&31: conflict-free;
+//      V through ds_read_b64_tr_b16, the hardware transpose),
+//   2. frees the tiles (barrier) and fires the next window's DMA,
+//   3. S^T = K Q^T, + rel-pos bias (head-constant: held packed in 32 VGPRs for the whole kernel) + shift mask,
+//      softmax with the query on the lane, O^T = V^T P^T from the packed accumulator tile,
+//   4. stores its 32 channels of the real query tokens.
+// Gather/mask tables of the geometry sit in LDS; the loop has no ordinary global load.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int HEADS = 8, ROWB = 512;             // 8 heads x 32 ch x 2 B per token row
+constexpr int TILE = 64 * ROWB;                  // one 64-slot tile of all heads: 32 KB
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct PwArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v0; const bf16_t* v1;
+    int ldq, ldk, ldv;
+    const bf16_t* k_pad; const bf16_t* v0_pad; const bf16_t* v1_pad; int k_pad_bs, v_pad_bs;
+    const float* bias; const int32_t* src; const uint8_t* region;
+    bf16_t* out0; bf16_t* out1; int ldo;
+    int B, T, nW, N; float scale_log2e;
+};
+
+union Frag { u32x4 u; bf16x8_t b; };
+
+template <bool DUAL>
+__global__ __launch_bounds__(512, 2) void window_attn_pw_kernel(PwArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // Q | K | V0 | (V1) tiles, then src[nW][64] i32, region[nW][64] u8
+    constexpr int NT = DUAL ? 4 : 3;
+    unsigned char* Qs = lds;
+    unsigned char* Ks = lds + TILE;
+    unsigned char* V0s = lds + 2 * TILE;
+    unsigned char* V1s = lds + 3 * TILE;
+    int32_t* srcs = (int32_t*)(lds + NT * TILE);
+    uint8_t* regs = (uint8_t*)(srcs + p.nW * 64);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // = head
+    const int r = lane & 31, h = lane >> 5;
+    const int nwin = p.B * p.nW;
+
+    for (int i = tid; i < p.nW * 64; i += 512) { srcs[i] = p.src[i]; regs[i] = p.region ? p.region[i] : 0; }
+    // relative-position bias of this head, for this lane's two query rows and its 32 keys each, packed bf16x2 pairs
+    // (the table is trained at std 0.02; bf16 keeps 3 significant digits of it, like every other operand in this mode)
+    unsigned bpk[2][2][8];                                                // [q tile][key tile][pair]
+    {
+        const float* bias = p.bias + (size_t)wave * 64 * 64;
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bv = *(const f32x4*)(bias + (q2 * 32 + r) * 64 + k2 * 32 + 8 * g + 4 * h);
+                    // entries for tile-padding keys are -1e30: keep them as a large negative bf16
+                    bpk[q2][k2][2 * g] = pack_bf16x2(bv[0] * LOG2E, bv[1] * LOG2E);
+                    bpk[q2][k2][2 * g + 1] = pack_bf16x2(bv[2] * LOG2E, bv[3] * LOG2E);
+                }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- LDS-DMA gather of one window: every tile = 64 rows x 512 B = 32 pieces of 1 KB (2 rows each); wave w moves
+    //      pieces 4w..4w+3 of each tile.  Position p of a row holds source chunk p ^ (row & 31). -----------------------------
+    auto gather = [&](int win) __attribute__((always_inline)) {
+        const int b = win / p.nW, w = win - b * p.nW;
+        const int32_t* src = srcs + w * 64;
+        const size_t tok0 = (size_t)b * p.T;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int I = wave * 4 + i;
+            const int row = 2 * I + (lane >> 5);
+            const int qc = (lane & 31) ^ (row & 31);                       // source chunk (8 channels) of this lane
+            const int idx = row < p.N ? src[row] : -1;
+            const size_t tk = tok0 + (idx < 0 ? 0 : idx);
+            const bf16_t* sq = p.q + tk * p.ldq + qc * 8;                  // padded query rows are never stored: any row will do
+            const bf16_t* sk = idx >= 0 ? p.k + tk * p.ldk + qc * 8 : p.k_pad + (size_t)b * p.k_pad_bs + qc * 8;
+            const bf16_t* s0 = idx >= 0 ? p.v0 + tk * p.ldv + qc * 8 : p.v0_pad + (size_t)b * p.v_pad_bs + qc * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sq, (__attribute__((address_space(3))) void*)(Qs + I * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sk, (__attribute__((address_space(3))) void*)(Ks + I * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s0, (__attribute__((address_space(3))) void*)(V0s + I * 1024), 16, 0, 0);
+            if (DUAL) {
+                const bf16_t* s1 = idx >= 0 ? p.v1 + tk * p.ldv + qc * 8 : p.v1_pad + (size_t)b * p.v_pad_bs + qc * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s1, (__attribute__((address_space(3))) void*)(V1s + I * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    int win = blockIdx.x;
+    if (win < nwin) gather(win);
+
+    const int g16 = (lane >> 4) & 1, i16 = lane & 15;
+    for (; win < nwin; win += gridDim.x) {
+        const int b = win / p.nW, w = win - b * p.nW;
+        const int32_t* src = srcs + w * 64;
+        const size_t tok0 = (size_t)b * p.T;
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                      // this window's tiles have landed (every wave waited for its own pieces)
+
+        // ---- 1. fragments of this head out of LDS ---------------------------------------------------------------------
+        Frag qf[2][2], kf[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int row = t * 32 + r;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int pos = ((wave * 4 + 2 * s + h) ^ (row & 31)) << 4;   // source chunk head*4 + 2s + h
+                qf[t][s].u = *(const u32x4*)(Qs + row * ROWB + pos);
+                kf[t][s].u = *(const u32x4*)(Ks + row * ROWB + pos);
+            }
+        }
+        // V^T fragments by transposed reads: k-step (k2, s) covers keys 32k2 + 16s + 8jj + 4h + (0..3); lane 4q+p of each
+        // 16-lane group addresses row key0+q, channels 16*g16 + 4p .. +3 of this head
+        union VF { s16x4 v[2]; bf16x8_t b; };
+        VF vf0[2][2], vf1[2][2];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int row = 32 * k2 + 16 * s + 8 * jj + 4 * h + (i16 >> 2);
+                    const int chunk = wave * 4 + 2 * g16 + ((i16 & 3) >> 1);
+                    const int off = row * ROWB + ((chunk ^ (row & 31)) << 4) + 8 * (i16 & 1);
+                    vf0[k2][s].v[jj] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(V0s + off));
+                    if (DUAL) vf1[k2][s].v[jj] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(V1s + off));
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                      // every head has its fragments: the tiles are free
+        if (win + gridDim.x < nwin) gather(win + gridDim.x);               // next window's rows fly under this window's math
+
+        // ---- 2. S^T[key][query] = K Q^T, scaled, + bias + shift mask -----------------------------------------------------
+        f32x16 st[2][2];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) st[k2][q2][e] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    st[k2][q2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[k2][s].b, qf[q2][s].b, st[k2][q2], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    st[k2][q2][2 * j] = st[k2][q2][2 * j] * p.scale_log2e + __uint_as_float(bpk[q2][k2][j] << 16);
+                    st[k2][q2][2 * j + 1] = st[k2][q2][2 * j + 1] * p.scale_log2e + __uint_as_float(bpk[q2][k2][j] & 0xffff0000u);
+                }
+            }
+        if (p.region) {
+            const uint8_t* reg = regs + w * 64;
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+                const unsigned rq = reg[q2 * 32 + r];
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const unsigned rk4 = *(const unsigned*)(reg + k2 * 32 + 8 * g + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (((rk4 >> (8 * e)) & 0xffu) != rq) st[k2][q2][4 * g + e] += -100.0f * LOG2E;
+                    }
+            }
+        }
+        // ---- 3. softmax over keys (query on the lane), probabilities packed as the B operand of P.V ------------------------------
+        float inv[2];
+        Frag pf[2][2][2];
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {
+            float mx = st[0][q2][0];
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[k2][q2][e]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned pk = pack_bf16x2(__builtin_amdgcn_exp2f(st[k2][q2][8 * s + 2 * j] - mx),
+                                                        __builtin_amdgcn_exp2f(st[k2][q2][8 * s + 2 * j + 1] - mx));
+                        pf[q2][k2][s].u[j] = pk;
+                        sum += __uint_as_float(pk << 16) + __uint_as_float(pk & 0xffff0000u);
+                    }
+            sum += __shfl_xor(sum, 32, 64);
+            inv[q2] = __builtin_amdgcn_rcpf(sum);
+        }
+        // ---- 4. O^T[d][query] = V^T P^T per value stream, stores for real query tokens -------------------------------------------
+        auto pv_store = [&](VF (&vf)[2][2], bf16_t* out) __attribute__((always_inline)) {
+            f32x16 ot[2];
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) ot[q2][e] = 0.f;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int q2 = 0; q2 < 2; ++q2)
+                        ot[q2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[k2][s].b, pf[q2][k2][s].b, ot[q2], 0, 0, 0);
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+                const int slot = q2 * 32 + r;
+                const int idx = slot < p.N ? src[slot] : -1;
+                if (idx < 0) continue;
+                bf16_t* op = out + (tok0 + idx) * p.ldo + wave * 32 + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 o;
+                    o[0] = pack_bf16x2(ot[q2][4 * g] * inv[q2], ot[q2][4 * g + 1] * inv[q2]);
+                    o[1] = pack_bf16x2(ot[q2][4 * g + 2] * inv[q2], ot[q2][4 * g + 3] * inv[q2]);
+                    *(u32x2*)(op + 8 * g) = o;
+                }
+            }
+        };
+        pv_store(vf0, p.out0);
+        if (DUAL) pv_store(vf1, p.out1);
+    }
+}
+
+}  // namespace
+
+// returns MASTER_ERR_UNSUPPORTED when the geometry is outside this kernel (caller falls back to window_attn_bf16)
+int window_attn_pw_bf16(const bf16_t* q, const bf16_t* k, const bf16_t* v0, const bf16_t* v1, int ldq, int ldk, int ldv,
+                        const bf16_t* k_pad, const bf16_t* v0_pad, const bf16_t* v1_pad, int k_pad_bs, int v_pad_bs,
+                        const float* bias, const int32_t* src, const uint8_t* region, bf16_t* out0, bf16_t* out1, int ldo,
+                        int B, int T, int heads, int nW, int N, float scale, hipStream_t s) {
+    if (heads != HEADS) return MASTER_ERR_UNSUPPORTED;
+    const int lds = (v1 ? 4 : 3) * TILE + nW * 64 * 5;
+    if (lds > 160 * 1024) return MASTER_ERR_UNSUPPORTED;
+    PwArgs p{q, k, v0, v1, ldq, ldk, ldv, k_pad, v0_pad, v1_pad, k_pad_bs, v_pad_bs, bias, src, region, out0, out1, ldo,
+             B, T, nW, N, scale * LOG2E};
+    int grid = B * nW;
+    if (grid > 256) grid = 256;
+    static int attr1 = 0, attr2 = 0;
+    if (v1) {
+        if (attr2 < lds) { (void)hipFuncSetAttribute((const void*)window_attn_pw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr2 = lds; }
+        hipLaunchKernelGGL(window_attn_pw_kernel<true>, dim3(grid), dim3(512), lds, s, p);
+    } else {
+        if (attr1 < lds) { (void)hipFuncSetAttribute((const void*)window_attn_pw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr1 = lds; }
+        hipLaunchKernelGGL(window_attn_pw_kernel<false>, dim3(grid), dim3(512), lds, s, p);
+    }
+    return master_check_launch("window_attn_pw_bf16");
+}

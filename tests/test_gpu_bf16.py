@@ -192,3 +192,27 @@ def test_fused_attention_block_c128_bf16(cuda, B, H, W, shift):
     assert got.data_ptr() != xd.data_ptr()
     mx, l2 = rel_err(got.view(B, H, W, C), ref)
     assert mx < 4e-2 and l2 < 1e-2, (mx, l2)
+
+
+@pytest.mark.parametrize("B,H,W,shift", [(2, 9, 9, 4), (1, 14, 14, 0), (3, 10, 17, 3), (1, 32, 32, 4), (40, 7, 7, 0)])
+def test_persistent_window_attention_8_heads_bf16(cuda, B, H, W, shift):
+    """the window-per-workgroup attention core (8 heads, LDS-DMA gathered tiles), single and dual value stream, against
+    the fp32 oracle; B=40 single-window images exercise several windows per persistent workgroup"""
+    from mastermetastyletransfer_amd import ShiftedWindowAttention, ShiftedWindowAttention_for_decoder_last_MHA
+    C, nh = 256, 8
+    m = ShiftedWindowAttention(C, nh, [7, 7], [shift, shift])
+    sd = seeded_state_dict(G.attn_shapes(C, nh), seed=91)
+    m.load_state_dict(sd); m = m.to(cuda).eval(); m.compute_dtype = BF
+    q, k, v = (seeded_input(f"pw{H}{W}{shift}{n}", (B, H, W, C), 6) for n in "qkv")
+    ref = O.shifted_window_attention(q, k, v, sd, "", (7, 7), (shift, shift), nh)
+    mx, l2 = rel_err(m(q.to(cuda), k.to(cuda), v.to(cuda)), ref)
+    assert mx < 5e-2 and l2 < 2e-2, ("single", mx, l2)
+    m2 = ShiftedWindowAttention_for_decoder_last_MHA(C, nh, [7, 7], [shift, shift])
+    sd2 = seeded_state_dict(G.attn_shapes(C, nh, ("Wk", "Wv_scale", "Wv_shift", "proj")), seed=92)
+    m2.load_state_dict(sd2); m2 = m2.to(cuda).eval(); m2.compute_dtype = BF
+    a, b_, c, d = (seeded_input(f"pw2{H}{W}{shift}{n}", (B, H, W, C), 7) for n in "abcd")
+    rs, rm = O.sigma_mu_attention(a, b_, c, d, sd2, "", (7, 7), (shift, shift), nh)
+    gs, gm = m2(a.to(cuda), b_.to(cuda), c.to(cuda), d.to(cuda))
+    for got, ref2, name in ((gs, rs, "sigma"), (gm, rm, "mu")):
+        mx, l2 = rel_err(got, ref2)
+        assert mx < 5e-2 and l2 < 2e-2, (name, mx, l2)
