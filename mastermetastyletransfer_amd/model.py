@@ -148,7 +148,7 @@ class MasterStyleTransferModel(nn.Module):
             raise ValueError("content and style batches must have the same shape")
         B = content_image.shape[0]
         # the two encoder passes of full_model.py:219-220 are independent -> one batch of 2B images
-        x, _, h, w = self.swin_encoder.run(torch.cat([content_image, style_image], dim=0))
+        x, _, h, w = self.swin_encoder.run(content_image, style_image)
         fc, fs = x[: B * h * w], x[B * h * w:]
         fcs = self.style_transformer.run(fc, fs, transformer_layer_count, B, h, w)
         # the reference permutes NHWC->NCHW here (:222); the decoder kernels read NHWC directly and the

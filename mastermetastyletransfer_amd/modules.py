@@ -636,15 +636,23 @@ class SwinEncoder(nn.Sequential):
                 if m.bias is not None:
                     nn.init.zeros_(m.bias)
 
-    def run(self, img: Tensor) -> Tuple[Tensor, int, int, int]:
-        """fp32 NCHW image -> (token matrix [B*H/8*W/8, 2E] in the compute dtype, B, H/8, W/8)"""
-        B, _, H, W = img.shape
+    def run(self, *imgs: Tensor) -> Tuple[Tensor, int, int, int]:
+        """fp32 NCHW image batch(es) -> (token matrix [B*H/8*W/8, 2E] in the compute dtype, B, H/8, W/8).  Several
+        batches (content, style) are embedded into consecutive slices of one buffer and encoded as one batch."""
+        _, _, H, W = imgs[0].shape
         if H % 8 or W % 8:
             raise ValueError("image sides must be multiples of 8 (patch 4 + one 2x2 merge)")
         conv, ln = self[0][0], self[0][2]
-        x = ops.patch_embed(img.contiguous().float(), conv.weight.detach().reshape(conv.weight.shape[0], -1).float().contiguous(),
+        B = sum(int(i.shape[0]) for i in imgs)
+        x = torch.empty((B, H // 4, W // 4, conv.weight.shape[0]), dtype=self.compute_dtype, device=imgs[0].device)
+        b0 = 0
+        for img in imgs:
+            if img.shape[1:] != imgs[0].shape[1:]:
+                raise ValueError("all image batches must have the same size")
+            ops.patch_embed(img.contiguous().float(), conv.weight.detach().reshape(conv.weight.shape[0], -1).float().contiguous(),
                             conv.bias.detach().float(), ln.weight.detach().float(), ln.bias.detach().float(),
-                            self.compute_dtype, ln.eps)
+                            self.compute_dtype, ln.eps, out=x[b0:b0 + img.shape[0]])
+            b0 += img.shape[0]
         h, w = H // 4, W // 4
         x = x.view(B * h * w, -1)
         for blk in self[1]:

@@ -288,13 +288,16 @@ def instnorm(x: torch.Tensor, B: int, T: int, pad_row: Optional[torch.Tensor] = 
     return out, pad_out
 
 
-def patch_embed(img: torch.Tensor, w: torch.Tensor, bias, gamma, beta, dtype: torch.dtype, eps: float = 1e-5):
-    """img fp32 NCHW [B,3,H,W] -> NHWC [B,H/4,W/4,E] with LayerNorm(E) applied."""
+def patch_embed(img: torch.Tensor, w: torch.Tensor, bias, gamma, beta, dtype: torch.dtype, eps: float = 1e-5,
+                out: Optional[torch.Tensor] = None):
+    """img fp32 NCHW [B,3,H,W] -> NHWC [B,H/4,W/4,E] with LayerNorm(E) applied (into `out` when given)."""
     _dev(img, w)
     B, _, H, W = img.shape
     E = w.shape[0]
     assert img.dtype == torch.float32 and img.is_contiguous()
-    out = torch.empty((B, H // 4, W // 4, E), dtype=dtype, device=img.device)
+    if out is None:
+        out = torch.empty((B, H // 4, W // 4, E), dtype=dtype, device=img.device)
+    assert out.shape == (B, H // 4, W // 4, E) and out.dtype == dtype and out.is_contiguous()
     _check(load_library().master_patch_embed_fwd(_p(img), _p(w), _p(bias), _p(gamma), _p(beta), _p(out), B, H, W, E, eps,
                                                   F32 if dtype == torch.float32 else BF16, _stream()),
            "master_patch_embed_fwd")

@@ -40,7 +40,11 @@ def test_linear_bf16(cuda, M, N, K):
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,up,relu,nchw", [(2, 8, 8, 256, 128, False, True, False), (1, 8, 8, 128, 128, True, True, False),
                                                           (2, 5, 7, 64, 64, True, True, False), (1, 16, 16, 64, 32, False, True, False),
-                                                          (2, 12, 10, 32, 32, True, True, False), (2, 12, 10, 32, 3, False, False, True)])
+                                                          (2, 12, 10, 32, 32, True, True, False), (2, 12, 10, 32, 3, False, False, True),
+                                                          # halo-tile kernel (Cin = 64, output multiple of 16 x 32): border and interior tiles
+                                                          (2, 8, 16, 64, 64, True, True, False), (1, 16, 32, 64, 32, False, True, False),
+                                                          (1, 32, 64, 64, 64, False, False, False), (3, 16, 16, 64, 32, True, True, False),
+                                                          (1, 48, 64, 64, 32, False, True, False)])
 def test_conv3x3_bf16(cuda, B, H, W, Cin, Cout, up, relu, nchw):
     from mastermetastyletransfer_amd import ops
     g = torch.Generator().manual_seed(H + Cout)
