@@ -32,6 +32,7 @@ int linear_ts_bf16(const bf16_t*, const float*, const float*, const bf16_t*, con
                    int, int, int, int, int, int, float, hipStream_t);
 int attn_block_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const float*, const float*,
                     const int32_t*, const uint8_t*, bf16_t*, int, int, int, int, int, int, float, float, hipStream_t);
+int patch_embed_bf16(const float*, const float*, const float*, const float*, const float*, bf16_t*, int, int, int, float, hipStream_t);
 int conv_halo_bf16(const bf16_t*, const bf16_t*, const float*, bf16_t*, int, int, int, int, int, int, int, hipStream_t);
 int conv_tail_bf16(const bf16_t*, const bf16_t*, const float*, const bf16_t*, const float*, float*, int, int, int, hipStream_t);
 int mlp_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const float*,
@@ -280,7 +281,8 @@ int master_patch_embed_fwd(const float* img, const void* w, const void* bias, co
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_PATCH_EMBED, s);
     if (dtype == MASTER_F32) return patch_embed_launch<float>(img, w, bias, gamma, beta, out, B, H, W, eps, s);
-    if (dtype == MASTER_BF16) return patch_embed_launch<bf16_t>(img, w, bias, gamma, beta, out, B, H, W, eps, s);
+    if (dtype == MASTER_BF16)      // matrix-core version (bf16 operands, fp32 accumulate and LayerNorm)
+        return patch_embed_bf16(img, (const float*)w, (const float*)bias, (const float*)gamma, (const float*)beta, (bf16_t*)out, B, H, W, eps, s);
     master_set_error("patch_embed: bad dtype %d", dtype);
     return MASTER_ERR_INVALID;
 }

@@ -220,3 +220,18 @@ def test_persistent_window_attention_8_heads_bf16(cuda, B, H, W, shift):
     for got, ref2, name in ((gs, rs, "sigma"), (gm, rm, "mu")):
         mx, l2 = rel_err(got, ref2)
         assert mx < 5e-2 and l2 < 2e-2, (name, mx, l2)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 256, 256), (3, 8, 8), (1, 40, 12)])
+def test_patch_embed_mfma_bf16(cuda, B, H, W):
+    """Conv2d(3,128,4,4) + LayerNorm(128) on the matrix cores (bf16 operands) vs fp32 torch; odd patch counts exercise the tail"""
+    from mastermetastyletransfer_amd import ops
+    g = torch.Generator().manual_seed(H + W)
+    img = torch.randn(B, 3, H, W, generator=g)
+    w, b = torch.randn(128, 3, 4, 4, generator=g) / 7, torch.randn(128, generator=g)
+    gw, gb = 1 + 0.2 * torch.randn(128, generator=g), 0.2 * torch.randn(128, generator=g)
+    ref = F.layer_norm(F.conv2d(img.to(BF).float(), w.to(BF).float(), b, stride=4).permute(0, 2, 3, 1), (128,), gw, gb, 1e-5)
+    out = ops.patch_embed(img.to(cuda), w.reshape(128, 48).to(cuda), b.to(cuda), gw.to(cuda), gb.to(cuda), BF)
+    assert out.dtype == BF and out.shape == ref.shape
+    mx, l2 = rel_err(out, ref)
+    assert mx < 1.5e-2 and l2 < 5e-3, (mx, l2)
