@@ -78,7 +78,20 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
     // q = (lane&7) ^ ((row>>1)&7).
     const int row0 = wave * (DMA_PER_STEP * 4) + (lane >> 4), l15 = lane & 15;        // 256-B-row layout
     const int row0b = wave * (DMA_PER_STEP * 8) + (lane >> 3), l7 = lane & 7;         // 128-B-row layout
-    auto issue = [&](int t) __attribute__((always_inline)) {
+    // One stream step = DMA_PER_STEP one-KB pieces per wave.  set_dma_step() works out the wave-uniform source of step t;
+    // dma_piece(i) issues piece i as  scalar base (+ piece rows, scalar)  +  32-bit per-lane byte offset: two VALU
+    // instructions per piece.  In the steady state the pieces go out one at a time between the MFMAs of the step being
+    // computed: the L2 -> LDS path moves 64 B/clk per CU, so a burst of 4 x 8 KB at the top of a step kept all four waves
+    // (and with them the matrix cores) waiting in the issue queue for ~580 cycles per step.
+    // Swizzle terms: (row & 15) of piece i depends on i & 3 only, ((row >> 1) & 7) on i & 1 only (waves own 32-/64-row bands).
+    // (named scalars, not arrays: a select between two array elements becomes a dynamically indexed private array = scratch)
+#define SW256(i) ((l15 ^ ((row0 + 4 * (i)) & 15)) << 4)      /* bytes */
+#define SW128(i) ((l7 ^ (((row0b + 8 * (i)) >> 1) & 7)) << 4)
+    const int sw256_0 = SW256(0), sw256_1 = SW256(1), sw256_2 = SW256(2), sw256_3 = SW256(3);
+    const int sw128_0 = SW128(0), sw128_1 = SW128(1);
+    const char* d_base = nullptr; int d_pstride = 0, d_vrow = 0; bool d_128 = false, d_valid = false; unsigned char* d_slot = nullptr;
+    auto set_dma_step = [&](int t) __attribute__((always_inline)) {
+        d_valid = t < T;
         bool is_w1; int hc, idx;
         if (t < KB) { is_w1 = true; hc = 0; idx = t; }
         else {
@@ -86,37 +99,27 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
             if (b < nhc - 1 && o < KB) { is_w1 = true; hc = b + 1; idx = o; }
             else { is_w1 = false; hc = b; idx = b < nhc - 1 ? o - KB : o; }
         }
-        unsigned char* slot = lds + (t % RING) * SLOT + wave * DMA_PER_STEP * 1024;
-        if (is_w1) {
-            const bf16_t* base = p.w1 + (size_t)hc * 128 * C + idx * 128;                 // wave-uniform
-#pragma unroll
-            for (int i = 0; i < DMA_PER_STEP; ++i) {
-                const int row = row0 + 4 * i;
-                const int off = row * C + ((l15 ^ (row & 15)) << 3);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
-                                                 (__attribute__((address_space(3))) void*)(slot + i * 1024), 16, 0, 0);
-            }
-        } else if (ROW2 == 256) {
-            const bf16_t* base = p.w2 + hc * 128;
-            const int hid = p.HID;
-#pragma unroll
-            for (int i = 0; i < DMA_PER_STEP; ++i) {
-                const int row = row0 + 4 * i;
-                const int off = row0 * hid + (4 * i) * hid + ((l15 ^ (row & 15)) << 3);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
-                                                 (__attribute__((address_space(3))) void*)(slot + i * 1024), 16, 0, 0);
-            }
-        } else {
-            const bf16_t* base = p.w2 + hc * 128 + idx * JB2;
-            const int hid = p.HID;
-#pragma unroll
-            for (int i = 0; i < DMA_PER_STEP; ++i) {
-                const int row = row0b + 8 * i;
-                const int off = row0b * hid + (8 * i) * hid + ((l7 ^ ((row >> 1) & 7)) << 3);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
-                                                 (__attribute__((address_space(3))) void*)(slot + i * 1024), 16, 0, 0);
-            }
+        d_slot = lds + (t % RING) * SLOT + wave * DMA_PER_STEP * 1024;
+        if (is_w1) { d_base = (const char*)(p.w1 + (size_t)hc * 128 * C + idx * 128); d_pstride = 4 * C * 2; d_vrow = row0 * (C * 2); d_128 = false; }
+        else {
+            d_base = (const char*)(p.w2 + hc * 128 + (ROW2 == 128 ? idx * JB2 : 0));
+            d_pstride = (ROW2 == 128 ? 8 : 4) * p.HID * 2; d_vrow = (ROW2 == 128 ? row0b : row0) * (p.HID * 2); d_128 = ROW2 == 128;   // byte offset of this lane's first row
         }
+    };
+    auto dma_piece = [&](int i) __attribute__((always_inline)) {
+        if (!d_valid) return;
+        const int a256 = (i & 3) == 0 ? sw256_0 : (i & 3) == 1 ? sw256_1 : (i & 3) == 2 ? sw256_2 : sw256_3;      // i is a constant here
+        const int a128 = (i & 1) == 0 ? sw128_0 : sw128_1;
+        const int sw = ROW2 == 128 ? (d_128 ? a128 : a256) : a256;
+        const unsigned voff = (unsigned)(d_vrow + sw);
+        const char* sb = d_base + (size_t)(unsigned)(i * d_pstride);                     // wave-uniform
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + voff),
+                                         (__attribute__((address_space(3))) void*)(d_slot + i * 1024), 16, 0, 0);
+    };
+    auto issue = [&](int t) __attribute__((always_inline)) {
+        set_dma_step(t);
+#pragma unroll
+        for (int i = 0; i < DMA_PER_STEP; ++i) dma_piece(i);
     };
 
     int t_issue = 0;
@@ -194,19 +197,12 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         PROBE_ADD(0);
-        if (t_issue < T) { issue(t_issue); ++t_issue; }
+        set_dma_step(t_issue);                              // its pieces go out between this step's MFMA groups
+        if (t_issue < T) ++t_issue;
         PROBE_ADD(1);
         const unsigned char* slot = lds + (t_cons % RING) * SLOT;
         ++t_cons;
         return slot;
-    };
-
-    // GELU in the sigmoid form of the tanh approximation, x / (1 + exp(-2*sqrt(2/pi)*(x + 0.044715 x^3))):
-    // 7 VALU ops (one v_exp, one v_rcp).  |error| vs the exact erf form <= 5e-4, below bf16 resolution; the fp32
-    // parity mode keeps the erf form (common.h).
-    auto gelu_bf16 = [](float x) {
-        const float a = fmaf(x * x, -0.0713548163f * 1.4426950408889634f, -1.5957691216f * 1.4426950408889634f);
-        return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * a));
     };
 
     f32x16 hacc[4], hprev[4], oacc[NT2];
@@ -216,25 +212,26 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[t][e] = 0.f;
 
-    // bias + GELU + pack of registers 8s..8s+7 of tile jt (one k-step of phase 2), then the half-wave exchange
-    // that turns the accumulator k order into the natural one
-    auto gelu_kstep = [&](int hc_prev, int jt, int s) __attribute__((always_inline)) {
-        unsigned u[4];
-#pragma unroll
-        for (int g2 = 0; g2 < 2; ++g2) {
-            const int g = 2 * s + g2;
-            const f32x4 bv = *(const f32x4*)(b1s + hc_prev * 128 + jt * 32 + 8 * g + 4 * h);
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_bf16(hprev[jt][4 * g + e] + bv[e]);
-            u[2 * g2] = pack_bf16x2(v[0], v[1]);
-            u[2 * g2 + 1] = pack_bf16x2(v[2], v[3]);
-        }
+    // GELU + pack of hidden chunk hc, sliced: a k-step of phase 2 (tile jt, half s) is registers 8s..8s+7 of hprev[jt] = four
+    // pairs (gelu_pair, 10 VALU instructions each), then the half-wave exchange that turns the accumulator k order into the
+    // natural one (gelu_swap).
+    unsigned gu[4];
+    auto gelu_pair = [&](int jt, int s, int q) __attribute__((always_inline)) {
+        const int e0 = 4 * (2 * s + (q >> 1)) + 2 * (q & 1);
+        const f32x2 v = gelu_poly2(f32x2{hprev[jt][e0], hprev[jt][e0 + 1]});          // common.h; b1 is already in the accumulator
+        gu[q] = pack_bf16x2(v[0], v[1]);
+    };
+    auto gelu_swap = [&](int jt, int s) __attribute__((always_inline)) {
         // half 0 keeps u0,u1 and takes the partner's u0,u1 as words 2,3; half 1 takes the partner's u2,u3 as words 0,1
-        auto sw0 = __builtin_amdgcn_permlane32_swap(u[0], u[2], false, false);
-        auto sw1 = __builtin_amdgcn_permlane32_swap(u[1], u[3], false, false);
+        auto sw0 = __builtin_amdgcn_permlane32_swap(gu[0], gu[2], false, false);
+        auto sw1 = __builtin_amdgcn_permlane32_swap(gu[1], gu[3], false, false);
         hf[jt][s].u[0] = sw0[0]; hf[jt][s].u[2] = sw0[1];
         hf[jt][s].u[1] = sw1[0]; hf[jt][s].u[3] = sw1[1];
+    };
+    auto gelu_kstep = [&](int jt, int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gelu_pair(jt, s, q);
+        gelu_swap(jt, s);
     };
 
     const int x256 = (h ^ (r & 15)) << 4;            // swizzle term for 256-B rows: chunk (2s+h) ^ (row&15)
@@ -248,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
 #define LGKM_WAIT(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
     auto lds_off = [&](const unsigned char* ptr) { return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)ptr; };
 
-    auto phase1_step = [&](const unsigned char* slot, int kb, bool pipe, int hc_prev) __attribute__((always_inline)) {
+    auto phase1_step = [&](const unsigned char* slot, int kb, bool pipe) __attribute__((always_inline)) {
         const unsigned base = lds_off(slot) + r * 256;
         u32x4 a[2][4];
         auto rd = [&](int buf, int s) {
@@ -259,18 +256,31 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
         rd(0, 0);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
+#ifdef MLP_X_NORD1
+            if (s == 0) { rd(1, 1); LGKM_WAIT(0); }
+#else
             if (s + 1 < 8) { rd((s + 1) & 1, s + 1); LGKM_WAIT(4); } else { LGKM_WAIT(0); }
+#endif
+#define SB() __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) {
                 Frag f; f.u = a[s & 1][jt];
                 hacc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, xf[kb * 8 + s].b, hacc[jt], 0, 0, 0);
+#ifndef MLP_X_NODMA1
+                if (jt == 1) { SB(); dma_piece(s); SB(); }      // two VALU instructions: hides behind the MFMA
+#endif
             }
+#ifndef MLP_X_NOGELU
             if (pipe) {
-                // 8 (tile, k-step) GELU slices per hidden chunk spread over the KB*8 MFMA groups of phase 1
+                // 8 k-step slices of GELU(previous chunk) between the KB*8 MFMA groups of this chunk.  Each slice is one burst of
+                // four independent packed-fp32 chains: v_pk_* does not overlap this wave's MFMAs (measured, issue_probe.hip:
+                // 4 x (MFMA ; 4 pk_fma) = 260 clocks against 128 + 75), and a dependent chain issues only every 8 clocks, so
+                // slicing finer than this costs more than it hides.
                 const int i = kb * 8 + s;
-                if (KB == 2) { if ((i & 1) == 0) gelu_kstep(hc_prev, i >> 2, (i >> 1) & 1); }
-                else gelu_kstep(hc_prev, i >> 1, i & 1);
+                if (KB == 2) { if ((i & 1) == 0) gelu_kstep(i >> 2, (i >> 1) & 1); }
+                else gelu_kstep(i >> 1, i & 1);
             }
+#endif
         }
     };
     auto phase2_step = [&](const unsigned char* slot, int sb) __attribute__((always_inline)) {
@@ -304,36 +314,43 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
             for (int nt = 0; nt < NT2; ++nt) {
                 Frag f; f.u = a[g & 1][nt];
                 oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, hf[jt][g & 1].b, oacc[nt], 0, 0, 0);
+                if (NG == 4) { if (nt == 1 || nt == 5) { SB(); dma_piece(2 * g + (nt > 1)); SB(); } }
+                else if (nt == 1) { SB(); dma_piece(g); SB(); }
             }
         }
     };
-    auto zero_hacc = [&]() {
+    // accumulators of hidden chunk hc start from its bias b1 (rows = hidden units: 16 per tile per lane, one batch of LDS reads)
+    auto init_hacc = [&](int hc) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) hacc[t][e] = 0.f;
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *(const f32x4*)(b1s + hc * 128 + t * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hacc[t][4 * g + e] = bv[e];
+            }
     };
 
 #ifdef MLP_CLOCK_PROBE
     probe_sec[4] = __builtin_amdgcn_s_memtime() - probe_t0;
 #endif
     // prologue: phase 1 of chunk 0
-    zero_hacc();
+    init_hacc(0);
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) { phase1_step(begin_step(), kb, false, 0); PROBE_ADD(2); }
+    for (int kb = 0; kb < KB; ++kb) { phase1_step(begin_step(), kb, false); PROBE_ADD(2); }
 
     for (int hc = 0; hc < nhc; ++hc) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) hprev[t] = hacc[t];
         if (hc + 1 < nhc) {
-            zero_hacc();
+            init_hacc(hc + 1);
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) { phase1_step(begin_step(), kb, true, hc); PROBE_ADD(2); }    // + GELU(hc) in the gaps
+            for (int kb = 0; kb < KB; ++kb) { phase1_step(begin_step(), kb, true); PROBE_ADD(2); }    // + GELU(hc) in the gaps
         } else {
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) gelu_kstep(hc, jt, s);
+                for (int s = 0; s < 2; ++s) gelu_kstep(jt, s);
         }
 #pragma unroll
         for (int sb = 0; sb < S2; ++sb) { phase2_step(begin_step(), sb); PROBE_ADD(3); }
