@@ -2,14 +2,17 @@
 // (the q/k/v/proj projections and PatchMerging's reduction: reference style_transformer.py:114-116,156,
 //  515-517,576,595 and the fused qkv of the Swin blocks; LayerNorm = norm1 of the block, folded in).
 //
-// Same machinery as the fused MLP (mlp_bf16.hip), minus its second phase.  One workgroup = 128 tokens, 4 waves,
-// wave w owns tokens [32w, 32w+32).  The product is computed transposed, O^T[n][m] = sum_k W[n][k] X[m][k]:
+// Same machinery as the fused MLP (mlp_bf16.hip), minus its second phase.  One workgroup = 128 tokens, 8 waves = two per
+// SIMD: waves w and w+4 both own tokens [32(w&3), +32) and split every 128-column chunk between them (tiles 0,1 / 2,3).
+// A wave issues in order, so with one wave per SIMD every stall (LDS-DMA issue on the 64 B/clk path, barrier, fragment
+// wait, epilogue) idled that SIMD's matrix core; with two, one wave's MFMAs run under the other's stalls, at the same LDS
+// and L2 traffic.  The product is computed transposed, O^T[n][m] = sum_k W[n][k] X[m][k]:
 // the token sits on the MFMA lane, the X fragments of the whole row (K <= 512) stay in registers for the entire
 // kernel (LayerNorm applied there), and the weight matrix is the only thing that streams - 32-KB steps
 // ([128 n][128 k]) through a 3-slot LDS ring by LDS-DMA, two steps ahead, counted vmcnt + one raw barrier per
 // step, source-swizzled so the fragment ds_read_b128 are conflict-free.  Output columns are produced in chunks of
 // 128; a chunk's epilogue runs while the next chunks' weights are already in flight: each wave transposes its
-// O^T accumulators through a private fp32 LDS tile and emits contiguous row segments (bias, r1, r2, bf16 stores).
+// O^T accumulators tile by tile through a private fp32 LDS tile and emits contiguous row segments (bias, r1, r2, bf16 stores).
 // Residual operands (N <= 256) are fetched once up front in that row layout, so the loop has no ordinary global load.
 #include "common.h"
 
@@ -27,15 +30,19 @@ struct LinArgs {
 
 union Frag { u32x4 u; bf16x8_t b; };
 
-constexpr int SLOT = 32768, RING = 3, AHEAD = 2, DMA_PER_STEP = 8;
-constexpr int STAGE = 32768;     // epilogue staging: 4 waves x [32 tokens][64 channels] fp32
+constexpr int SLOT = 32768, RING = 3, AHEAD = 2;
+constexpr int STAGE = 32768;     // epilogue staging: 8 waves x [32 tokens][32 channels] fp32
 
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define LDS_READ128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:" #imm : "=v"(dst) : "v"(addr))
 #define LGKM_WAIT(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
-template <int K, bool RES>
-__global__ __launch_bounds__(256, 1) void linear_ts_bf16_kernel(LinArgs p) {
+// NW = 8 waves (K <= 256), or 4 (K = 512: the X row alone is 128 registers, which leaves no room for two waves per SIMD)
+template <int K, bool RES, int NW>
+__global__ __launch_bounds__(NW * 64) void linear_ts_bf16_kernel(LinArgs p) {
+    constexpr int NTHREADS = NW * 64;
+    constexpr int DMA_PER_STEP = 32 / NW;       // one-KB LDS-DMA pieces per wave per 32-KB step
+    constexpr int TPW = 16 / NW;                // 32-column tiles per wave per 128-column chunk (4 or 2)
     constexpr int KS = K / 16;                  // k-steps over the whole row
     constexpr int KB = K / 128;                 // 32-KB weight steps per 128-column chunk
 
@@ -46,8 +53,9 @@ __global__ __launch_bounds__(256, 1) void linear_ts_bf16_kernel(LinArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int band = wave & 3, nh = wave >> 2;      // token band, and which half of every 128-column chunk this wave computes
     const int r = lane & 31, h = lane >> 5;
-    const int m = blockIdx.x * 128 + wave * 32 + r;
+    const int m = blockIdx.x * 128 + band * 32 + r;
     const int mc = m < p.M ? m : p.M - 1;
     const int nch = p.N / 128;
     const int T = nch * KB;
@@ -68,19 +76,20 @@ __global__ __launch_bounds__(256, 1) void linear_ts_bf16_kernel(LinArgs p) {
     int t_issue = 0;
     for (; t_issue < AHEAD && t_issue < T; ++t_issue) issue(t_issue);
 
-    for (int i = tid; i < p.N; i += 256) bs[i] = p.bias ? p.bias[i] : 0.f;
-    if (p.ln_g) for (int i = tid; i < K; i += 256) { lng[i] = p.ln_g[i]; lnb[i] = p.ln_b[i]; }
+    for (int i = tid; i < p.N; i += NTHREADS) bs[i] = p.bias ? p.bias[i] : 0.f;
+    if (p.ln_g) for (int i = tid; i < K; i += NTHREADS) { lng[i] = p.ln_g[i]; lnb[i] = p.ln_b[i]; }
 
-    // residual operands, fetched once in the layout of the epilogue's row pass: iteration (nc, half, it) handles rows
-    // it*4 + (lane>>4) of this wave's 32 tokens, channels nc*128 + half*64 + (lane&15)*4 .. +3  (128-B row segments)
-    const int m0w = blockIdx.x * 128 + wave * 32;
-    u32x2 rq1[RES ? 32 : 1], rq2[RES ? 32 : 1];
+    // residual operands, fetched once in the layout of the epilogue's row pass: iteration (nc, jt, it) handles rows
+    // it*8 + (lane>>3) of this wave's 32 tokens, channels nc*128 + nh*64 + jt*32 + (lane&7)*4 .. +3  (64-B row segments)
+    const int m0w = blockIdx.x * 128 + band * 32;
+    constexpr int NRQ = RES ? 8 * TPW : 1;
+    u32x2 rq1[NRQ], rq2[NRQ];
     if (RES) {
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const int nc = j >> 4, half = (j >> 3) & 1, it = j & 7;
-            const int mm = m0w + it * 4 + (lane >> 4);
-            const int n = nc * 128 + half * 64 + (lane & 15) * 4;
+        for (int j = 0; j < 8 * TPW; ++j) {
+            const int nc = j / (4 * TPW), jt = (j >> 2) % TPW, it = j & 3;
+            const int mm = m0w + it * 8 + (lane >> 3);
+            const int n = nc * 128 + nh * (TPW * 32) + jt * 32 + (lane & 7) * 4;
             rq1[j] = u32x2{0u, 0u}; rq2[j] = u32x2{0u, 0u};
             if (n < p.N && mm < p.M) {
                 if (p.r1) rq1[j] = *(const u32x2*)(p.r1 + (size_t)mm * p.ldr + n);
@@ -135,10 +144,10 @@ __global__ __launch_bounds__(256, 1) void linear_ts_bf16_kernel(LinArgs p) {
 
     int t_cons = 0;
     auto begin_step = [&]() __attribute__((always_inline)) {
-        // conservative count: stores of the previous chunk's epilogue are younger than every DMA, so "at most 16 (8)
+        // conservative count: stores of the previous chunk's epilogue are younger than every DMA, so "at most 4
         // outstanding" still implies the DMAs of step t_cons have landed
         const int ahead = t_issue - 1 - t_cons;
-        if (ahead >= 1) WAIT_VMCNT(8); else WAIT_VMCNT(0);
+        if (ahead >= 1) { if (DMA_PER_STEP == 8) WAIT_VMCNT(8); else WAIT_VMCNT(4); } else WAIT_VMCNT(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (t_issue < T) { issue(t_issue); ++t_issue; }
@@ -149,61 +158,59 @@ __global__ __launch_bounds__(256, 1) void linear_ts_bf16_kernel(LinArgs p) {
     auto lds_off = [&](const unsigned char* ptr) { return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)ptr; };
     const int x256 = (h ^ (r & 15)) << 4;
 
-    f32x16 acc[4];
+    f32x16 acc[TPW];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < TPW; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
     };
     auto step = [&](const unsigned char* slot, int kb) __attribute__((always_inline)) {
-        const unsigned base = lds_off(slot) + r * 256;
-        u32x4 a[2][4];
+        const unsigned base = lds_off(slot) + nh * 16384 + r * 256;             // this wave's 32-row tiles of the 128-row step
+        u32x4 a[2][TPW];
         auto rd = [&](int buf, int s) {
             const unsigned ad = base + ((32 * s) ^ x256);
             LDS_READ128(a[buf][0], ad, 0); LDS_READ128(a[buf][1], ad, 8192);
-            LDS_READ128(a[buf][2], ad, 16384); LDS_READ128(a[buf][3], ad, 24576);
+            if (TPW == 4) { LDS_READ128(a[buf][TPW - 2], ad, 16384); LDS_READ128(a[buf][TPW - 1], ad, 24576); }
         };
         rd(0, 0);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            if (s + 1 < 8) { rd((s + 1) & 1, s + 1); LGKM_WAIT(4); } else { LGKM_WAIT(0); }
+            if (s + 1 < 8) { rd((s + 1) & 1, s + 1); if (TPW == 4) LGKM_WAIT(4); else LGKM_WAIT(2); } else { LGKM_WAIT(0); }
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
+            for (int jt = 0; jt < TPW; ++jt) {
                 Frag f; f.u = a[s & 1][jt];
                 acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, xf[kb * 8 + s].b, acc[jt], 0, 0, 0);
             }
         }
     };
-    // epilogue of output columns [nc*128, nc*128+128).  The accumulators hold O^T (lane = token, registers = channels);
-    // storing that directly means 8-byte stores strided by the row pitch.  Each wave instead transposes half a chunk
-    // (2 tiles = 64 channels) at a time through its private fp32 staging tile and emits 128-B row segments.
+    // epilogue of this wave's output columns [nc*128 + nh*32*TPW, +32*TPW).  The accumulators hold O^T (lane = token, registers =
+    // channels); storing that directly means 8-byte stores strided by the row pitch.  Each wave instead transposes one tile
+    // (32 channels) at a time through its private fp32 staging tile and emits 64-B row segments.
     auto epilogue = [&](int nc) __attribute__((always_inline)) {
-        float* stage = (float*)(lds + RING * SLOT + wave * 8192);              // [32 tokens][64 ch] fp32, 16-B chunks swizzled by token&15
+        float* stage = (float*)(lds + RING * SLOT + wave * 4096);              // [32 tokens][32 ch] fp32, 16-B chunks swizzled by token&7
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int jt = 0; jt < TPW; ++jt) {
 #pragma unroll
-            for (int j2 = 0; j2 < 2; ++j2)
+            for (int g = 0; g < 4; ++g) {
+                const int c = 2 * g + h;                                        // 16-B chunk of channels 8g + 4h .. +3 within the tile
+                f32x4 v;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int jt = half * 2 + j2;
-                    const int c = j2 * 8 + 2 * g + h;                           // 16-B chunk of channels j2*32 + 8g + 4h .. +3 within the half
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[jt][4 * g + e];
-                    *(f32x4*)(stage + r * 64 + ((c ^ (r & 15)) << 2)) = v;
-                }
+                for (int e = 0; e < 4; ++e) v[e] = acc[jt][4 * g + e];
+                *(f32x4*)(stage + r * 32 + ((c ^ (r & 7)) << 2)) = v;
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const f32x4 bv = *(const f32x4*)(bs + nc * 128 + half * 64 + (lane & 15) * 4);
+            const int n0 = nc * 128 + nh * (TPW * 32) + jt * 32 + (lane & 7) * 4;
+            const f32x4 bv = *(const f32x4*)(bs + n0);
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int row = it * 4 + (lane >> 4), mm = m0w + row;
-                f32x4 v = *(const f32x4*)(stage + row * 64 + (((lane & 15) ^ (row & 15)) << 2));
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + (lane >> 3), mm = m0w + row;
+                f32x4 v = *(const f32x4*)(stage + row * 32 + (((lane & 7) ^ (row & 7)) << 2));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += bv[e];
                 if (RES) {
-                    const u32x2 a1 = nc == 0 ? rq1[half * 8 + it] : rq1[(16 + half * 8 + it) % (RES ? 32 : 1)];
-                    const u32x2 a2 = nc == 0 ? rq2[half * 8 + it] : rq2[(16 + half * 8 + it) % (RES ? 32 : 1)];
+                    const u32x2 a1 = nc == 0 ? rq1[(jt * 4 + it) % NRQ] : rq1[(4 * TPW + jt * 4 + it) % NRQ];
+                    const u32x2 a2 = nc == 0 ? rq2[(jt * 4 + it) % NRQ] : rq2[(4 * TPW + jt * 4 + it) % NRQ];
                     if (p.r1) {
                         v[0] *= __uint_as_float(a1[0] << 16); v[1] *= __uint_as_float(a1[0] & 0xffff0000u);
                         v[2] *= __uint_as_float(a1[1] << 16); v[3] *= __uint_as_float(a1[1] & 0xffff0000u);
@@ -214,9 +221,9 @@ __global__ __launch_bounds__(256, 1) void linear_ts_bf16_kernel(LinArgs p) {
                     }
                 }
                 u32x2 o; o[0] = pack_bf16x2(v[0], v[1]); o[1] = pack_bf16x2(v[2], v[3]);
-                if (mm < p.M) *(u32x2*)(p.out + (size_t)mm * p.ldo + nc * 128 + half * 64 + (lane & 15) * 4) = o;
+                if (mm < p.M) *(u32x2*)(p.out + (size_t)mm * p.ldo + n0) = o;
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // tile reads done before the next half overwrites it
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // tile reads done before the next tile overwrites it
         }
     };
 
@@ -230,13 +237,14 @@ __global__ __launch_bounds__(256, 1) void linear_ts_bf16_kernel(LinArgs p) {
 
 template <int K, bool RES>
 int launch(const LinArgs& p, hipStream_t s) {
+    constexpr int NW = K <= 256 ? 8 : 4;
     const size_t lds = (size_t)RING * SLOT + STAGE + (size_t)(p.N + 2 * K) * sizeof(float);
     static size_t attr_set = 0;
     if (attr_set < lds) {
-        (void)hipFuncSetAttribute((const void*)linear_ts_bf16_kernel<K, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)linear_ts_bf16_kernel<K, RES, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = lds;
     }
-    hipLaunchKernelGGL((linear_ts_bf16_kernel<K, RES>), dim3((p.M + 127) / 128), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((linear_ts_bf16_kernel<K, RES, NW>), dim3((p.M + 127) / 128), dim3(NW * 64), lds, s, p);
     return master_check_launch("linear_ts_bf16");
 }
 

@@ -13,7 +13,7 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmaster_hip.so")
+LIB_PATH = os.environ.get("MASTER_HIP_LIB") or os.path.join(_HERE, "csrc", "libmaster_hip.so")   # override: A/B runs of two builds
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
