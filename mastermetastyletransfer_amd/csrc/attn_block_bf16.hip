@@ -39,6 +39,7 @@ struct BlockArgs {
     const float* bias64; const int32_t* src; const uint8_t* region;
     bf16_t* out;
     int B, T, nW, N; float eps, scale;
+    int wchunk, R;               // windows-per-image slices: workgroup g serves slice g % R = windows [slice*wchunk, +wchunk) of every image
 };
 
 union Frag { u32x4 u; bf16x8_t b; };
@@ -61,7 +62,12 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // = head
     const int r = lane & 31, h = lane >> 5;
-    const int nwin = p.B * p.nW;
+    // Geometries with many windows (512x512: 361) do not fit their tables in LDS next to the tiles and the rel-pos bias, so
+    // the windows of an image are cut into R slices; a workgroup loads the tables of ONE slice and walks (image, window in slice).
+    const int slice = blockIdx.x % p.R, w0 = slice * p.wchunk;
+    const int cnt = p.nW - w0 < p.wchunk ? p.nW - w0 : p.wchunk;            // windows in this slice
+    const int gi = blockIdx.x / p.R, ng = (gridDim.x - slice + p.R - 1) / p.R;   // this workgroup's index among those serving the slice
+    const int nwin = p.B * cnt;
 
     // ---- once per workgroup: lane-private weight fragments and bias values -------------------------------
     Frag wq[KS], wk[KS], wv[KS], wp[KS];
@@ -85,8 +91,8 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
     for (int i = tid; i < HEADS * 64 * 64; i += 256) ((float*)(lds + BIAS))[(i >> 6) * BSTR + (i & 63)] = p.bias64[i];
     // the pad/roll/partition tables of every window of the geometry: the loop below then has no ordinary global load
     int32_t* srcs = (int32_t*)(lds + TABLES);
-    uint8_t* regs = (uint8_t*)(srcs + p.nW * 64);
-    for (int i = tid; i < p.nW * 64; i += 256) { srcs[i] = p.src[i]; regs[i] = p.region ? p.region[i] : 0; }
+    uint8_t* regs = (uint8_t*)(srcs + cnt * 64);
+    for (int i = tid; i < cnt * 64; i += 256) { srcs[i] = p.src[w0 * 64 + i]; regs[i] = p.region ? p.region[w0 * 64 + i] : 0; }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     // LayerNorm parameters of this thread's 32 channels (thread = (row t>>2, quarter t&3) in the LN phase)
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
 
     // ---- gather of a window's token rows by LDS-DMA: piece I of 1 KB = slots 4I..4I+3 ----------------------------
     auto gather = [&](int win, int buf) {
-        const int b = win / p.nW, w = win - b * p.nW;
+        const int b = win / cnt, w = win - b * cnt;                        // w: window within the slice (table row)
         const int32_t* src = srcs + w * 64;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -113,11 +119,11 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
         }
     };
 
-    int win = blockIdx.x, buf = 0;
+    int win = gi, buf = 0;
     if (win < nwin) gather(win, 0);
 
-    for (; win < nwin; win += gridDim.x, buf ^= 1) {
-        const int b = win / p.nW, w = win - b * p.nW;
+    for (; win < nwin; win += ng, buf ^= 1) {
+        const int b = win / cnt, w = win - b * cnt;
         const int32_t* src = srcs + w * 64;
         const size_t tok0 = (size_t)b * p.T;
         const unsigned char* raw = lds + XRAW + buf * 64 * ROWB;           // this window's un-normalised rows (also the residual)
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                      // XS complete
-        if (win + gridDim.x < nwin) gather(win + gridDim.x, buf ^ 1);      // next window's rows fly under this window's math
+        if (win + ng < nwin) gather(win + ng, buf ^ 1);      // next window's rows fly under this window's math
 
         // ---- 2. Q^T, K^T [channel][slot] and V [slot][channel] of this wave's head --------------------------------------
         f32x16 qt[2], kt[2], vt[2];
@@ -340,9 +346,10 @@ int attn_block_bf16(const bf16_t* x, const float* ln_g, const float* ln_b, const
                     const bf16_t* wproj, const float* bproj, const float* bias64, const int32_t* src, const uint8_t* region,
                     bf16_t* out, int B, int T, int Cc, int heads, int nW, int N, float eps, float scale, hipStream_t s) {
     if (Cc != C || heads != HEADS) return MASTER_ERR_UNSUPPORTED;
-    const int LDS_BYTES = TABLES + nW * 64 * 5;
-    if (LDS_BYTES > LDS_MAX) return MASTER_ERR_UNSUPPORTED;           // too many windows per image for the in-LDS tables
-    BlockArgs p{x, ln_g, ln_b, wqkv, bqkv, wproj, bproj, bias64, src, region, out, B, T, nW, N, eps, scale};
+    constexpr int WMAX = (LDS_MAX - TABLES) / (64 * 5);               // table rows that fit next to the tiles and the bias (140)
+    const int R = (nW + WMAX - 1) / WMAX, wchunk = (nW + R - 1) / R;
+    const int LDS_BYTES = TABLES + wchunk * 64 * 5;
+    BlockArgs p{x, ln_g, ln_b, wqkv, bqkv, wproj, bproj, bias64, src, region, out, B, T, nW, N, eps, scale, wchunk, R};
     static int attr_set = 0;
     if (attr_set < LDS_BYTES) {
         (void)hipFuncSetAttribute((const void*)attn_block_c128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -350,6 +357,7 @@ int attn_block_bf16(const bf16_t* x, const float* ln_g, const float* ln_b, const
     }
     int grid = B * nW;
     if (grid > 256) grid = 256;                      // persistent: one workgroup per CU walks the windows
+    if (grid < R) grid = R;                          // every slice needs a workgroup
     hipLaunchKernelGGL(attn_block_c128_kernel, dim3(grid), dim3(256), LDS_BYTES, s, p);
     return master_check_launch("attn_block_bf16");
 }

@@ -87,7 +87,7 @@ def test_sigma_mu_and_style_transformer_bf16(cuda, golden):
     assert mx < 8e-2 and l2 < 3e-2, (mx, l2)
 
 
-@pytest.mark.parametrize("B,S", [(1, 256), (2, 64)])
+@pytest.mark.parametrize("B,S", [(1, 256), (2, 64), (1, 512), (1, 200)])
 def test_full_forward_bf16(cuda, B, S):
     from mastermetastyletransfer_amd import MasterStyleTransferModel
     with warnings.catch_warnings():
@@ -175,7 +175,8 @@ def test_token_stationary_linear_and_ln_bf16(cuda, M, N, K, res):
     assert mx < 1.5e-2 and l2 < 5e-3, ("ln", mx, l2)
 
 
-@pytest.mark.parametrize("B,H,W,shift", [(2, 14, 14, 3), (1, 14, 14, 0), (3, 10, 17, 3), (1, 64, 64, 3), (2, 7, 7, 0)])
+@pytest.mark.parametrize("B,H,W,shift", [(2, 14, 14, 3), (1, 14, 14, 0), (3, 10, 17, 3), (1, 64, 64, 3), (2, 7, 7, 0),
+                                          (1, 128, 128, 3), (2, 90, 100, 3)])      # 361 / 195 windows: table slices (R = 3 / 2)
 def test_fused_attention_block_c128_bf16(cuda, B, H, W, shift):
     """x + proj(window_attention(qkv(LN(x)))) in one persistent launch (Swin stage-1 geometry: C=128, 4 heads) against
     the fp32 oracle (torchvision-style block half) on bf16-rounded weights/inputs."""
