@@ -150,6 +150,13 @@ int master_patch_embed_fwd(const float* img, const void* w, const void* bias, co
 int master_patch_merge_ln_fwd(const void* x, const void* gamma, const void* beta, void* out, int B, int H,
                               int W, int C, float eps, int dtype, master_stream_t stream);
 
+/* The whole Swin PatchMerging in one launch (bf16): the 2x2 gather and LayerNorm(4C) above happen in the prologue of
+ * the token-stationary Linear(4C, N, no bias): out[B*H/2*W/2, N] = LN(gather(x)) . w^T, w = [N, 4C].  Replaces torchvision
+ * swin_b.features[2] (built at reference codes/utils.py:89-93).  MASTER_ERR_UNSUPPORTED unless dtype = bf16, 4C in
+ * {128,256,512}, N % 128 == 0. */
+int master_patch_merge_linear_fwd(const void* x, const float* gamma, const float* beta, const void* w, void* out, int B,
+                                  int H, int W, int C, int N, float eps, int dtype, master_stream_t stream);
+
 /* Element type conversion fp32 <-> bf16 for n elements (weights at load, activations at the edges). */
 int master_convert(const void* src, void* dst, size_t n, int src_dtype, int dst_dtype, master_stream_t stream);
 

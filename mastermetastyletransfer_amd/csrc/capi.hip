@@ -29,7 +29,7 @@ template <typename T> int instnorm_launch(const void*, void*, const void*, void*
 template <typename T> int patch_embed_launch(const float*, const void*, const void*, const void*, const void*, void*, int, int, int, float, hipStream_t);
 int convert_launch(const void*, void*, size_t, int, int, hipStream_t);
 int linear_ts_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const bf16_t*, bf16_t*,
-                   int, int, int, int, int, int, float, hipStream_t);
+                   int, int, int, int, int, int, float, hipStream_t, int mH = 0, int mW = 0, int mC = 0);
 int attn_block_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const float*, const float*,
                     const int32_t*, const uint8_t*, bf16_t*, int, int, int, int, int, int, float, float, hipStream_t);
 int patch_embed_bf16(const float*, const float*, const float*, const float*, const float*, bf16_t*, int, int, int, float, hipStream_t);
@@ -143,6 +143,21 @@ int master_linear_ln_fwd(const void* x, const float* ln_gamma, const float* ln_b
     const int rc = linear_ts_bf16((const bf16_t*)x, ln_gamma, ln_beta, (const bf16_t*)w, (const float*)bias, (const bf16_t*)r1,
                                   (const bf16_t*)r2, (bf16_t*)out, M, N, K, ldx, ldr, ldo, eps, s);
     if (rc == MASTER_ERR_UNSUPPORTED) master_set_error("linear_ln: shape M=%d N=%d K=%d not covered by the fused kernel", M, N, K);
+    return rc;
+}
+
+int master_patch_merge_linear_fwd(const void* x, const float* gamma, const float* beta, const void* w, void* out, int B, int H,
+                                  int W, int C, int N, float eps, int dtype, master_stream_t stream) {
+    REQUIRE(x && gamma && beta && w && out, "patch_merge_linear: null operand");
+    REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && N > 0, "patch_merge_linear: H, W must be even");
+    if (dtype != MASTER_BF16) { master_set_error("patch_merge_linear: fused kernel is bf16-only; use master_patch_merge_ln_fwd + master_linear_fwd"); return MASTER_ERR_UNSUPPORTED; }
+    REQUIRE(al16(x) && al16(w), "patch_merge_linear: alignment");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_LINEAR, s);
+    const int M = B * (H / 2) * (W / 2);
+    const int rc = linear_ts_bf16((const bf16_t*)x, gamma, beta, (const bf16_t*)w, nullptr, nullptr, nullptr, (bf16_t*)out, M, N, 4 * C,
+                                  4 * C, 0, N, eps, s, H, W, C);
+    if (rc == MASTER_ERR_UNSUPPORTED) master_set_error("patch_merge_linear: C=%d N=%d not covered by the fused kernel", C, N);
     return rc;
 }
 

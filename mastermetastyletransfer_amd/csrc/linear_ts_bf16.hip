@@ -26,6 +26,7 @@ struct LinArgs {
     const bf16_t* x; const float* ln_g; const float* ln_b; const bf16_t* w; const float* bias;
     const bf16_t* r1; const bf16_t* r2; bf16_t* out;
     int M, N, ldx, ldr, ldo; float eps;
+    int mH, mW, mC;              // PatchMerging gather: x is NHWC [B, mH, mW, mC] and row m = the 2x2 neighbourhood (K = 4 mC); 0 = off
 };
 
 union Frag { u32x4 u; bf16x8_t b; };
@@ -100,9 +101,21 @@ __global__ __launch_bounds__(NW * 64) void linear_ts_bf16_kernel(LinArgs p) {
 
     Frag xf[KS];
     {
-        const bf16_t* xp = p.x + (size_t)mc * p.ldx + 8 * h;
+        if (p.mC) {
+            // torchvision PatchMerging: cat(x[0::2,0::2], x[1::2,0::2], x[0::2,1::2], x[1::2,1::2]) -> segment q is pixel (dy = q&1, dx = q>>1)
+            const int W2 = p.mW >> 1, H2 = p.mH >> 1;
+            const int b = mc / (H2 * W2), rem = mc - b * (H2 * W2), y2 = rem / W2, x2 = rem - y2 * W2;
+            const bf16_t* px = p.x + (((size_t)b * p.mH + 2 * y2) * p.mW + 2 * x2) * p.mC;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) xf[s].u = *(const u32x4*)(xp + 16 * s);
+            for (int s = 0; s < KS; ++s) {
+                const int k0 = 16 * s + 8 * h, q = k0 / p.mC, c = k0 - q * p.mC;
+                xf[s].u = *(const u32x4*)(px + ((size_t)(q & 1) * p.mW + (q >> 1)) * p.mC + c);
+            }
+        } else {
+            const bf16_t* xp = p.x + (size_t)mc * p.ldx + 8 * h;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) xf[s].u = *(const u32x4*)(xp + 16 * s);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (p.ln_g) {
@@ -253,10 +266,11 @@ int launch(const LinArgs& p, hipStream_t s) {
 // returns MASTER_ERR_UNSUPPORTED when the shape is outside what this kernel covers (the caller then uses the tiled GEMM)
 int linear_ts_bf16(const bf16_t* x, const float* ln_g, const float* ln_b, const bf16_t* w, const float* bias,
                    const bf16_t* r1, const bf16_t* r2, bf16_t* out, int M, int N, int K, int ldx, int ldr, int ldo, float eps,
-                   hipStream_t s) {
+                   hipStream_t s, int mH = 0, int mW = 0, int mC = 0) {
     const bool res = r1 || r2;
     if (N % 128 != 0 || N > 1024 || (res && N > 256) || (K != 128 && K != 256 && K != 512)) return MASTER_ERR_UNSUPPORTED;
-    LinArgs p{x, ln_g, ln_b, w, bias, r1, r2, out, M, N, ldx, ldr, ldo, eps};
+    if (mC && (4 * mC != K || mC % 8 != 0)) return MASTER_ERR_UNSUPPORTED;
+    LinArgs p{x, ln_g, ln_b, w, bias, r1, r2, out, M, N, ldx, ldr, ldo, eps, mH, mW, mC};
     if (K == 128) return res ? launch<128, true>(p, s) : launch<128, false>(p, s);
     if (K == 256) return res ? launch<256, true>(p, s) : launch<256, false>(p, s);
     return res ? launch<512, true>(p, s) : launch<512, false>(p, s);

@@ -612,8 +612,8 @@ class PatchMerging(_HipModule):
         C = x2d.shape[1]
         if H % 2 or W % 2:
             raise NotImplementedError("odd feature maps need torchvision's pad-to-even; image sides must be multiples of 8")
-        g = ops.patch_merge_ln(x2d.view(B, H, W, C), self._b("nw", self.norm.weight), self._b("nb", self.norm.bias), self.norm.eps)
-        return ops.linear(g.view(B * (H // 2) * (W // 2), 4 * C), self._w("red", self.reduction.weight))
+        return ops.patch_merge_linear(x2d.view(B, H, W, C), self._b("nw", self.norm.weight), self._b("nb", self.norm.bias),
+                                      self._w("red", self.reduction.weight), self.norm.eps)
 
 
 class SwinEncoder(nn.Sequential):

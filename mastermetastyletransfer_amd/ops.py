@@ -22,7 +22,7 @@ K_FAMILIES = ("linear", "conv3x3", "window_attn", "layernorm", "instnorm", "patc
 EXPORTS = (
     "master_version", "master_last_error_string", "master_linear_fwd", "master_conv3x3_reflect_fwd",
     "master_window_attn_fwd", "master_layernorm_fwd", "master_instnorm_fwd", "master_patch_embed_fwd",
-    "master_patch_merge_ln_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_linear_ln_fwd", "master_attn_block_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
+    "master_patch_merge_ln_fwd", "master_patch_merge_linear_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_linear_ln_fwd", "master_attn_block_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
 )
 
 _lib = None
@@ -77,6 +77,7 @@ def load_library() -> ctypes.CDLL:
     lib.master_instnorm_fwd.argtypes = [vp] * 4 + [ci] * 4 + [cf, ci, ci, vp]
     lib.master_patch_embed_fwd.argtypes = [vp] * 6 + [ci] * 4 + [cf, ci, vp]
     lib.master_patch_merge_ln_fwd.argtypes = [vp] * 4 + [ci] * 4 + [cf, ci, vp]
+    lib.master_patch_merge_linear_fwd.argtypes = [vp] * 5 + [ci] * 5 + [cf, ci, vp]
     lib.master_convert.argtypes = [vp, vp, ctypes.c_size_t, ci, ci, vp]
     lib.master_mlp_fwd.argtypes = [vp] * 9 + [ci] * 6 + [cf, ci, vp]
     lib.master_linear_ln_fwd.argtypes = [vp] * 8 + [ci] * 6 + [cf, ci, vp]
@@ -312,6 +313,24 @@ def patch_merge_ln(x: torch.Tensor, gamma, beta, eps: float = 1e-5) -> torch.Ten
     _check(load_library().master_patch_merge_ln_fwd(_p(x), _p(gamma), _p(beta), _p(out), B, H, W, C, eps, _dt(x),
                                                      _stream()), "master_patch_merge_ln_fwd")
     return out
+
+
+def patch_merge_linear(x: torch.Tensor, gamma, beta, w: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """torchvision PatchMerging: Linear(4C, N, no bias)(LayerNorm(2x2 gather(x))); x NHWC [B,H,W,C] -> [B*H/2*W/2, N].
+    bf16 mode: one launch (gather + LN in the GEMM prologue); otherwise gather+LN, then Linear."""
+    B, H, W, C = x.shape
+    N = w.shape[0]
+    if x.dtype == torch.bfloat16 and 4 * C in (128, 256, 512) and N % 128 == 0 and N <= 1024 and x.is_contiguous():
+        _dev(x, w)
+        M = B * (H // 2) * (W // 2)
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+        if _COUNT_ON:
+            _count("linear", flops=2.0 * M * N * 4 * C, bytes=x.element_size() * (x.numel() + w.numel() + M * N))
+        _check(load_library().master_patch_merge_linear_fwd(_p(x), _p(gamma), _p(beta), _p(w), _p(out), B, H, W, C, N, eps, _dt(x),
+                                                            _stream()), "master_patch_merge_linear_fwd")
+        return out
+    g = patch_merge_ln(x, gamma, beta, eps)
+    return linear(g.view(B * (H // 2) * (W // 2), 4 * C), w)
 
 
 def convert(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:

@@ -236,3 +236,21 @@ def test_patch_embed_mfma_bf16(cuda, B, H, W):
     assert out.dtype == BF and out.shape == ref.shape
     mx, l2 = rel_err(out, ref)
     assert mx < 1.5e-2 and l2 < 5e-3, (mx, l2)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 16, 24), (1, 64, 64), (3, 6, 10)])
+def test_patch_merge_linear_fused_bf16(cuda, B, H, W):
+    """torchvision PatchMerging (2x2 gather in the order (0,0),(1,0),(0,1),(1,1) -> LayerNorm(4C) -> Linear(4C,2C, no bias)) in one launch"""
+    from mastermetastyletransfer_amd import ops
+    C = 128
+    g = torch.Generator().manual_seed(B + H)
+    x = torch.randn(B, H, W, C, generator=g).to(BF)
+    gw, gb = 1 + 0.2 * torch.randn(4 * C, generator=g), 0.2 * torch.randn(4 * C, generator=g)
+    w = (torch.randn(2 * C, 4 * C, generator=g) / (4 * C) ** 0.5).to(BF)
+    xf = x.float()
+    cat = torch.cat([xf[:, 0::2, 0::2], xf[:, 1::2, 0::2], xf[:, 0::2, 1::2], xf[:, 1::2, 1::2]], -1)
+    ref = F.linear(F.layer_norm(cat, (4 * C,), gw, gb, 1e-5).to(BF).float(), w.float()).reshape(-1, 2 * C)
+    out = ops.patch_merge_linear(x.to(cuda), gw.to(cuda), gb.to(cuda), w.to(cuda))
+    assert out.shape == ref.shape and out.dtype == BF
+    mx, l2 = rel_err(out, ref)
+    assert mx < 1.5e-2 and l2 < 5e-3, (mx, l2)

@@ -230,3 +230,25 @@ def test_full_batch_32_properties(cuda):
             assert torch.equal(one, full[i:i + 1]), f"sample {i} depends on its batch"
         ref = O.full_forward(c[5:6].cpu(), s[5:6].cpu(), 1, swin_sd, st_sd, dec_sd)
     assert_close(full[5:6], ref, "sample 5 of the bs=32 batch")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_graph_replay_matches_eager(cuda, mode):
+    """hipGraph capture of the forward (GraphedStylizer): replays are bit-identical to eager calls, also for new inputs"""
+    import warnings
+    from mastermetastyletransfer_amd import GraphedStylizer, MasterStyleTransferModel
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7])
+    m = m.to(cuda).eval().set_compute_dtype(torch.float32 if mode == "fp32" else torch.bfloat16)
+    g = torch.Generator().manual_seed(5)
+    stylize = GraphedStylizer(m, 2, 64, 96, transformer_layer_count=2)
+    for _ in range(3):
+        c, s = torch.rand(2, 3, 64, 96, generator=g).to(cuda), torch.rand(2, 3, 64, 96, generator=g).to(cuda)
+        with torch.no_grad():
+            want = m(c, s, 2)
+        got = stylize(c, s, copy=True)
+        assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        stylize(torch.zeros(1, 3, 64, 96, device=cuda), torch.zeros(1, 3, 64, 96, device=cuda))
