@@ -157,6 +157,20 @@ int master_patch_merge_ln_fwd(const void* x, const void* gamma, const void* beta
 int master_patch_merge_linear_fwd(const void* x, const float* gamma, const float* beta, const void* w, void* out, int B,
                                   int H, int W, int C, int N, float eps, int dtype, master_stream_t stream);
 
+/* ---- pre/post-processing around the forward (reference test_model.py:39-48,110-125 and :207) -------------------------
+ * master_resize_plan: HOST helper, no GPU work.  Pillow's bilinear resample tables for one axis (what
+ *   transforms.Resize does to a PIL image): bounds[out][2] = (first source index, tap count), coeffs[out][ksize] = 22-bit
+ *   fixed-point weights.  Call with bounds = coeffs = NULL to get ksize, allocate, call again; upload once per geometry.
+ * master_preprocess_fwd: img uint8 [B,H,W,3] RGB -> out fp32 [B,3,OH,OW]: horizontal pass (skipped when OW == W, as Pillow
+ *   does) into tmp uint8 [B,H,OW,3], vertical pass, ToTensor (/255), and Normalize ((x-mean)/std, host pointers to 3 floats
+ *   each, both NULL = off).  Integer arithmetic identical to Pillow: bit-exact.  Tables are DEVICE pointers.
+ * master_postprocess_fwd: img fp32 [B,3,H,W] -> out uint8 [B,H,W,3] = clip(x*255, 0, 255) truncated (np.clip(...).astype(uint8)). */
+int master_resize_plan(int in_size, int out_size, int32_t* bounds, int32_t* coeffs, int* ksize);
+int master_preprocess_fwd(const uint8_t* img, int B, int H, int W, float* out, int OH, int OW, const int32_t* h_bounds,
+                          const int32_t* h_coeffs, int h_ksize, const int32_t* v_bounds, const int32_t* v_coeffs, int v_ksize,
+                          uint8_t* tmp, const float* mean, const float* stdv, master_stream_t stream);
+int master_postprocess_fwd(const float* img, uint8_t* out, int B, int H, int W, master_stream_t stream);
+
 /* Element type conversion fp32 <-> bf16 for n elements (weights at load, activations at the edges). */
 int master_convert(const void* src, void* dst, size_t n, int src_dtype, int dst_dtype, master_stream_t stream);
 

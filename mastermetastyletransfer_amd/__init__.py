@@ -1,9 +1,10 @@
 """MI355X-native stylization path of Master (Meta Style Transformer): a drop-in for the reference's
 ``codes.full_model.MasterStyleTransferModel`` whose forward runs hand-written gfx950 HIP kernels."""
 from .graph import GraphedStylizer
+from .imageio import Preprocess, postprocess
 from .model import MasterStyleTransferModel
 from .modules import (Decoder, ShiftedWindowAttention, ShiftedWindowAttention_for_decoder_last_MHA, StyleDecoder,
                       StyleEncoder, StyleSwinTransformerBlock, StyleTransformer, SwinEncoder)
 
-__all__ = ["MasterStyleTransferModel", "GraphedStylizer", "StyleTransformer", "StyleEncoder", "StyleDecoder", "StyleSwinTransformerBlock",
+__all__ = ["MasterStyleTransferModel", "GraphedStylizer", "Preprocess", "postprocess", "StyleTransformer", "StyleEncoder", "StyleDecoder", "StyleSwinTransformerBlock",
            "ShiftedWindowAttention", "ShiftedWindowAttention_for_decoder_last_MHA", "Decoder", "SwinEncoder"]

@@ -39,6 +39,10 @@ int conv_halo_bf16(const bf16_t*, const bf16_t*, const float*, bf16_t*, int, int
 int conv_tail_bf16(const bf16_t*, const bf16_t*, const float*, const bf16_t*, const float*, float*, int, int, int, hipStream_t);
 int mlp_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const float*,
              const bf16_t*, bf16_t*, int, int, int, int, int, int, float, hipStream_t);
+int resize_plan_host(int, int, int32_t*, int32_t*, int*);
+int preprocess_launch(const uint8_t*, int, int, int, float*, int, int, const int32_t*, const int32_t*, int, const int32_t*, const int32_t*, int,
+                      uint8_t*, const float*, const float*, hipStream_t);
+int postprocess_launch(const float*, uint8_t*, int, int, int, hipStream_t);
 int mlp_pc_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const float*,
                 const bf16_t*, bf16_t*, int, int, int, int, int, int, float, hipStream_t);
 
@@ -148,6 +152,27 @@ int master_linear_ln_fwd(const void* x, const float* ln_gamma, const float* ln_b
                                   (const bf16_t*)r2, (bf16_t*)out, M, N, K, ldx, ldr, ldo, eps, s);
     if (rc == MASTER_ERR_UNSUPPORTED) master_set_error("linear_ln: shape M=%d N=%d K=%d not covered by the fused kernel", M, N, K);
     return rc;
+}
+
+int master_resize_plan(int in_size, int out_size, int32_t* bounds, int32_t* coeffs, int* ksize) {
+    REQUIRE(in_size > 0 && out_size > 0 && ksize, "resize_plan: sizes must be positive and ksize non-null");
+    return resize_plan_host(in_size, out_size, bounds, coeffs, ksize);
+}
+
+int master_preprocess_fwd(const uint8_t* img, int B, int H, int W, float* out, int OH, int OW, const int32_t* h_bounds,
+                          const int32_t* h_coeffs, int h_ksize, const int32_t* v_bounds, const int32_t* v_coeffs, int v_ksize,
+                          uint8_t* tmp, const float* mean, const float* stdv, master_stream_t stream) {
+    REQUIRE(img && out && v_bounds && v_coeffs, "preprocess: null operand");
+    REQUIRE(B > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && v_ksize > 0, "preprocess: bad dims");
+    REQUIRE(OW == W || (h_bounds && h_coeffs && h_ksize > 0 && tmp), "preprocess: the horizontal pass needs its tables and the [B,H,OW,3] workspace");
+    REQUIRE((mean == nullptr) == (stdv == nullptr), "preprocess: mean and std come together");
+    return preprocess_launch(img, B, H, W, out, OH, OW, h_bounds, h_coeffs, h_ksize, v_bounds, v_coeffs, v_ksize, tmp, mean, stdv,
+                             (hipStream_t)stream);
+}
+
+int master_postprocess_fwd(const float* img, uint8_t* out, int B, int H, int W, master_stream_t stream) {
+    REQUIRE(img && out && B > 0 && H > 0 && W > 0, "postprocess: bad operand");
+    return postprocess_launch(img, out, B, H, W, (hipStream_t)stream);
 }
 
 int master_patch_merge_linear_fwd(const void* x, const float* gamma, const float* beta, const void* w, void* out, int B, int H,

@@ -22,7 +22,7 @@ K_FAMILIES = ("linear", "conv3x3", "window_attn", "layernorm", "instnorm", "patc
 EXPORTS = (
     "master_version", "master_last_error_string", "master_linear_fwd", "master_conv3x3_reflect_fwd",
     "master_window_attn_fwd", "master_layernorm_fwd", "master_instnorm_fwd", "master_patch_embed_fwd",
-    "master_patch_merge_ln_fwd", "master_patch_merge_linear_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_linear_ln_fwd", "master_attn_block_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
+    "master_patch_merge_ln_fwd", "master_patch_merge_linear_fwd", "master_resize_plan", "master_preprocess_fwd", "master_postprocess_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_linear_ln_fwd", "master_attn_block_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
 )
 
 _lib = None
@@ -79,6 +79,9 @@ def load_library() -> ctypes.CDLL:
     lib.master_patch_merge_ln_fwd.argtypes = [vp] * 4 + [ci] * 4 + [cf, ci, vp]
     lib.master_patch_merge_linear_fwd.argtypes = [vp] * 5 + [ci] * 5 + [cf, ci, vp]
     lib.master_convert.argtypes = [vp, vp, ctypes.c_size_t, ci, ci, vp]
+    lib.master_resize_plan.argtypes = [ci, ci, vp, vp, ctypes.POINTER(ci)]
+    lib.master_preprocess_fwd.argtypes = [vp, ci, ci, ci, vp, ci, ci, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp]
+    lib.master_postprocess_fwd.argtypes = [vp, vp, ci, ci, ci, vp]
     lib.master_mlp_fwd.argtypes = [vp] * 9 + [ci] * 6 + [cf, ci, vp]
     lib.master_linear_ln_fwd.argtypes = [vp] * 8 + [ci] * 6 + [cf, ci, vp]
     lib.master_attn_block_fwd.argtypes = [vp] * 11 + [ci] * 6 + [cf, cf, ci, vp]
@@ -331,6 +334,54 @@ def patch_merge_linear(x: torch.Tensor, gamma, beta, w: torch.Tensor, eps: float
         return out
     g = patch_merge_ln(x, gamma, beta, eps)
     return linear(g.view(B * (H // 2) * (W // 2), 4 * C), w)
+
+
+_RESIZE_PLANS = {}
+
+
+def resize_plan(in_size: int, out_size: int, device) -> tuple:
+    """Pillow bilinear resample tables of one axis as device tensors (bounds int32 [out,2], coeffs int32 [out,ksize]); cached."""
+    key = (in_size, out_size, str(device))
+    hit = _RESIZE_PLANS.get(key)
+    if hit is None:
+        import ctypes
+        lib = load_library()
+        ks = ctypes.c_int(0)
+        _check(lib.master_resize_plan(in_size, out_size, None, None, ctypes.byref(ks)), "master_resize_plan")
+        b = torch.empty((out_size, 2), dtype=torch.int32)
+        k = torch.empty((out_size, ks.value), dtype=torch.int32)
+        _check(lib.master_resize_plan(in_size, out_size, ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(k.data_ptr()), ctypes.byref(ks)),
+               "master_resize_plan")
+        hit = _RESIZE_PLANS[key] = (b.to(device), k.to(device))
+    return hit
+
+
+def preprocess(img: torch.Tensor, out_h: int, out_w: int, mean=None, std=None) -> torch.Tensor:
+    """uint8 [B,H,W,3] RGB -> fp32 [B,3,out_h,out_w]: Pillow-exact bilinear resize, /255, optional (x - mean) / std"""
+    import ctypes
+    _dev(img)
+    assert img.dtype == torch.uint8 and img.dim() == 4 and img.shape[3] == 3 and img.is_contiguous()
+    B, H, W, _ = img.shape
+    hb, hk = resize_plan(W, out_w, img.device)
+    vb, vk = resize_plan(H, out_h, img.device)
+    out = torch.empty((B, 3, out_h, out_w), dtype=torch.float32, device=img.device)
+    tmp = torch.empty((B, H, out_w, 3), dtype=torch.uint8, device=img.device) if out_w != W else None
+    m = (ctypes.c_float * 3)(*mean) if mean is not None else None
+    d = (ctypes.c_float * 3)(*std) if std is not None else None
+    _check(load_library().master_preprocess_fwd(_p(img), B, H, W, _p(out), out_h, out_w, _p(hb), _p(hk), hk.shape[1], _p(vb), _p(vk),
+                                                vk.shape[1], _p(tmp), m, d, _stream()), "master_preprocess_fwd")
+    return out
+
+
+def postprocess(img: torch.Tensor) -> torch.Tensor:
+    """fp32 [B,3,H,W] -> uint8 [B,H,W,3] = clip(x * 255, 0, 255) truncated"""
+    _dev(img)
+    assert img.dtype == torch.float32 and img.dim() == 4 and img.shape[1] == 3
+    img = img.contiguous()
+    B, _, H, W = img.shape
+    out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=img.device)
+    _check(load_library().master_postprocess_fwd(_p(img), _p(out), B, H, W, _stream()), "master_postprocess_fwd")
+    return out
 
 
 def convert(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:

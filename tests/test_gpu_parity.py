@@ -252,3 +252,27 @@ def test_graph_replay_matches_eager(cuda, mode):
         assert torch.equal(got, want)
     with pytest.raises(ValueError):
         stylize(torch.zeros(1, 3, 64, 96, device=cuda), torch.zeros(1, 3, 64, 96, device=cuda))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,oh,ow,norm", [(2, 240, 320, 256, 256, True), (1, 300, 200, 256, 256, False), (3, 64, 48, 256, 256, True),
+                                              (1, 256, 256, 256, 256, True), (1, 256, 500, 256, 256, True), (2, 1000, 33, 31, 17, True)])
+def test_preprocess_bit_exact(cuda, B, H, W, oh, ow, norm):
+    """device resize + ToTensor + Normalize == the Pillow-pinned CPU restatement, bit for bit (integer passes, IEEE fp32 epilogue)"""
+    from oracle import imageio_oracle as IO
+    from mastermetastyletransfer_amd import Preprocess
+    rng = np.random.default_rng(H + W)
+    imgs = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    got = Preprocess((oh, ow), imagenet_normalization=norm)(torch.from_numpy(imgs).to(cuda)).cpu().numpy()
+    want = np.stack([IO.preprocess(imgs[b], oh, ow, normalize=norm) for b in range(B)])
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_postprocess_bit_exact(cuda):
+    from oracle import imageio_oracle as IO
+    from mastermetastyletransfer_amd import postprocess
+    x = torch.randn(3, 3, 37, 53, generator=torch.Generator().manual_seed(2)) * 0.8 + 0.5
+    x[0, 0, 0, :4] = torch.tensor([0.0, 1.0, 1.0 - 1e-7, 254.999 / 255])
+    got = postprocess(x.to(cuda)).cpu().numpy()
+    assert got.dtype == np.uint8 and np.array_equal(got, IO.postprocess(x.numpy()))
