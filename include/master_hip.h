@@ -157,6 +157,29 @@ int master_patch_merge_ln_fwd(const void* x, const void* gamma, const void* beta
 int master_patch_merge_linear_fwd(const void* x, const float* gamma, const float* beta, const void* w, void* out, int B,
                                   int H, int W, int C, int N, float eps, int dtype, master_stream_t stream);
 
+/* ---- perceptual loss forward (reference codes/loss.py: VGG19_custom :15-37, custom_loss.get_overall_loss :201-336; evaluated under
+ *      no_grad by test_model.py:190-203).  All maps NHWC.
+ * master_image_to_nhwc_fwd: fp32 NCHW image [N,3,H,W] -> [N,H,W,Cpad], channels >= 3 zero (the first VGG conv runs with Cin = Cpad = 32
+ *   and zero weights on the padding).
+ * master_conv3x3_zero_fwd: nn.Conv2d(Cin, Cout, 3, padding=1) (+ReLU): the implicit GEMM of master_conv3x3_reflect_fwd with zero
+ *   padding; w = [Cout][3][3][Cin], Cin % 32 == 0.
+ * master_maxpool2x2_fwd: nn.MaxPool2d(2, 2).
+ * master_channel_stats_fwd: mean and BIASED variance over the HW positions of every (image, channel) (two passes, fp32):
+ *   x.mean([2,3]); x.std([2,3]) = sqrt(var * HW / (HW-1)); the statistics of nn.InstanceNorm2d.  work = 2 * N * S * C floats of
+ *   workspace, S = master_stats_slices(HW) row slices (per-slice partials are added in a fixed order: deterministic).
+ * master_instnorm_distance_fwd: for pairs (image i, image i + pair_offset), i < pairs: per (row slice, pair) partial sums of
+ *   |IN(a) - IN(b)| (squared = 0) or (IN(a) - IN(b))^2 into partial[pairs * S] - the caller's fixed-order sum / (pairs*C*HW)
+ *   is content_loss_each_term (loss.py:112-118).  C a power-of-two multiple of 8 (bf16) / 4 (fp32) up to 2048 / 1024. */
+int master_image_to_nhwc_fwd(const float* img, void* out, int N, int H, int W, int Cpad, int dtype, master_stream_t stream);
+int master_conv3x3_zero_fwd(const void* x, const void* w, const void* bias, void* out, int B, int H, int W, int Cin, int Cout,
+                            int relu, int dtype, master_stream_t stream);
+int master_maxpool2x2_fwd(const void* x, void* out, int N, int H, int W, int C, int dtype, master_stream_t stream);
+int master_stats_slices(int HW);
+int master_channel_stats_fwd(const void* x, float* mean, float* var, float* work, int N, int HW, int C, int dtype,
+                             master_stream_t stream);
+int master_instnorm_distance_fwd(const void* x, const float* mean, const float* var, float* partial, int pairs, int pair_offset,
+                                 int HW, int C, float eps, int squared, int dtype, master_stream_t stream);
+
 /* ---- pre/post-processing around the forward (reference test_model.py:39-48,110-125 and :207) -------------------------
  * master_resize_plan: HOST helper, no GPU work.  Pillow's bilinear resample tables for one axis (what
  *   transforms.Resize does to a PIL image): bounds[out][2] = (first source index, tap count), coeffs[out][ksize] = 22-bit

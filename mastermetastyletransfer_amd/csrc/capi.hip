@@ -12,14 +12,19 @@
 int gemm_f32_linear(const float*, const float*, const float*, const float*, const float*, float*, int, int, int, int,
                     int, int, int, hipStream_t);
 int gemm_f32_conv3x3(const float*, const float*, const float*, float*, int, int, int, int, int, int, int, int,
-                     hipStream_t);
+                     hipStream_t, int zero_pad = 0);
+template <typename T> int image_to_nhwc_launch(const float*, void*, int, int, int, int, hipStream_t);
+template <typename T> int maxpool2_launch(const void*, void*, int, int, int, int, hipStream_t);
+template <typename T> int chan_stats_launch(const void*, float*, float*, float*, int, int, int, hipStream_t);
+int stats_slices(int HW);
+template <typename T> int in_dist_launch(const void*, const float*, const float*, float*, int, int, int, int, float, int, hipStream_t);
 int window_attn_f32(const float*, const float*, const float*, const float*, int, int, int, const float*, const float*,
                     const float*, int, int, const float*, const int32_t*, const uint8_t*, float*, float*, int, int,
                     int, int, int, int, float, hipStream_t);
 int gemm_bf16_linear(const bf16_t*, const bf16_t*, const float*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int,
                      int, int, int, int, hipStream_t);
 int gemm_bf16_conv3x3(const bf16_t*, const bf16_t*, const float*, void*, int, int, int, int, int, int, int, int,
-                      hipStream_t);
+                      hipStream_t, int zero_pad = 0);
 int window_attn_pw_bf16(const bf16_t*, const bf16_t*, const bf16_t*, const bf16_t*, int, int, int, const bf16_t*,
                         const bf16_t*, const bf16_t*, int, int, const float*, const int32_t*, const uint8_t*, bf16_t*,
                         bf16_t*, int, int, int, int, int, int, float, hipStream_t);
@@ -235,6 +240,55 @@ int master_conv3x3_reflect_fwd(const void* x, const void* w, const void* bias, v
     }
     master_set_error("conv3x3: bad dtype %d", dtype);
     return MASTER_ERR_INVALID;
+}
+
+int master_conv3x3_zero_fwd(const void* x, const void* w, const void* bias, void* out, int B, int H, int W, int Cin, int Cout,
+                            int relu, int dtype, master_stream_t stream) {
+    REQUIRE(x && w && out, "conv3x3_zero: null operand");
+    REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cin > 0 && Cin % 32 == 0, "conv3x3_zero: need Cin%%32==0 (Cin=%d; pad the 3-channel image to 32)", Cin);
+    REQUIRE(al16(x) && al16(w), "conv3x3_zero: x/w must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_CONV, s);
+    if (dtype == MASTER_F32)
+        return gemm_f32_conv3x3((const float*)x, (const float*)w, (const float*)bias, (float*)out, B, H, W, Cin, Cout, 0, relu, 0, s, 1);
+    if (dtype == MASTER_BF16)
+        return gemm_bf16_conv3x3((const bf16_t*)x, (const bf16_t*)w, (const float*)bias, out, B, H, W, Cin, Cout, 0, relu, 0, s, 1);
+    master_set_error("conv3x3_zero: bad dtype %d", dtype);
+    return MASTER_ERR_INVALID;
+}
+
+int master_image_to_nhwc_fwd(const float* img, void* out, int N, int H, int W, int Cpad, int dtype, master_stream_t stream) {
+    REQUIRE(img && out && N > 0 && H > 0 && W > 0 && Cpad >= 3, "image_to_nhwc: bad operand");
+    if (dtype == MASTER_F32) return image_to_nhwc_launch<float>(img, out, N, H, W, Cpad, (hipStream_t)stream);
+    if (dtype == MASTER_BF16) return image_to_nhwc_launch<bf16_t>(img, out, N, H, W, Cpad, (hipStream_t)stream);
+    master_set_error("image_to_nhwc: bad dtype %d", dtype); return MASTER_ERR_INVALID;
+}
+
+int master_maxpool2x2_fwd(const void* x, void* out, int N, int H, int W, int C, int dtype, master_stream_t stream) {
+    REQUIRE(x && out && N > 0 && H >= 2 && W >= 2 && C > 0, "maxpool2x2: bad operand");
+    if (dtype == MASTER_F32) return maxpool2_launch<float>(x, out, N, H, W, C, (hipStream_t)stream);
+    if (dtype == MASTER_BF16) return maxpool2_launch<bf16_t>(x, out, N, H, W, C, (hipStream_t)stream);
+    master_set_error("maxpool2x2: bad dtype %d", dtype); return MASTER_ERR_INVALID;
+}
+
+int master_stats_slices(int HW) { return stats_slices(HW); }
+
+int master_channel_stats_fwd(const void* x, float* mean, float* var, float* work, int N, int HW, int C, int dtype, master_stream_t stream) {
+    REQUIRE(x && mean && var && work && N > 0 && HW > 0 && C > 0, "channel_stats: bad operand");
+    const int V = dtype == MASTER_F32 ? 4 : 8;
+    REQUIRE(C % V == 0 && C / V <= 256 && 256 % (C / V) == 0 && al16(x), "channel_stats: C=%d must be a power-of-two multiple of the 16-byte vector, at most 256 vectors", C);
+    if (dtype == MASTER_F32) return chan_stats_launch<float>(x, mean, var, work, N, HW, C, (hipStream_t)stream);
+    if (dtype == MASTER_BF16) return chan_stats_launch<bf16_t>(x, mean, var, work, N, HW, C, (hipStream_t)stream);
+    master_set_error("channel_stats: bad dtype %d", dtype); return MASTER_ERR_INVALID;
+}
+
+int master_instnorm_distance_fwd(const void* x, const float* mean, const float* var, float* partial, int pairs, int pair_offset, int HW,
+                                 int C, float eps, int squared, int dtype, master_stream_t stream) {
+    REQUIRE(x && mean && var && partial && pairs > 0 && pair_offset > 0 && HW > 0 && C > 0, "instnorm_distance: bad operand");
+    { const int V = dtype == MASTER_F32 ? 4 : 8; REQUIRE(C % V == 0 && C / V <= 256 && 256 % (C / V) == 0 && al16(x), "instnorm_distance: C=%d unsupported", C); }
+    if (dtype == MASTER_F32) return in_dist_launch<float>(x, mean, var, partial, pairs, pair_offset, HW, C, eps, squared, (hipStream_t)stream);
+    if (dtype == MASTER_BF16) return in_dist_launch<bf16_t>(x, mean, var, partial, pairs, pair_offset, HW, C, eps, squared, (hipStream_t)stream);
+    master_set_error("instnorm_distance: bad dtype %d", dtype); return MASTER_ERR_INVALID;
 }
 
 int master_decoder_tail_fwd(const void* x, const void* w8, const float* b8, const void* w9, const float* b9, float* out,

@@ -25,6 +25,7 @@ struct GemmArgsB {
     const bf16_t* a; const bf16_t* w; const float* bias; const bf16_t* r1; const bf16_t* r2; void* out;
     int M, N, K, lda, ldo, ldr, act;
     int Hin, Win, Cin, Hout, Wout, up, out_nchw;
+    int zero_pad;      // conv gather: out-of-image taps read 0 (nn.Conv2d padding=1) instead of the mirror pixel (padding_mode='reflect')
     int Kw;            // real length (and stride) of a weight row; K - Kw trailing columns are zero padding
 };
 
@@ -93,9 +94,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_bf16_kernel(G
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
 #pragma unroll
             for (int i = 0; i < ACH; ++i) {
-                const int sy = reflect1(cy[i] + dy, p.Hout) >> p.up;
-                const int sx = reflect1(cx[i] + dx, p.Wout) >> p.up;
+                const int yy = cy[i] + dy, xx = cx[i] + dx;
+                const int sy = reflect1(yy, p.Hout) >> p.up;
+                const int sx = reflect1(xx, p.Wout) >> p.up;
                 a_st[i] = *(const u32x4*)(p.a + ((size_t)(cb[i] * p.Hin + sy) * p.Win + sx) * p.Cin + c);
+                if (p.zero_pad && ((unsigned)yy >= (unsigned)p.Hout || (unsigned)xx >= (unsigned)p.Wout)) a_st[i] = u32x4{0u, 0u, 0u, 0u};
             }
         } else {
 #pragma unroll
@@ -241,16 +244,16 @@ int dispatch(const GemmArgsB& p, hipStream_t s) {
 int gemm_bf16_linear(const bf16_t* a, const bf16_t* w, const float* bias, const bf16_t* r1, const bf16_t* r2,
                      bf16_t* out, int M, int N, int K, int lda, int ldo, int ldr, int act, hipStream_t s) {
     if (K % BK != 0) { master_set_error("linear(bf16): K must be a multiple of 64 (K=%d)", K); return MASTER_ERR_INVALID; }
-    GemmArgsB p{a, w, bias, r1, r2, out, M, N, K, lda, ldo, ldr, act, 0, 0, 0, 1, 1, 0, 0, K};
+    GemmArgsB p{a, w, bias, r1, r2, out, M, N, K, lda, ldo, ldr, act, 0, 0, 0, 1, 1, 0, 0, 0, K};
     return dispatch<false>(p, s);
 }
 
 // w: [Cout][3][3][Cin]; the K loop runs to roundup(9*Cin, 64) with the tail treated as zero weights
 int gemm_bf16_conv3x3(const bf16_t* x, const bf16_t* w, const float* bias, void* out, int B, int Hin, int Win, int Cin,
-                      int Cout, int up, int relu, int out_nchw, hipStream_t s) {
+                      int Cout, int up, int relu, int out_nchw, hipStream_t s, int zero_pad = 0) {
     const int Hout = Hin << up, Wout = Win << up;
     const int Kpad = (9 * Cin + BK - 1) / BK * BK;
     GemmArgsB p{x, w, bias, nullptr, nullptr, out, B * Hout * Wout, Cout, Kpad, 0, Cout, 0,
-                relu ? MASTER_ACT_RELU : MASTER_ACT_NONE, Hin, Win, Cin, Hout, Wout, up, out_nchw, 9 * Cin};
+                relu ? MASTER_ACT_RELU : MASTER_ACT_NONE, Hin, Win, Cin, Hout, Wout, up, out_nchw, zero_pad, 9 * Cin};
     return dispatch<true>(p, s);
 }

@@ -21,7 +21,7 @@ constexpr int LDK = 36;   // padded LDS row stride (floats)
 struct GemmArgs {
     const float* a; const float* w; const float* bias; const float* r1; const float* r2; float* out;
     int M, N, K, lda, ldo, ldr, act;
-    int Hin, Win, Cin, Hout, Wout, up, out_nchw;   // conv gather only
+    int Hin, Win, Cin, Hout, Wout, up, out_nchw, zero_pad;   // conv gather only (zero_pad: out-of-image taps read 0 instead of the mirror pixel)
 };
 
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
@@ -85,9 +85,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(Ge
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
 #pragma unroll
             for (int i = 0; i < ACH; ++i) {
-                int sy = reflect1(cy[i] + dy, p.Hout) >> p.up;
-                int sx = reflect1(cx[i] + dx, p.Wout) >> p.up;
+                const int yy = cy[i] + dy, xx = cx[i] + dx;
+                int sy = reflect1(yy, p.Hout) >> p.up;
+                int sx = reflect1(xx, p.Wout) >> p.up;
                 a_st[i] = *(const f32x4*)(p.a + ((size_t)(cb[i] * p.Hin + sy) * p.Win + sx) * p.Cin + c0);
+                if (p.zero_pad && ((unsigned)yy >= (unsigned)p.Hout || (unsigned)xx >= (unsigned)p.Wout)) a_st[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         } else {
 #pragma unroll
@@ -198,14 +200,14 @@ int dispatch(const GemmArgs& p, hipStream_t s) {
 
 int gemm_f32_linear(const float* a, const float* w, const float* bias, const float* r1, const float* r2, float* out,
                     int M, int N, int K, int lda, int ldo, int ldr, int act, hipStream_t s) {
-    GemmArgs p{a, w, bias, r1, r2, out, M, N, K, lda, ldo, ldr, act, 0, 0, 0, 1, 1, 0, 0};
+    GemmArgs p{a, w, bias, r1, r2, out, M, N, K, lda, ldo, ldr, act, 0, 0, 0, 1, 1, 0, 0, 0};
     return dispatch<false>(p, s);
 }
 
 int gemm_f32_conv3x3(const float* x, const float* w, const float* bias, float* out, int B, int Hin, int Win, int Cin,
-                     int Cout, int up, int relu, int out_nchw, hipStream_t s) {
+                     int Cout, int up, int relu, int out_nchw, hipStream_t s, int zero_pad = 0) {
     const int Hout = Hin << up, Wout = Win << up;
     GemmArgs p{x, w, bias, nullptr, nullptr, out, B * Hout * Wout, Cout, 9 * Cin, 0, Cout, 0,
-               relu ? MASTER_ACT_RELU : MASTER_ACT_NONE, Hin, Win, Cin, Hout, Wout, up, out_nchw};
+               relu ? MASTER_ACT_RELU : MASTER_ACT_NONE, Hin, Win, Cin, Hout, Wout, up, out_nchw, zero_pad};
     return dispatch<true>(p, s);
 }

@@ -1,0 +1,145 @@
+"""MI355X-native forward of the reference's perceptual loss (codes/loss.py), as test_model.py:190-203 evaluates it under no_grad
+around every stylization: VGG-19 features (relu2_1, relu3_1, relu4_1, relu5_1) of content, style and output - one batch of 3B through
+zero-padded implicit-GEMM convolutions - then
+    content = sum_l mean |IN(Fc_l) - IN(Fcs_l)|                      (loss.py:112-118, 272-296)
+    style   = sum_l mean |mu(Fs_l) - mu(Fcs_l)| + mean |sigma(Fs_l) - sigma(Fcs_l)|     (loss.py:121-130, 300-322; unbiased sigma)
+    total   = content + lambda * style                                 (loss.py:246)
+Same class name, constructor keywords, forward signature and return tuples as the reference.  Backward is not implemented (the
+train step is SURVEY 8f-1): calling it with tensors that require grad raises.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import ops
+
+# torchvision vgg19().features[:30]: index -> (Cin, Cout) of the convolutions; max-pools and the taps VGG19_custom returns (loss.py:23-37)
+VGG19_CONVS = {0: (3, 64), 2: (64, 64), 5: (64, 128), 7: (128, 128), 10: (128, 256), 12: (256, 256), 14: (256, 256), 16: (256, 256),
+               19: (256, 512), 21: (512, 512), 23: (512, 512), 25: (512, 512), 28: (512, 512)}
+VGG19_POOLS = (4, 9, 18, 27)
+VGG19_TAPS = (6, 11, 20, 29)
+_CPAD = 32                                  # the 3-channel image is padded to 32 channels (zero weights) for the implicit GEMM
+
+
+class VGG19_custom(nn.Module):
+    """reference loss.py:15-37 - holds `features` with torchvision's child indices, so state dicts of the reference's saved cut
+    model ("0.weight", "2.weight", ... "28.bias") load by key; forward returns [relu2_1, relu3_1, relu4_1, relu5_1] as NHWC maps."""
+
+    def __init__(self, features: Optional[nn.Module] = None):
+        super().__init__()
+        if features is None:
+            layers = []
+            for i in range(30):
+                layers.append(nn.Conv2d(*VGG19_CONVS[i], kernel_size=3, padding=1) if i in VGG19_CONVS
+                              else nn.MaxPool2d(2, 2) if i in VGG19_POOLS else nn.ReLU(inplace=True))
+            features = nn.Sequential(*layers)
+        self.features = features
+        self.compute_dtype = torch.float32
+        self._packed: Dict[int, tuple] = {}
+
+    def _weights(self, i: int):
+        conv = self.features[i]
+        key = (conv.weight.data_ptr(), conv.weight._version, self.compute_dtype, str(conv.weight.device))
+        hit = self._packed.get(i)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                w = conv.weight.detach().permute(0, 2, 3, 1)                       # [Cout,3,3,Cin]
+                if w.shape[3] % 32:
+                    w = torch.nn.functional.pad(w, (0, _CPAD - w.shape[3]))
+                hit = (key, ops.convert(w.contiguous().float(), self.compute_dtype), conv.bias.detach().float().contiguous())
+            self._packed[i] = hit
+        return hit[1], hit[2]
+
+    def forward(self, x: Tensor):
+        """x: fp32 NCHW image batch -> list of four NHWC feature maps in the compute dtype"""
+        h = ops.image_to_nhwc(x, _CPAD, self.compute_dtype)
+        taps = []
+        for i in range(30):
+            if i in VGG19_CONVS:
+                w, b = self._weights(i)
+                h = ops.conv3x3_zero(h, w, b, relu=True)                           # conv i and the ReLU at i+1 in one launch
+            elif i in VGG19_POOLS:
+                h = ops.maxpool2x2(h)
+            elif i in VGG19_TAPS:
+                taps.append(h)
+        return taps
+
+
+class custom_loss(nn.Module):
+    """reference loss.py:69-176 constructor keywords; `vgg_state_dict` (extra, optional) supplies the VGG weights directly."""
+
+    def __init__(self, project_absolute_path: str = "", feature_extractor_model_relative_path: Optional[str] = None,
+                 use_vgg19_with_batchnorm: bool = False, default_lambda_value=10, distance_content: str = "euclidian",
+                 distance_style: str = "euclidian", vgg_state_dict: Optional[dict] = None, compute_dtype: torch.dtype = torch.float32):
+        super().__init__()
+        assert distance_content in ["euclidian", "euclidian_squared"], "distance should be either 'euclidian' or 'euclidian_squared'"
+        assert distance_style in ["euclidian", "euclidian_squared"], "distance should be either 'euclidian' or 'euclidian_squared'"
+        if use_vgg19_with_batchnorm:
+            raise NotImplementedError("the batch-norm VGG-19 variant (loss.py:41-62) is not built; the reference default is the plain one")
+        self.lambda_value = default_lambda_value
+        self.distance_content, self.distance_style = distance_content, distance_style
+        self.feature_extractor_model = VGG19_custom()
+        if vgg_state_dict is None:
+            if feature_extractor_model_relative_path is None:
+                feature_extractor_model_relative_path = os.path.join("weights", "vgg_19_last_layer_is_relu_5_1_output.pt")
+            path = os.path.join(project_absolute_path, feature_extractor_model_relative_path)
+            if not os.path.exists(path):
+                raise ValueError(f"VGG-19 weights not found at {path}: the reference downloads them from torchvision (utils.py:10-57), "
+                                 "which needs a network; save vgg19().features[:30].state_dict() there or pass vgg_state_dict=")
+            loaded = torch.load(path, map_location="cpu")
+            vgg_state_dict = loaded.state_dict() if isinstance(loaded, nn.Module) else loaded
+        self.feature_extractor_model.features.load_state_dict(vgg_state_dict)
+        for param in self.feature_extractor_model.parameters():               # loss.py:173-175
+            param.requires_grad = False
+        self.set_compute_dtype(compute_dtype)
+
+    def set_compute_dtype(self, dtype: torch.dtype) -> "custom_loss":
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute_dtype must be torch.float32 or torch.bfloat16")
+        self.feature_extractor_model.compute_dtype = dtype
+        return self
+
+    def forward(self, content_image, style_image, output_image, distance="euclidian", lambda_value=None,
+                output_content_and_style_loss=False, output_similarity_loss=False):
+        if lambda_value is not None:                                           # loss.py:193-194 (sic): an explicit value is replaced
+            lambda_value = self.lambda_value
+        return self.get_overall_loss(content_image=content_image, style_image=style_image, output_image=output_image,
+                                     loss_weight=lambda_value, output_content_and_style_loss=output_content_and_style_loss,
+                                     output_similarity_loss=output_similarity_loss)
+
+    def get_overall_loss(self, content_image, style_image, output_image, loss_weight=None, output_content_and_style_loss=False,
+                         output_similarity_loss=False):
+        assert content_image.shape == style_image.shape == output_image.shape, "All images should be in the exact same shape"
+        assert content_image.requires_grad == False, "Content image should not require gradient"
+        assert style_image.requires_grad == False, "Style image should not require gradient"
+        if output_image.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError("the loss backward (train step, SURVEY 8f-1) is not built: call under torch.no_grad()")
+        if loss_weight is None:
+            loss_weight = self.lambda_value
+        B = content_image.shape[0]
+        # the three feature extractions of loss.py:227-229 are independent: one batch [content | style | output]
+        taps = self.feature_extractor_model(torch.cat([content_image, style_image, output_image], dim=0))
+        content_loss, style_loss = 0.0, 0.0
+        for f in taps:
+            N, H, W, C = f.shape
+            mean, var = ops.channel_stats(f)
+            # content: IN(Fc) vs IN(Fcs) = images [0,B) vs [2B,3B)                                    (loss.py:272-296)
+            content_loss = content_loss + ops.instnorm_distance(f, mean, var, B, 2 * B, self.distance_content == "euclidian_squared")
+            # style: mean and unbiased std of Fs = images [B,2B) vs Fcs = [2B,3B)                      (loss.py:300-322)
+            std = torch.sqrt(var * (float(H * W) / float(H * W - 1)))
+            dm, ds = mean[B:2 * B] - mean[2 * B:], std[B:2 * B] - std[2 * B:]
+            if self.distance_style == "euclidian_squared":
+                style_loss = style_loss + torch.mean(torch.square(dm)) + torch.mean(torch.square(ds))
+            else:
+                style_loss = style_loss + torch.mean(torch.abs(dm)) + torch.mean(torch.abs(ds))
+        total_loss = content_loss + loss_weight * style_loss
+        if output_similarity_loss:
+            # loss.py:326-336 compares the CONTENT features with themselves (sic), so the term is identically zero
+            similarity_loss = torch.zeros((), dtype=torch.float32, device=content_image.device)
+            return (total_loss, content_loss, style_loss, similarity_loss) if output_content_and_style_loss else (total_loss, similarity_loss)
+        return (total_loss, content_loss, style_loss) if output_content_and_style_loss else total_loss

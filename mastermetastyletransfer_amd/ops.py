@@ -22,7 +22,7 @@ K_FAMILIES = ("linear", "conv3x3", "window_attn", "layernorm", "instnorm", "patc
 EXPORTS = (
     "master_version", "master_last_error_string", "master_linear_fwd", "master_conv3x3_reflect_fwd",
     "master_window_attn_fwd", "master_layernorm_fwd", "master_instnorm_fwd", "master_patch_embed_fwd",
-    "master_patch_merge_ln_fwd", "master_patch_merge_linear_fwd", "master_resize_plan", "master_preprocess_fwd", "master_postprocess_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_linear_ln_fwd", "master_attn_block_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
+    "master_patch_merge_ln_fwd", "master_patch_merge_linear_fwd", "master_resize_plan", "master_preprocess_fwd", "master_postprocess_fwd", "master_image_to_nhwc_fwd", "master_conv3x3_zero_fwd", "master_maxpool2x2_fwd", "master_channel_stats_fwd", "master_stats_slices", "master_instnorm_distance_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_linear_ln_fwd", "master_attn_block_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
 )
 
 _lib = None
@@ -82,6 +82,12 @@ def load_library() -> ctypes.CDLL:
     lib.master_resize_plan.argtypes = [ci, ci, vp, vp, ctypes.POINTER(ci)]
     lib.master_preprocess_fwd.argtypes = [vp, ci, ci, ci, vp, ci, ci, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp]
     lib.master_postprocess_fwd.argtypes = [vp, vp, ci, ci, ci, vp]
+    lib.master_image_to_nhwc_fwd.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
+    lib.master_conv3x3_zero_fwd.argtypes = [vp] * 4 + [ci] * 7 + [vp]
+    lib.master_maxpool2x2_fwd.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
+    lib.master_channel_stats_fwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
+    lib.master_stats_slices.argtypes = [ci]
+    lib.master_instnorm_distance_fwd.argtypes = [vp] * 4 + [ci] * 4 + [cf, ci, ci, vp]
     lib.master_mlp_fwd.argtypes = [vp] * 9 + [ci] * 6 + [cf, ci, vp]
     lib.master_linear_ln_fwd.argtypes = [vp] * 8 + [ci] * 6 + [cf, ci, vp]
     lib.master_attn_block_fwd.argtypes = [vp] * 11 + [ci] * 6 + [cf, cf, ci, vp]
@@ -334,6 +340,60 @@ def patch_merge_linear(x: torch.Tensor, gamma, beta, w: torch.Tensor, eps: float
         return out
     g = patch_merge_ln(x, gamma, beta, eps)
     return linear(g.view(B * (H // 2) * (W // 2), 4 * C), w)
+
+
+def image_to_nhwc(img: torch.Tensor, cpad: int, dtype: torch.dtype) -> torch.Tensor:
+    """fp32 NCHW [N,3,H,W] -> dtype NHWC [N,H,W,cpad] with zero channels 3..cpad-1"""
+    _dev(img)
+    img = img.contiguous().float()
+    N, _, H, W = img.shape
+    out = torch.empty((N, H, W, cpad), dtype=dtype, device=img.device)
+    _check(load_library().master_image_to_nhwc_fwd(_p(img), _p(out), N, H, W, cpad, _dt(out), _stream()), "master_image_to_nhwc_fwd")
+    return out
+
+
+def conv3x3_zero(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, relu: bool = True) -> torch.Tensor:
+    """nn.Conv2d(Cin, Cout, 3, padding=1) (+ReLU) on NHWC x; w_packed = [Cout,3,3,Cin]"""
+    _dev(x, w_packed)
+    B, H, W, Cin = x.shape
+    Cout = w_packed.shape[0]
+    out = torch.empty((B, H, W, Cout), dtype=x.dtype, device=x.device)
+    if _COUNT_ON:
+        _count("conv3x3", flops=2.0 * B * H * W * Cout * 9 * Cin, bytes=x.element_size() * (x.numel() + w_packed.numel() + out.numel()))
+    _check(load_library().master_conv3x3_zero_fwd(_p(x), _p(w_packed), _p(bias), _p(out), B, H, W, Cin, Cout, int(relu), _dt(x), _stream()),
+           "master_conv3x3_zero_fwd")
+    return out
+
+
+def maxpool2x2(x: torch.Tensor) -> torch.Tensor:
+    _dev(x)
+    N, H, W, C = x.shape
+    out = torch.empty((N, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
+    _check(load_library().master_maxpool2x2_fwd(_p(x), _p(out), N, H, W, C, _dt(x), _stream()), "master_maxpool2x2_fwd")
+    return out
+
+
+def channel_stats(x: torch.Tensor):
+    """NHWC x -> (mean [N,C], biased variance [N,C]) over the positions, fp32"""
+    _dev(x)
+    N, H, W, C = x.shape
+    mean = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    var = torch.empty_like(mean)
+    lib = load_library()
+    work = torch.empty((2 * N * lib.master_stats_slices(H * W) * C,), dtype=torch.float32, device=x.device)
+    _check(lib.master_channel_stats_fwd(_p(x), _p(mean), _p(var), _p(work), N, H * W, C, _dt(x), _stream()), "master_channel_stats_fwd")
+    return mean, var
+
+
+def instnorm_distance(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, pairs: int, pair_offset: int, squared: bool,
+                      eps: float = 1e-5) -> torch.Tensor:
+    """mean over pairs, channels and positions of |IN(x[i]) - IN(x[i + pair_offset])| (or its square): a 0-d fp32 tensor"""
+    _dev(x)
+    N, H, W, C = x.shape
+    partial = torch.empty((pairs * load_library().master_stats_slices(H * W),), dtype=torch.float32, device=x.device)
+    _check(load_library().master_instnorm_distance_fwd(_p(x), _p(mean), _p(var), _p(partial), pairs, pair_offset, H * W, C, eps, int(squared),
+                                                       _dt(x), _stream()), "master_instnorm_distance_fwd")
+    return partial.sum() / float(pairs * C * H * W)
 
 
 _RESIZE_PLANS = {}

@@ -1,5 +1,6 @@
 // In-kernel clock of the fused MLP kernel: stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) around the
 // whole kernel in wave 0 of every workgroup (diagnostic build only: the stamps go to a buffer of their own).
+// Ablation switches (probe builds only): -DMLP_X_NOGELU (note: the phase-1 MFMAs then become dead code too), -DMLP_X_NODMA1, -DMLP_X_NORD1.
 // build+run on the GPU box:  hipcc -O3 --offload-arch=gfx950 -std=c++17 -Iinclude -DMLP_CLOCK_PROBE profiles/probes/clock_probe.hip -o /tmp/clock_probe && /tmp/clock_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>

@@ -1,4 +1,5 @@
 // In-kernel clock sections of the producer/consumer MLP (mlp_pc_bf16.hip): wave 0 (fc1) and wave 4 (fc2) of every workgroup.
+// Ablation switches (probe builds only; results are wrong, timings are what is read): -DPC_X_NOGELU, -DPC_X_NODMA, -DPC_X_NOREAD.
 // build+run on the GPU box:  hipcc -O3 --offload-arch=gfx950 -std=c++17 -Iinclude -DMLP_CLOCK_PROBE profiles/probes/clock_probe_pc.hip -o /tmp/cp_pc && /tmp/cp_pc [C]
 #include <hip/hip_runtime.h>
 #include <cstdio>
