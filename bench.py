@@ -220,18 +220,25 @@ def extras(model, content, style, k, args, ops):
         out["parity_fp32_mode"] = {"max_abs_vs_cpu_oracle": float((got32 - ref).abs().max()), "tolerance": 1e-3,
                                    "pass": bool((got32 - ref).abs().max() <= 1e-3)}
     # ---- CPU baseline: the oracle (a port of the reference) on the host cores, bounded sample -------
-    nb = 4
-    cc, ss = content[:nb].cpu(), style[:nb].cpu()
     # the GPU box gives one GPU a share of 16 host cores; more threads than that only oversubscribes
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    runs, spent = [], 0.0
     with torch.no_grad():
-        O.full_forward(cc[:1], ss[:1], k, *sds)                     # warm-up
-        ts = []
-        for _ in range(3):
-            t0 = time.perf_counter(); O.full_forward(cc, ss, k, *sds); ts.append(time.perf_counter() - t0)
-    med = sorted(ts)[1]
-    out["cpu_baseline"] = {"value": round(nb / med, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-                           "sample": f"{nb} pairs {S}x{S} k={k} through oracle.full_forward (fp32 torch CPU), median of 3 after warm-up"}
+        O.full_forward(content[:1].cpu(), style[:1].cpu(), k, *sds)                     # warm-up
+        # the reference harness feeds one pair at a time (test_model.py:110-147); larger CPU batches are tried too and the BEST
+        # throughput is the baseline (batch 32 is markedly slower per image on the CPU than batch 1-8)
+        for nb, reps in ((1, 12), (4, 6), (8, 4), (min(B, 32), 1)):
+            cc, ss = content[:nb].cpu(), style[:nb].cpu()
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter(); O.full_forward(cc, ss, k, *sds); ts.append(time.perf_counter() - t0)
+            spent += sum(ts)
+            runs.append((nb / sorted(ts)[len(ts) // 2], nb, reps))
+    best = max(runs)
+    out["cpu_baseline"] = {"value": round(best[0], 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                           "sample": f"oracle.full_forward (fp32 torch CPU) on {S}x{S} pairs, k={k}: median images/s at batch "
+                                     + ", ".join(f"{nb} (x{reps}): {v:.1f}" for v, nb, reps in runs)
+                                     + f"; best reported; {spent:.1f} s of CPU time in total"}
     return out
 
 
