@@ -223,7 +223,15 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
                 }
             }
         }
+        // the shift mask only bites in windows that straddle a region boundary: when all 64 slots carry the same region id
+        // (interior windows) nothing is masked and the per-element test is skipped (wave-uniform branch)
+        bool mixed = false;
         if (p.region) {
+            const uint8_t* reg = regs + w * 64;
+            const unsigned r0 = reg[0];
+            mixed = __builtin_amdgcn_ballot_w64(reg[lane] != r0) != 0ull;
+        }
+        if (mixed) {
             const uint8_t* reg = regs + w * 64;
 #pragma unroll
             for (int q2 = 0; q2 < 2; ++q2) {

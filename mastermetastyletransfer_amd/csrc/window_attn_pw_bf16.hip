@@ -162,7 +162,15 @@ __global__ __launch_bounds__(512, 2) void window_attn_pw_kernel(PwArgs p) {
                     st[k2][q2][2 * j + 1] = st[k2][q2][2 * j + 1] * p.scale_log2e + __uint_as_float(bpk[q2][k2][j] & 0xffff0000u);
                 }
             }
+        // the shift mask only bites in windows that straddle a region boundary: when all 64 slots carry the same region id
+        // (interior windows) nothing is masked and the per-element test is skipped (wave-uniform branch)
+        bool mixed = false;
         if (p.region) {
+            const uint8_t* reg = regs + w * 64;
+            const unsigned r0 = reg[0];
+            mixed = __builtin_amdgcn_ballot_w64(reg[lane] != r0) != 0ull;
+        }
+        if (mixed) {
             const uint8_t* reg = regs + w * 64;
 #pragma unroll
             for (int q2 = 0; q2 < 2; ++q2) {
