@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
         }
     };
 
+    Frag ones; ones.u = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // bf16 1.0 x 8
     int win = gi, buf = 0;
     if (win < nwin) gather(win, 0);
 
@@ -257,20 +258,24 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[k2][q2][e]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            float sum = 0.f;
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const unsigned pk = pack_bf16x2(__builtin_amdgcn_exp2f(st[k2][q2][8 * s + 2 * j] - mx),
-                                                        __builtin_amdgcn_exp2f(st[k2][q2][8 * s + 2 * j + 1] - mx));
-                        pf[q2][k2][s].u[j] = pk;
-                        sum += __uint_as_float(pk << 16) + __uint_as_float(pk & 0xffff0000u);
-                    }
-            sum += __shfl_xor(sum, 32, 64);
-            inv[q2] = __builtin_amdgcn_rcpf(sum);
+                    for (int j = 0; j < 4; ++j)
+                        pf[q2][k2][s].u[j] = pack_bf16x2(__builtin_amdgcn_exp2f(st[k2][q2][8 * s + 2 * j] - mx),
+                                                         __builtin_amdgcn_exp2f(st[k2][q2][8 * s + 2 * j + 1] - mx));
+            // denominator on the matrix core (4 % busy in this kernel) instead of ~128 VALU ops: with an all-ones A fragment every
+            // row of the product holds sum_k P[k][query] of the ROUNDED probabilities (the values P.V uses), so register 0 is it
+            f32x16 rs;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) rs[e] = 0.f;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) rs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones.b, pf[q2][k2][s].b, rs, 0, 0, 0);
+            inv[q2] = __builtin_amdgcn_rcpf(rs[0]);
         }
 
         // ---- 4. O^T[d][query] = V^T P^T (V tiles as the A operand: X^T B with X = V[key][d]) ------------------------------------
