@@ -26,12 +26,12 @@ PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}     # dense MFMA peaks, MI355X_MIC
 HBM_PEAK_GBS = 8000.0
 
 
-def build_model(device, dtype):
+def build_model(device, dtype, window=7):
     from mastermetastyletransfer_amd import MasterStyleTransferModel
     torch.manual_seed(1)                            # seed 1, reference initialisers, random weights
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        m = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7],
+        m = MasterStyleTransferModel(style_encoder_window_size=[window, window], style_decoder_window_size=[window, window],
                                      style_encoder_shift_size=[4, 4], style_decoder_shift_size=[4, 4])
     # biases/rel-pos tables at the scale the reference's trainer uses (trunc-normal 0.02) instead of zeros,
     # so padded-slot rows and position biases are real data
@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="pairs per GPU (weak scaling)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--layers", type=int, default=1, help="transformer_layer_count k")
+    ap.add_argument("--window", type=int, default=7, help="StyleTransformer window (7 = BASELINE.json; 8 = the reference constructor's default)")
     ap.add_argument("--dtype", choices=["fp32", "bf16"], default=os.environ.get("MASTER_BENCH_DTYPE", "bf16"),
                     help="bf16 = BASELINE.json's configuration (bf16 MFMA, fp32 accumulate); fp32 = exact-fp32 parity mode")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / parity / cpu_baseline legs")
@@ -75,7 +76,7 @@ def main():
     if device.type != "cuda":
         raise SystemExit("bench.py needs a GPU: the stylization path has no CPU fallback")
 
-    model = build_model(device, args.dtype)
+    model = build_model(device, args.dtype, args.window)
     B, S, k = args.batch, args.size, args.layers
     content, style = synthetic_batch(B, S, device, seed=rank)      # each rank its own shard of the global batch
 
@@ -114,7 +115,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"bs={B}/GPU {S}x{S} content+style pairs through MasterStyleTransferModel.forward "
-                               f"(Swin-B[:2 stages] -> StyleTransformer k={k}, window 7 shift 4 -> decoder), "
+                               f"(Swin-B[:2 stages] -> StyleTransformer k={k}, window {args.window} shift 4 -> decoder), "
                                f"outputs all-gathered over RCCL when n_gpus>1",
                    "global_batch": B * world, "image_size": S, "transformer_layer_count": k, "parallelism": f"dp{world}"},
     }

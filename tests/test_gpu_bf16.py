@@ -257,3 +257,27 @@ def test_patch_merge_linear_fused_bf16(cuda, B, H, W):
     assert out.shape == ref.shape and out.dtype == BF
     mx, l2 = rel_err(out, ref)
     assert mx < 1.5e-2 and l2 < 5e-3, (mx, l2)
+
+
+@pytest.mark.parametrize("S", [256, 200])
+def test_default_constructor_window8_both_modes(cuda, S):
+    """The reference's default constructor arguments (full_model.py:30-33): 8x8 windows (64 tokens = the whole 64-slot tile), shift 4.
+    256^2 -> 32x32 map, no padding; 200^2 -> 25x25 map, padded to 32."""
+    from mastermetastyletransfer_amd import MasterStyleTransferModel
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = MasterStyleTransferModel()
+    assert m.style_transformer.encoder.shared_MHA_without_MLP.attn.window_size == [8, 8]
+    sds = (seeded_state_dict(O.swin_shapes(), 41), seeded_state_dict(O.style_transformer_shapes(ws=(8, 8)), 42, ws=(8, 8)), seeded_state_dict(O.decoder_shapes(), 43))
+    m.swin_encoder.load_state_dict(sds[0]); m.style_transformer.load_state_dict(sds[1]); m.decoder.load_state_dict(sds[2])
+    m = m.to(cuda).eval()
+    c = seeded_input(f"c8_{S}", (1, 3, S, S), 8, kind="image"); s = seeded_input(f"s8_{S}", (1, 3, S, S), 9, kind="image")
+    with torch.no_grad():
+        cfg = dict(O.DEFAULT_ST_CFG, encoder_window_size=(8, 8), decoder_window_size=(8, 8))
+        ref = O.full_forward(c, s, 1, *sds, cfg=cfg)
+        got32 = m(c.to(cuda), s.to(cuda), 1).cpu()
+        m.set_compute_dtype(BF)
+        got16 = m(c.to(cuda), s.to(cuda), 1).cpu()
+    assert (got32 - ref).abs().max() < 1e-3
+    mx, l2 = rel_err(got16, ref)
+    assert l2 < 5e-2 and mx < 0.25, (mx, l2)
