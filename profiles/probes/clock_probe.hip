@@ -12,8 +12,8 @@ void master_set_error(const char*, ...) {}
 int master_check_launch(const char*) { return hipGetLastError() == hipSuccess ? 0 : -3; }
 #include "../../mastermetastyletransfer_amd/csrc/mlp_bf16.hip"
 
-int main() {
-    const int M = 32768, C = 256, HID = 1024, WGS = M / 128;
+int main(int argc, char** argv) {
+    const int C = argc > 1 ? atoi(argv[1]) : 256, HID = 4 * C, M = 32768, WGS = M / 128;
     unsigned short *x, *w1, *w2, *out; float *b1, *b2; unsigned long long* probe;
     hipMalloc(&x, (size_t)M * C * 2); hipMalloc(&out, (size_t)M * C * 2); hipMalloc(&w1, (size_t)HID * C * 2); hipMalloc(&w2, (size_t)HID * C * 2);
     hipMalloc(&b1, HID * 4); hipMalloc(&b2, C * 4); hipMalloc(&probe, WGS * 10 * 8);
@@ -33,6 +33,6 @@ int main() {
     printf("workgroups %d: in-kernel clock median %.3f GHz (min %.3f max %.3f); cycles per workgroup median %.0f (%.1f us)\n", WGS, ghz[WGS/2], ghz[0], ghz[WGS-1], cyc[WGS/2], cyc[WGS/2] / ghz[WGS/2] / 1e3);
     double sec[6] = {0, 0, 0, 0, 0, 0};
     for (int i = 0; i < WGS; ++i) for (int j = 0; j < 6; ++j) sec[j] += (double)p[WGS * 4 + i * 6 + j] / WGS;
-    printf("mean cycles per workgroup by section: wait+barrier %.0f | DMA issue %.0f | phase-1 steps %.0f | phase-2 steps %.0f | prologue %.0f | epilogue %.0f  (32 steps; stamps add ~40 cycles each)\n", sec[0], sec[1], sec[2], sec[3], sec[4], sec[5]);
+    printf("mean cycles per workgroup by section: wait+barrier %.0f | DMA issue %.0f | phase-1 steps %.0f | phase-2 steps %.0f | prologue %.0f | epilogue %.0f  (stamps add ~40 cycles each)\n", sec[0], sec[1], sec[2], sec[3], sec[4], sec[5]);
     return 0;
 }
