@@ -40,6 +40,7 @@ int linear_ts_bf16(const bf16_t*, const float*, const float*, const bf16_t*, con
 int attn_block_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const float*, const float*,
                     const int32_t*, const uint8_t*, bf16_t*, int, int, int, int, int, int, float, float, hipStream_t);
 int patch_embed_bf16(const float*, const float*, const float*, const float*, const float*, bf16_t*, int, int, int, float, hipStream_t);
+int conv_ring_bf16(const bf16_t*, const bf16_t*, const float*, bf16_t*, int, int, int, int, int, int, int, hipStream_t);
 int conv_halo_bf16(const bf16_t*, const bf16_t*, const float*, bf16_t*, int, int, int, int, int, int, int, hipStream_t);
 int conv_tail_bf16(const bf16_t*, const bf16_t*, const float*, const bf16_t*, const float*, float*, int, int, int, hipStream_t);
 int mlp_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const float*,
@@ -238,9 +239,11 @@ int master_conv3x3_reflect_fwd(const void* x, const void* w, const void* bias, v
         return gemm_f32_conv3x3((const float*)x, (const float*)w, (const float*)bias, (float*)out, B, Hin, Win, Cin,
                                 Cout, upsample, relu, out_nchw, s);
     if (dtype == MASTER_BF16) {
-        if (!out_nchw) {      // halo-tile kernel (source tile in LDS, weights in registers) where it applies
-            const int rc = conv_halo_bf16((const bf16_t*)x, (const bf16_t*)w, (const float*)bias, (bf16_t*)out, B, Hin, Win, Cin, Cout,
-                                          upsample, relu, s);
+        if (!out_nchw) {      // halo-tile kernels where they apply: Cin = 64 (weights in registers), Cin = 128 (weights through an LDS ring)
+            int rc = conv_halo_bf16((const bf16_t*)x, (const bf16_t*)w, (const float*)bias, (bf16_t*)out, B, Hin, Win, Cin, Cout,
+                                    upsample, relu, s);
+            if (rc != MASTER_ERR_UNSUPPORTED) return rc;
+            rc = conv_ring_bf16((const bf16_t*)x, (const bf16_t*)w, (const float*)bias, (bf16_t*)out, B, Hin, Win, Cin, Cout, upsample, relu, s);
             if (rc != MASTER_ERR_UNSUPPORTED) return rc;
         }
         return gemm_bf16_conv3x3((const bf16_t*)x, (const bf16_t*)w, (const float*)bias, out, B, Hin, Win, Cin, Cout,

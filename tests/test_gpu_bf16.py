@@ -44,7 +44,11 @@ def test_linear_bf16(cuda, M, N, K):
                                                           # halo-tile kernel (Cin = 64, output multiple of 16 x 32): border and interior tiles
                                                           (2, 8, 16, 64, 64, True, True, False), (1, 16, 32, 64, 32, False, True, False),
                                                           (1, 32, 64, 64, 64, False, False, False), (3, 16, 16, 64, 32, True, True, False),
-                                                          (1, 48, 64, 64, 32, False, True, False)])
+                                                          (1, 48, 64, 64, 32, False, True, False),
+                                                          # Cin = 128: pixel-stationary ring kernel (tile 8x32), with / without upsample, Cout 128 / 64
+                                                          (2, 16, 32, 128, 128, False, True, False), (1, 8, 16, 128, 128, True, True, False),
+                                                          (2, 24, 64, 128, 64, False, True, False), (1, 4, 16, 128, 64, True, False, False),
+                                                          (1, 64, 64, 128, 128, False, True, False)])
 def test_conv3x3_bf16(cuda, B, H, W, Cin, Cout, up, relu, nchw):
     from mastermetastyletransfer_amd import ops
     g = torch.Generator().manual_seed(H + Cout)
