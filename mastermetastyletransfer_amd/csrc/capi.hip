@@ -239,11 +239,10 @@ int master_conv3x3_reflect_fwd(const void* x, const void* w, const void* bias, v
         return gemm_f32_conv3x3((const float*)x, (const float*)w, (const float*)bias, (float*)out, B, Hin, Win, Cin,
                                 Cout, upsample, relu, out_nchw, s);
     if (dtype == MASTER_BF16) {
-        if (!out_nchw) {      // halo-tile kernels where they apply: Cin = 64 (weights in registers), Cin = 128 (weights through an LDS ring)
-            int rc = conv_halo_bf16((const bf16_t*)x, (const bf16_t*)w, (const float*)bias, (bf16_t*)out, B, Hin, Win, Cin, Cout,
-                                    upsample, relu, s);
+        if (!out_nchw) {      // tile kernels where they apply: pixel-stationary ring (Cin 256/128, and 64 -> 32), then the Cin = 64 halo kernel
+            int rc = conv_ring_bf16((const bf16_t*)x, (const bf16_t*)w, (const float*)bias, (bf16_t*)out, B, Hin, Win, Cin, Cout, upsample, relu, s);
             if (rc != MASTER_ERR_UNSUPPORTED) return rc;
-            rc = conv_ring_bf16((const bf16_t*)x, (const bf16_t*)w, (const float*)bias, (bf16_t*)out, B, Hin, Win, Cin, Cout, upsample, relu, s);
+            rc = conv_halo_bf16((const bf16_t*)x, (const bf16_t*)w, (const float*)bias, (bf16_t*)out, B, Hin, Win, Cin, Cout, upsample, relu, s);
             if (rc != MASTER_ERR_UNSUPPORTED) return rc;
         }
         return gemm_bf16_conv3x3((const bf16_t*)x, (const bf16_t*)w, (const float*)bias, out, B, Hin, Win, Cin, Cout,

@@ -1,17 +1,21 @@
-// 3x3 reflect-pad convolution (+ nearest x2 upsample in front, + ReLU) for Cin = 128, Cout = 64 / 128, bf16: the middle layers of the
-// decoder (reference codes/decoder.py:26-37: Upsample, Conv(128,128) x3, Conv(128,64)), NHWC in and out.
+// 3x3 reflect-pad convolution (+ nearest x2 upsample in front, + ReLU), bf16, NHWC in and out, PIXEL-stationary: the decoder layers
+// the other conv kernels serve badly (reference codes/decoder.py:24-46):
+//     Cin 256 -> 128 (first layer, 32x32 maps)      tile  4 x 32, one pixel row per wave
+//     Cin 128 -> 128 / 64 (Upsample?, 64x64 maps)   tile  8 x 32, two rows per wave
+//     Cin  64 -> 32 (128x128 maps)                  tile 16 x 32, four rows per wave
 //
-// The implicit GEMM (gemm_bf16.hip) re-gathers every source pixel nine times through L2 and reaches ~550 TFLOP/s on these
-// layers; the halo kernel for Cin = 64 (conv_halo_bf16.hip) keeps its weights in registers, which Cin = 128 cannot (288
-// registers per 32 output channels).  Here the PIXELS are stationary in LDS and the weights stream:
-//   workgroup = 8 x 32 output pixels x all output channels, 4 waves, wave w = output rows 2w, 2w+1 (two 32-pixel MFMA tiles);
-//   the (8+2) x (32+2) source halo tile (reflect and upsample folded into the gather) is fetched ONCE by LDS-DMA: 340 pixel
-//     rows of 256 B, position p of row i holds channel chunk p ^ (i & 15) (conflict-free B-fragment reads);
-//   out^T[cout][pixel] = sum_k W[cout][k] X[pixel][k], k = (tap, channel): A = weights, streamed in 18 steps of
-//     [Cout rows][64 k] (128-B rows, chunk p ^ ((row >> 1) & 7)) through a 4-slot LDS ring by LDS-DMA three steps ahead,
-//     counted vmcnt + one barrier per step; B = pixel fragments read straight from the halo tile at (y+dy, x+dx);
-//   per k-step 4 (2) weight fragments + 2 pixel fragments feed 8 (4) MFMAs;
-//   epilogue: + bias, ReLU, bf16, transposed through the idle ring into whole 256-B (128-B) pixel rows.
+// The implicit GEMM (gemm_bf16.hip) re-gathers every source pixel nine times through L2 (~350-550 TFLOP/s on these layers); the halo
+// kernel for Cin = 64 (conv_halo_bf16.hip) keeps its weights in registers, which Cin >= 128 cannot, and with Cout = 32 it has one
+// MFMA per LDS read.  Here the PIXELS are stationary in LDS and the weights stream:
+//   workgroup = TH x 32 output pixels x all output channels, 4 waves, wave w = output rows RPW w .. RPW w + RPW-1 (RPW 32-pixel MFMA tiles);
+//   the (TH+2) x (32+2) source halo tile (reflect and upsample folded into the gather) is fetched ONCE by LDS-DMA, one pixel = one
+//     row of 2 Cin bytes, 16-B channel chunks swizzled (p ^ (pixel & 15), or p ^ ((pixel >> 1) & 7) for 128-B rows): conflict-free
+//     B-fragment reads;
+//   out^T[cout][pixel] = sum_k W[cout][k] X[pixel][k], k = (tap, channel): A = weights, streamed in 9 Cin/64 steps of [Cout rows][64 k]
+//     (128-B rows, chunk p ^ ((row >> 1) & 7)) through an LDS ring by LDS-DMA, counted vmcnt + one barrier per step; B = pixel
+//     fragments read straight from the halo tile at (y+dy, x+dx);
+//   per k-step Cout/32 weight fragments + RPW pixel fragments feed RPW Cout/32 MFMAs;
+//   epilogue: + bias, ReLU, bf16, transposed through the (now idle) halo region into whole pixel rows of 2 Cout bytes.
 #include "common.h"
 
 namespace {
@@ -20,10 +24,17 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int CIN = 128, TH = 8, TW = 32, HW_ = TW + 2, HROWS = (TH + 2) * HW_;     // 340 halo pixels
-constexpr int HALO_BYTES = HROWS * CIN * 2;                                            // 87 040
-constexpr int RING = 4, AHEAD = 3, KSTEP = 64;                                         // ring step = [Cout][64 k]
-constexpr int NSTEPS = 9 * CIN / KSTEP;                                                // 18
+constexpr int TW = 32, HW_ = TW + 2, KSTEP = 64;                                       // tile width, halo width, k per ring step
+template <int CIN, int RPW> struct Geo {
+    static constexpr int TH = 4 * RPW, HROWS = (TH + 2) * HW_;                          // halo pixels: 204 / 340 / 612
+    static constexpr int RPP = 1024 / (CIN * 2);                                        // pixel rows per one-KB DMA piece: 2 / 4 / 8
+    static constexpr int HPIECES = (HROWS + RPP - 1) / RPP;
+    static constexpr int HALO_BYTES = HPIECES * 1024;                                   // 104 448 / 87 040 / 78 848
+    static constexpr int RING = CIN == 256 ? 3 : 4, AHEAD = RING - 1;                   // the 104-KB halo of Cin 256 leaves room for 3 slots
+    static constexpr int NSTEPS = 9 * CIN / KSTEP;
+};
+template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); }
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 struct RingArgs {
     const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* out;
@@ -33,16 +44,17 @@ struct RingArgs {
 union Frag { u32x4 u; bf16x8_t b; };
 
 #define LDS_READ128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:" #imm : "=v"(dst) : "v"(addr))
-#define LGKM_WAIT(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
-template <int COUT>
+template <int CIN, int COUT, int RPW>
 __global__ __launch_bounds__(256, 1) void conv_ring_kernel(RingArgs p) {
+    typedef Geo<CIN, RPW> G;
+    constexpr int TH = G::TH, HROWS = G::HROWS, HALO_BYTES = G::HALO_BYTES, RING = G::RING, AHEAD = G::AHEAD, NSTEPS = G::NSTEPS;
     constexpr int NT = COUT / 32;                    // output-channel tiles
-    constexpr int SLOTB = COUT * KSTEP * 2;          // 16 KB (Cout 128) / 8 KB (Cout 64)
-    constexpr int PW = SLOTB / 1024 / 4;             // DMA pieces per wave per step: 4 / 2
+    constexpr int SLOTB = COUT * KSTEP * 2;          // 16 / 8 / 4 KB
+    constexpr int PW = SLOTB / 1024 / 4;             // DMA pieces per wave per step: 4 / 2 / 1
+    constexpr int CPR = CIN / 8;                     // 16-B channel chunks per pixel row
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // halo tile | ring | bias[COUT]
     unsigned char* halo = lds;
     unsigned char* ring = lds + HALO_BYTES;
@@ -66,16 +78,19 @@ __global__ __launch_bounds__(256, 1) void conv_ring_kernel(RingArgs p) {
                                          (__attribute__((address_space(3))) void*)(ring + (t % RING) * SLOTB + (wave * PW + i) * 1024), 16, 0, 0);
     };
     int t_issue = 0;
-    for (; t_issue < AHEAD; ++t_issue)
+    for (; t_issue < AHEAD && t_issue < NSTEPS; ++t_issue)
 #pragma unroll
         for (int i = 0; i < PW; ++i) dma_piece(t_issue, i);
 
-    // ---- halo gather: 340 pixel rows of 256 B = 85 pieces of 4 rows; source pixel = reflect at output resolution, then >> up -------
-    for (int I = wave; I < HROWS / 4; I += 4) {
-        const int hp = 4 * I + (lane >> 4);                              // halo pixel index = ly * 34 + lx
+    // ---- halo gather: one-KB pieces of RPP pixel rows; source pixel = reflect at output resolution, then >> up ----------------
+    auto pix_swz = [&](int hp) { return CIN == 64 ? (hp >> 1) & 7 : hp & 15; };      // XOR term of a pixel row's chunk positions
+    for (int I = wave; I < G::HPIECES; I += 4) {
+        int hp = G::RPP * I + lane / CPR;                                // halo pixel index = ly * 34 + lx
+        const int hps = hp;                                              // (the last piece of the 16-row tile runs past the tile: any pixel will do)
+        hp = hp < HROWS ? hp : HROWS - 1;
         const int ly = hp / HW_, lx = hp - ly * HW_;
         const int sy = reflect1(y0 + ly - 1, p.Hout) >> p.up, sx = reflect1(x0 + lx - 1, p.Wout) >> p.up;
-        const int q = (lane & 15) ^ (hp & 15);
+        const int q = (lane % CPR) ^ pix_swz(hps);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.x + (((size_t)b * p.Hin + sy) * p.Win + sx) * CIN + q * 8),
                                          (__attribute__((address_space(3))) void*)(halo + I * 1024), 16, 0, 0);
     }
@@ -87,9 +102,9 @@ __global__ __launch_bounds__(256, 1) void conv_ring_kernel(RingArgs p) {
     const unsigned halo0 = lds_off(halo), ring0 = lds_off(ring);
     const int xsw = (h ^ ((r >> 1) & 7)) << 4;                           // weight rows (128 B): chunk (2s+h) ^ ((row>>1)&7)
 
-    f32x16 acc[2][NT];
+    f32x16 acc[RPW][NT];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+    for (int tt = 0; tt < RPW; ++tt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -99,58 +114,61 @@ __global__ __launch_bounds__(256, 1) void conv_ring_kernel(RingArgs p) {
     for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3, dx = tap - 3 * dy;                       // halo offsets 0..2 (= tap offsets -1..1, the halo starts at -1)
         // halo pixel of this lane's output pixel for this tap, per token tile tt (output row 2 wave + tt)
-        unsigned pix[2]; int psw[2];
+        unsigned pix[RPW]; int psw[RPW];
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int hp = (2 * wave + tt + dy) * HW_ + r + dx;
-            pix[tt] = halo0 + hp * (CIN * 2); psw[tt] = hp & 15;
+        for (int tt = 0; tt < RPW; ++tt) {
+            const int hp = (RPW * wave + tt + dy) * HW_ + r + dx;
+            pix[tt] = halo0 + hp * (CIN * 2); psw[tt] = pix_swz(hp);
         }
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {                           // two ring steps per tap: channels [64 half, 64 half + 64)
+        for (int half = 0; half < CIN / KSTEP; ++half) {                 // ring steps of this tap: channels [64 half, 64 half + 64)
             // my DMA pieces of step t_cons have landed -> barrier -> everyone's have, and everyone left the slot step t_cons+3 goes into
             {
-                const int ahead = t_issue - 1 - t_cons;
-                if (PW == 4) { if (ahead >= 2) WAIT_VMCNT(8); else if (ahead == 1) WAIT_VMCNT(4); else WAIT_VMCNT(0); }
-                else { if (ahead >= 2) WAIT_VMCNT(4); else if (ahead == 1) WAIT_VMCNT(2); else WAIT_VMCNT(0); }
+                const int ahead = t_issue - 1 - t_cons;                 // steps issued beyond the one about to be consumed (<= AHEAD - 1)
+                if (ahead >= 2) wait_vm<2 * PW>(); else if (ahead == 1) wait_vm<PW>(); else wait_vm<0>();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
             const int t_dma = t_issue < NSTEPS ? t_issue++ : -1;
             const unsigned wb = ring0 + (t_cons % RING) * SLOTB + r * 128;
             ++t_cons;
-            u32x4 a[2][NT], xb[2][2];
+            u32x4 a[2][NT], xb[2][RPW];
             auto rd = [&](int buf, int s) {                              // k-step s of this ring step: channels 64 half + 16 s ..
                 const unsigned ad = wb + ((32 * s) ^ xsw);
-                LDS_READ128(a[buf][0], ad, 0); LDS_READ128(a[buf][1], ad, 4096);
+                LDS_READ128(a[buf][0], ad, 0);
+                if (NT >= 2) LDS_READ128(a[buf][NT >= 2 ? 1 : 0], ad, 4096);
                 if (NT == 4) { LDS_READ128(a[buf][NT - 2], ad, 8192); LDS_READ128(a[buf][NT - 1], ad, 12288); }
-                const int c = 8 * half + 2 * s + h;                      // 16-B channel chunk within the 256-B pixel row
-                LDS_READ128(xb[buf][0], pix[0] + ((c ^ psw[0]) << 4), 0);
-                LDS_READ128(xb[buf][1], pix[1] + ((c ^ psw[1]) << 4), 0);
+                const int c = 8 * half + 2 * s + h;                      // 16-B channel chunk within the pixel row
+#pragma unroll
+                for (int tt = 0; tt < RPW; ++tt) LDS_READ128(xb[buf][tt], pix[tt] + ((c ^ psw[tt]) << 4), 0);
             };
             rd(0, 0);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                if (s + 1 < 4) { rd((s + 1) & 1, s + 1); if (NT == 4) LGKM_WAIT(6); else LGKM_WAIT(4); } else { LGKM_WAIT(0); }
+                if (s + 1 < 4) { rd((s + 1) & 1, s + 1); wait_lgkm<NT + RPW>(); } else { wait_lgkm<0>(); }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    Frag f, x0f, x1f; f.u = a[s & 1][nt]; x0f.u = xb[s & 1][0]; x1f.u = xb[s & 1][1];
-                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, x0f.b, acc[0][nt], 0, 0, 0);
-                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, x1f.b, acc[1][nt], 0, 0, 0);
+                    Frag f; f.u = a[s & 1][nt];
+#pragma unroll
+                    for (int tt = 0; tt < RPW; ++tt) {
+                        Frag xf; xf.u = xb[s & 1][tt];
+                        acc[tt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, xf.b, acc[tt][nt], 0, 0, 0);
+                    }
                     if (nt == 0 && t_dma >= 0 && s < PW) { __builtin_amdgcn_sched_barrier(0); dma_piece(t_dma, s); __builtin_amdgcn_sched_barrier(0); }
                 }
             }
         }
     }
 
-    // ---- epilogue: + bias, ReLU, bf16; each wave transposes its [64 pixels][COUT] tile through the idle ring (16-B chunks swizzled
-    //      by pixel & 15) and stores whole pixel rows (COUT * 2 bytes) ------------------------------------------------------------------
+    // ---- epilogue: + bias, ReLU, bf16; each wave transposes its [32 RPW pixels][COUT] tile through the idle halo region (16-B chunks
+    //      swizzled by the pixel index) and stores whole pixel rows (COUT * 2 bytes) -----------------------------------------------------
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                        // every wave is done with the ring
+    __builtin_amdgcn_s_barrier();                                        // every wave is done with the halo tile and the ring
     {
-        constexpr int ROWB = COUT * 2, CH = ROWB / 16;                   // bytes and 16-B chunks per pixel row (16 / 8)
-        unsigned char* stage = ring + wave * (64 * ROWB);               // 16 KB / 8 KB per wave: the ring is 64 KB / 32 KB
+        constexpr int ROWB = COUT * 2, CH = ROWB / 16, NPX = 32 * RPW;   // bytes / 16-B chunks per pixel row (16 / 8 / 4); pixels per wave
+        unsigned char* stage = halo + wave * (NPX * ROWB);              // <= 16 KB per wave
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+        for (int tt = 0; tt < RPW; ++tt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -164,37 +182,43 @@ __global__ __launch_bounds__(256, 1) void conv_ring_kernel(RingArgs p) {
                     *(u32x2*)(stage + px * ROWB + (((c ^ (px & (CH - 1))) << 4)) + (ch0 & 4) * 2) = o;
                 }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // wave-private tile
-        constexpr int PPI = 64 / CH;                                     // pixels per wave instruction (4 / 8)
+        constexpr int PPI = 64 / CH;                                     // pixels per wave instruction (4 / 8 / 16)
         const int q = lane % CH, psub = lane / CH;
 #pragma unroll
-        for (int it = 0; it < 64 / PPI; ++it) {
-            const int px = it * PPI + psub;                              // 0..63: row 2 wave + (px >> 5), column px & 31
+        for (int it = 0; it < NPX / PPI; ++it) {
+            const int px = it * PPI + psub;                              // row RPW wave + (px >> 5), column px & 31
             const u32x4 v = *(const u32x4*)(stage + px * ROWB + ((q ^ (px & (CH - 1))) << 4));
-            const int oy = y0 + 2 * wave + (px >> 5), ox = x0 + (px & 31);
+            const int oy = y0 + RPW * wave + (px >> 5), ox = x0 + (px & 31);
             *(u32x4*)(p.out + (((size_t)b * p.Hout + oy) * p.Wout + ox) * COUT + q * 8) = v;
         }
     }
 }
 
-template <int COUT>
+template <int CIN, int COUT, int RPW>
 int launch(const RingArgs& p, hipStream_t s) {
-    const int lds = HALO_BYTES + RING * COUT * KSTEP * 2 + COUT * 4;
+    typedef Geo<CIN, RPW> G;
+    const int lds = G::HALO_BYTES + G::RING * COUT * KSTEP * 2 + COUT * 4;
     static int attr_set = 0;
     if (attr_set < lds) {
-        (void)hipFuncSetAttribute((const void*)conv_ring_kernel<COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv_ring_kernel<CIN, COUT, RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = lds;
     }
-    hipLaunchKernelGGL((conv_ring_kernel<COUT>), dim3(p.B * (p.Hout / TH) * (p.Wout / TW)), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((conv_ring_kernel<CIN, COUT, RPW>), dim3(p.B * (p.Hout / G::TH) * (p.Wout / TW)), dim3(256), lds, s, p);
     return master_check_launch("conv_ring_bf16");
 }
 
 }  // namespace
 
-// MASTER_ERR_UNSUPPORTED outside Cin = 128, Cout in {64, 128}, Hout % 8 == 0, Wout % 32 == 0 (the caller then uses the implicit GEMM)
+// MASTER_ERR_UNSUPPORTED outside (Cin, Cout) in {(256,128), (128,128), (128,64), (64,32)} with the output a multiple of the tile
+// (4 / 8 / 8 / 16 rows x 32 columns); the caller then uses the other conv kernels
 int conv_ring_bf16(const bf16_t* x, const bf16_t* w, const float* bias, bf16_t* out, int B, int Hin, int Win, int Cin, int Cout, int up,
                    int relu, hipStream_t s) {
     const int Hout = Hin << up, Wout = Win << up;
-    if (Cin != CIN || (Cout != 64 && Cout != 128) || Hout % TH != 0 || Wout % TW != 0 || Hout < 2 || Wout < 2) return MASTER_ERR_UNSUPPORTED;
+    if (Wout % TW != 0 || Hout < 2) return MASTER_ERR_UNSUPPORTED;
     RingArgs p{x, w, bias, out, B, Hin, Win, Hout, Wout, up, relu};
-    return Cout == 128 ? launch<128>(p, s) : launch<64>(p, s);
+    if (Cin == 256 && Cout == 128 && Hout % 4 == 0) return launch<256, 128, 1>(p, s);
+    if (Cin == 128 && Cout == 128 && Hout % 8 == 0) return launch<128, 128, 2>(p, s);
+    if (Cin == 128 && Cout == 64 && Hout % 8 == 0) return launch<128, 64, 2>(p, s);
+    if (Cin == 64 && Cout == 32 && Hout % 16 == 0) return launch<64, 32, 4>(p, s);
+    return MASTER_ERR_UNSUPPORTED;
 }

@@ -48,7 +48,10 @@ def test_linear_bf16(cuda, M, N, K):
                                                           # Cin = 128: pixel-stationary ring kernel (tile 8x32), with / without upsample, Cout 128 / 64
                                                           (2, 16, 32, 128, 128, False, True, False), (1, 8, 16, 128, 128, True, True, False),
                                                           (2, 24, 64, 128, 64, False, True, False), (1, 4, 16, 128, 64, True, False, False),
-                                                          (1, 64, 64, 128, 128, False, True, False)])
+                                                          (1, 64, 64, 128, 128, False, True, False),
+                                                          # Cin = 256 (tile 4x32) and 64 -> 32 (tile 16x32) on the same kernel
+                                                          (2, 8, 32, 256, 128, False, True, False), (1, 32, 32, 256, 128, False, True, False),
+                                                          (1, 2, 16, 256, 128, True, False, False), (2, 32, 64, 64, 32, False, True, False)])
 def test_conv3x3_bf16(cuda, B, H, W, Cin, Cout, up, relu, nchw):
     from mastermetastyletransfer_amd import ops
     g = torch.Generator().manual_seed(H + Cout)
