@@ -81,14 +81,23 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
             wp[s].u = *(const u32x4*)(p.wproj + (size_t)(wave * 32 + r) * C + 8 * h + 16 * s);
         }
     }
+    // the softmax scale (head_dim^-0.5, x log2 e for exp2) is folded into Wq and bq once per workgroup instead of 32 multiplies per
+    // head and window when Q is packed
+    const float qmul = p.scale * LOG2E;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            wq[s].u[i] = pack_bf16x2(__uint_as_float(wq[s].u[i] << 16) * qmul, __uint_as_float(wq[s].u[i] & 0xffff0000u) * qmul);
     float bq[16], bk[16], bp[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int ch = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;        // channel of accumulator register e
-        bq[e] = p.bqkv[ch]; bk[e] = p.bqkv[C + ch]; bp[e] = p.bproj[ch];
+        bq[e] = p.bqkv[ch] * qmul; bk[e] = p.bqkv[C + ch]; bp[e] = p.bproj[ch];
     }
     const float bvl = p.bqkv[2 * C + wave * 32 + r];                      // V tiles have the channel on the lane
-    for (int i = tid; i < HEADS * 64 * 64; i += 256) ((float*)(lds + BIAS))[(i >> 6) * BSTR + (i & 63)] = p.bias64[i];
+    // rel-pos bias in the exp2 domain (x log2 e) once, instead of 64 multiplies per head and window
+    for (int i = tid; i < HEADS * 64 * 64; i += 256) ((float*)(lds + BIAS))[(i >> 6) * BSTR + (i & 63)] = p.bias64[i] * LOG2E;
     // the pad/roll/partition tables of every window of the geometry: the loop below then has no ordinary global load
     int32_t* srcs = (int32_t*)(lds + TABLES);
     uint8_t* regs = (uint8_t*)(srcs + cnt * 64);
@@ -201,11 +210,10 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
         f32x16 st[2][2];
         {
             Frag qf[2][2], kf[2][2];
-            const float qmul = p.scale * LOG2E;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) { qf[t][s] = pack_tile(qt[t], s, qmul); kf[t][s] = pack_tile(kt[t], s, 1.0f); }
+                for (int s = 0; s < 2; ++s) { qf[t][s] = pack_tile(qt[t], s, 1.0f); kf[t][s] = pack_tile(kt[t], s, 1.0f); }
             const float* bias = (const float*)(lds + BIAS) + wave * 64 * BSTR;
 #pragma unroll
             for (int q2 = 0; q2 < 2; ++q2) {
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 bv = *(const f32x4*)(brow + k2 * 32 + 8 * g + 4 * h);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) st[k2][q2][4 * g + e] = bv[e] * LOG2E;
+                        for (int e = 0; e < 4; ++e) st[k2][q2][4 * g + e] = bv[e];
                     }
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
