@@ -55,23 +55,38 @@ __global__ __launch_bounds__(512, 2) void window_attn_pw_kernel(PwArgs p) {
     const int nwin = p.B * p.nW;
 
     for (int i = tid; i < p.nW * 64; i += 512) { srcs[i] = p.src[i]; regs[i] = p.region ? p.region[i] : 0; }
-    // relative-position bias of this head, for this lane's two query rows and its 32 keys each, packed bf16x2 pairs
-    // (the table is trained at std 0.02; bf16 keeps 3 significant digits of it, like every other operand in this mode)
-    unsigned bpk[2][2][8];                                                // [q tile][key tile][pair]
+    // Relative-position bias of this head, added on the MATRIX CORE (this kernel is VALU-bound, its matrix cores ~7 % busy):
+    //   S^T[key][query] += sum_q' BT[key][q'] I[q'][query],   BT[key][q'] = bias[q'][key] / scale  (S stays in raw q.k units; the
+    // softmax scale and log2 e are applied once, inside the exp2 argument).  For the (key tile k2, query tile q2) accumulator only
+    // q' in tile q2 contributes: two k-steps, A = BT fragment (lane = key row, 8 consecutive q'; packed bf16, 32 VGPRs for the
+    // whole kernel, the same budget the packed table had), B = identity fragment (lane = query, one 1.0 in one of the two k-steps).
+    // The table is trained at std 0.02; bf16 keeps 3 significant digits of it, like every other operand in this mode.  Entries for
+    // tile-padding keys are -1e30 and stay a large negative bf16.
+    Frag bfr[2][2][2];                                                    // [key tile][query tile][k-step]
     {
         const float* bias = p.bias + (size_t)wave * 64 * 64;
+        const float inv_scale = 1.0f / p.scale_log2e * LOG2E;            // bias is in natural-log units: bias * log2e / (scale * log2e)
 #pragma unroll
-        for (int q2 = 0; q2 < 2; ++q2)
+        for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2)
+            for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 bv = *(const f32x4*)(bias + (q2 * 32 + r) * 64 + k2 * 32 + 8 * g + 4 * h);
-                    // entries for tile-padding keys are -1e30: keep them as a large negative bf16
-                    bpk[q2][k2][2 * g] = pack_bf16x2(bv[0] * LOG2E, bv[1] * LOG2E);
-                    bpk[q2][k2][2 * g + 1] = pack_bf16x2(bv[2] * LOG2E, bv[3] * LOG2E);
+                for (int ks = 0; ks < 2; ++ks) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = bias[(q2 * 32 + 16 * ks + 8 * h + j) * 64 + k2 * 32 + r] * inv_scale;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bfr[k2][q2][ks].u[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
                 }
     }
+    Frag idf[2];                                                          // identity: element j of k-step ks is 1 iff 16 ks + 8 h + j == r
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q0 = 16 * ks + 8 * h + 2 * j;
+            idf[ks].u[j] = (q0 == r ? 0x00003f80u : 0u) | (q0 + 1 == r ? 0x3f800000u : 0u);
+        }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -105,6 +120,7 @@ __global__ __launch_bounds__(512, 2) void window_attn_pw_kernel(PwArgs p) {
     if (win < nwin) gather(win);
 
     const int g16 = (lane >> 4) & 1, i16 = lane & 15;
+    const float mask_raw = -100.0f * LOG2E / p.scale_log2e;              // the -100 of the shift mask in raw q.k units
     Frag ones; ones.u = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // bf16 1.0 x 8
     for (; win < nwin; win += gridDim.x) {
         const int b = win / p.nW, w = win - b * p.nW;
@@ -158,10 +174,8 @@ __global__ __launch_bounds__(512, 2) void window_attn_pw_kernel(PwArgs p) {
                 for (int s = 0; s < 2; ++s)
                     st[k2][q2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[k2][s].b, qf[q2][s].b, st[k2][q2], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    st[k2][q2][2 * j] = st[k2][q2][2 * j] * p.scale_log2e + __uint_as_float(bpk[q2][k2][j] << 16);
-                    st[k2][q2][2 * j + 1] = st[k2][q2][2 * j + 1] * p.scale_log2e + __uint_as_float(bpk[q2][k2][j] & 0xffff0000u);
-                }
+                for (int ks = 0; ks < 2; ++ks)                             // + bias / scale, through the identity
+                    st[k2][q2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][q2][ks].b, idf[ks].b, st[k2][q2], 0, 0, 0);
             }
         // the shift mask only bites in windows that straddle a region boundary: when all 64 slots carry the same region id
         // (interior windows) nothing is masked and the per-element test is skipped (wave-uniform branch)
@@ -183,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void window_attn_pw_kernel(PwArgs p) {
                         const unsigned rk4 = *(const unsigned*)(reg + k2 * 32 + 8 * g + 4 * h);
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (((rk4 >> (8 * e)) & 0xffu) != rq) st[k2][q2][4 * g + e] += -100.0f * LOG2E;
+                            if (((rk4 >> (8 * e)) & 0xffu) != rq) st[k2][q2][4 * g + e] += mask_raw;
                     }
             }
         }
@@ -198,14 +212,15 @@ __global__ __launch_bounds__(512, 2) void window_attn_pw_kernel(PwArgs p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[k2][q2][e]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float nmx = -mx * p.scale_log2e;                        // scale, log2 e and the max in one fma per element
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        pf[q2][k2][s].u[j] = pack_bf16x2(__builtin_amdgcn_exp2f(st[k2][q2][8 * s + 2 * j] - mx),
-                                                         __builtin_amdgcn_exp2f(st[k2][q2][8 * s + 2 * j + 1] - mx));
+                        pf[q2][k2][s].u[j] = pack_bf16x2(__builtin_amdgcn_exp2f(fmaf(st[k2][q2][8 * s + 2 * j], p.scale_log2e, nmx)),
+                                                         __builtin_amdgcn_exp2f(fmaf(st[k2][q2][8 * s + 2 * j + 1], p.scale_log2e, nmx)));
             // denominator on the matrix core (4 % busy in this kernel) instead of ~128 VALU ops: with an all-ones A fragment every
             // row of the product holds sum_k P[k][query] of the ROUNDED probabilities (the values P.V uses), so register 0 is it
             f32x16 rs;
