@@ -3,9 +3,11 @@
 // Scale/Shift calls of the StyleEncoder :867-882).
 //
 // The one-problem-per-wave kernel (window_attn_bf16.hip) is latency-bound: every wave walks a chain of dependent
-// global loads (table -> rows -> bias) with two waves per SIMD to hide it (3 % MFMA busy).  Here a workgroup is a
-// WINDOW and stays resident: 8 waves = 8 heads, and while window i computes, the 64-slot Q / K / V(/V1) tiles of
-// window i+1 (32 KB each, all heads) are gathered by LDS-DMA with the pad/roll/partition table as per-lane source
+// global loads (table -> rows -> bias) with two waves per SIMD to hide it (3 % MFMA busy).  Here a workgroup is HALF A
+// WINDOW (4 waves = 4 of its 8 heads; two workgroups are resident per CU, so a CU still runs 8 heads at a time but is fed in
+// half-window units: 800 windows on 256 CUs then cost 3.5 window-times instead of 4) and stays resident on its head group:
+// while window i computes, the 64-slot Q / K / V(/V1) tiles of window i+1 (16 KB each, the group's 128 channels) are
+// gathered by LDS-DMA with the pad/roll/partition table as per-lane source
 // address (padded slots fetch the projection-bias row).  Per window a wave
 //   1. pulls its head's Q, K and V fragments out of LDS (16-B chunks source-swizzled by row&31: conflict-free;
 //      V through ds_read_b64_tr_b16, the hardware transpose),
@@ -23,8 +25,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int HEADS = 8, ROWB = 512;             // 8 heads x 32 ch x 2 B per token row
-constexpr int TILE = 64 * ROWB;                  // one 64-slot tile of all heads: 32 KB
+constexpr int HEADS = 8, HPW = 4;                // heads of the layer; heads (= waves) per workgroup
+constexpr int ROWB = HPW * 32 * 2;               // bytes of a workgroup's slice of a token row: 256
+constexpr int TILE = 64 * ROWB;                  // one 64-slot tile of the workgroup's heads: 16 KB
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct PwArgs {
@@ -39,7 +42,7 @@ struct PwArgs {
 union Frag { u32x4 u; bf16x8_t b; };
 
 template <bool DUAL>
-__global__ __launch_bounds__(512, 2) void window_attn_pw_kernel(PwArgs p) {
+__global__ __launch_bounds__(HPW * 64, 2) void window_attn_pw_kernel(PwArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // Q | K | V0 | (V1) tiles, then src[nW][64] i32, region[nW][64] u8
     constexpr int NT = DUAL ? 4 : 3;
     unsigned char* Qs = lds;
@@ -50,11 +53,13 @@ __global__ __launch_bounds__(512, 2) void window_attn_pw_kernel(PwArgs p) {
     uint8_t* regs = (uint8_t*)(srcs + p.nW * 64);
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // = head
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // head within the workgroup's group
     const int r = lane & 31, h = lane >> 5;
+    const int hg = blockIdx.x % (HEADS / HPW);                            // this workgroup's head group: heads hg*HPW .. +HPW-1 (its bias stays in registers)
+    const int head = hg * HPW + wave;
     const int nwin = p.B * p.nW;
 
-    for (int i = tid; i < p.nW * 64; i += 512) { srcs[i] = p.src[i]; regs[i] = p.region ? p.region[i] : 0; }
+    for (int i = tid; i < p.nW * 64; i += HPW * 64) { srcs[i] = p.src[i]; regs[i] = p.region ? p.region[i] : 0; }
     // Relative-position bias of this head, added on the MATRIX CORE (this kernel is VALU-bound, its matrix cores ~7 % busy):
     //   S^T[key][query] += sum_q' BT[key][q'] I[q'][query],   BT[key][q'] = bias[q'][key] / scale  (S stays in raw q.k units; the
     // softmax scale and log2 e are applied once, inside the exp2 argument).  For the (key tile k2, query tile q2) accumulator only
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(512, 2) void window_attn_pw_kernel(PwArgs p) {
     // tile-padding keys are -1e30 and stay a large negative bf16.
     Frag bfr[2][2][2];                                                    // [key tile][query tile][k-step]
     {
-        const float* bias = p.bias + (size_t)wave * 64 * 64;
+        const float* bias = p.bias + (size_t)head * 64 * 64;
         const float inv_scale = 1.0f / p.scale_log2e * LOG2E;            // bias is in natural-log units: bias * log2e / (scale * log2e)
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2)
@@ -90,8 +95,8 @@ __global__ __launch_bounds__(512, 2) void window_attn_pw_kernel(PwArgs p) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    // ---- LDS-DMA gather of one window: every tile = 64 rows x 512 B = 32 pieces of 1 KB (2 rows each); wave w moves
-    //      pieces 4w..4w+3 of each tile.  Position p of a row holds source chunk p ^ (row & 31). -----------------------------
+    // ---- LDS-DMA gather of one window, the channels of this workgroup's heads: every tile = 64 rows x 256 B = 16 pieces of 1 KB
+    //      (4 rows each); wave w moves pieces 4w..4w+3 of each tile.  Position p of a row holds source chunk p ^ (row & 15). ---------
     auto gather = [&](int win) __attribute__((always_inline)) {
         const int b = win / p.nW, w = win - b * p.nW;
         const int32_t* src = srcs + w * 64;
@@ -99,8 +104,8 @@ __global__ __launch_bounds__(512, 2) void window_attn_pw_kernel(PwArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int I = wave * 4 + i;
-            const int row = 2 * I + (lane >> 5);
-            const int qc = (lane & 31) ^ (row & 31);                       // source chunk (8 channels) of this lane
+            const int row = 4 * I + (lane >> 4);
+            const int qc = hg * (HPW * 4) + ((lane & 15) ^ (row & 15));    // source chunk (8 channels) of this lane within the full token row
             const int idx = row < p.N ? src[row] : -1;
             const size_t tk = tok0 + (idx < 0 ? 0 : idx);
             const bf16_t* sq = p.q + tk * p.ldq + qc * 8;                  // padded query rows are never stored: any row will do
@@ -116,13 +121,14 @@ __global__ __launch_bounds__(512, 2) void window_attn_pw_kernel(PwArgs p) {
         }
     };
 
-    int win = blockIdx.x;
+    const int wstride = gridDim.x / (HEADS / HPW);                       // workgroups serving this head group
+    int win = blockIdx.x / (HEADS / HPW);
     if (win < nwin) gather(win);
 
     const int g16 = (lane >> 4) & 1, i16 = lane & 15;
     const float mask_raw = -100.0f * LOG2E / p.scale_log2e;              // the -100 of the shift mask in raw q.k units
     Frag ones; ones.u = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // bf16 1.0 x 8
-    for (; win < nwin; win += gridDim.x) {
+    for (; win < nwin; win += wstride) {
         const int b = win / p.nW, w = win - b * p.nW;
         const int32_t* src = srcs + w * 64;
         const size_t tok0 = (size_t)b * p.T;
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void window_attn_pw_kernel(PwArgs p) {
             const int row = t * 32 + r;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const int pos = ((wave * 4 + 2 * s + h) ^ (row & 31)) << 4;   // source chunk head*4 + 2s + h
+                const int pos = ((wave * 4 + 2 * s + h) ^ (row & 15)) << 4;   // chunk wave*4 + 2s + h of the workgroup's 16 chunks
                 qf[t][s].u = *(const u32x4*)(Qs + row * ROWB + pos);
                 kf[t][s].u = *(const u32x4*)(Ks + row * ROWB + pos);
             }
@@ -154,13 +160,13 @@ __global__ __launch_bounds__(512, 2) void window_attn_pw_kernel(PwArgs p) {
                 for (int jj = 0; jj < 2; ++jj) {
                     const int row = 32 * k2 + 16 * s + 8 * jj + 4 * h + (i16 >> 2);
                     const int chunk = wave * 4 + 2 * g16 + ((i16 & 3) >> 1);
-                    const int off = row * ROWB + ((chunk ^ (row & 31)) << 4) + 8 * (i16 & 1);
+                    const int off = row * ROWB + ((chunk ^ (row & 15)) << 4) + 8 * (i16 & 1);
                     vf0[k2][s].v[jj] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(V0s + off));
                     if (DUAL) vf1[k2][s].v[jj] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(V1s + off));
                 }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                      // every head has its fragments: the tiles are free
-        if (win + gridDim.x < nwin) gather(win + gridDim.x);               // next window's rows fly under this window's math
+        if (win + wstride < nwin) gather(win + wstride);               // next window's rows fly under this window's math
 
         // ---- 2. S^T[key][query] = K Q^T, scaled, + bias + shift mask -----------------------------------------------------
         f32x16 st[2][2];
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void window_attn_pw_kernel(PwArgs p) {
                 const int slot = q2 * 32 + r;
                 const int idx = slot < p.N ? src[slot] : -1;
                 if (idx < 0) continue;
-                bf16_t* op = out + (tok0 + idx) * p.ldo + wave * 32 + 4 * h;
+                bf16_t* op = out + (tok0 + idx) * p.ldo + head * 32 + 4 * h;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     u32x2 o;
@@ -278,15 +284,16 @@ int window_attn_pw_bf16(const bf16_t* q, const bf16_t* k, const bf16_t* v0, cons
     if (lds > 160 * 1024) return MASTER_ERR_UNSUPPORTED;
     PwArgs p{q, k, v0, v1, ldq, ldk, ldv, k_pad, v0_pad, v1_pad, k_pad_bs, v_pad_bs, bias, src, region, out0, out1, ldo,
              B, T, nW, N, scale * LOG2E};
-    int grid = B * nW;
-    if (grid > 256) grid = 256;
+    // two workgroups (head groups) per window, two workgroups resident per CU: 512 slots; even grid so that both groups are served
+    int grid = B * nW * (HEADS / HPW);
+    if (grid > 512) grid = 512;
     static int attr1 = 0, attr2 = 0;
     if (v1) {
         if (attr2 < lds) { (void)hipFuncSetAttribute((const void*)window_attn_pw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr2 = lds; }
-        hipLaunchKernelGGL(window_attn_pw_kernel<true>, dim3(grid), dim3(512), lds, s, p);
+        hipLaunchKernelGGL(window_attn_pw_kernel<true>, dim3(grid), dim3(HPW * 64), lds, s, p);
     } else {
         if (attr1 < lds) { (void)hipFuncSetAttribute((const void*)window_attn_pw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr1 = lds; }
-        hipLaunchKernelGGL(window_attn_pw_kernel<false>, dim3(grid), dim3(512), lds, s, p);
+        hipLaunchKernelGGL(window_attn_pw_kernel<false>, dim3(grid), dim3(HPW * 64), lds, s, p);
     }
     return master_check_launch("window_attn_pw_bf16");
 }
