@@ -4,8 +4,6 @@ on small seeded uint8 images.  Inputs are regenerated from the seed; only sizes 
     python tests/golden/make_golden_imageio.py  ->  tests/golden/golden_imageio.npz"""
 import os
 import numpy as np
-import PIL
-from PIL import Image
 
 CASES = [(48, 64, 32, 32), (30, 20, 32, 32), (20, 24, 32, 48), (100, 77, 24, 24), (32, 50, 32, 16), (37, 32, 16, 32)]   # H, W, out_h, out_w
 
@@ -15,6 +13,8 @@ def seeded_image(i, H, W):
 
 
 if __name__ == "__main__":
+    import PIL                      # only the generator needs Pillow; the tests import CASES / seeded_image from this file
+    from PIL import Image
     out = {"pillow_version": np.array(PIL.__version__)}
     for i, (H, W, oh, ow) in enumerate(CASES):
         out[f"case{i}"] = np.asarray(Image.fromarray(seeded_image(i, H, W)).resize((ow, oh), Image.BILINEAR))
