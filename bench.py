@@ -128,7 +128,7 @@ def main():
         dist.destroy_process_group()
 
 
-PMC_KERNELS = {"mlp": ("mlp_bf16_kernel", "mlp_c128_kernel", "mlp_pc_kernel"), "linear": ("linear_ts_bf16_kernel", "gemm_bf16_kernel<128, 128, 64, 64, false>"),
+PMC_KERNELS = {"mlp": ("mlp_bf16_kernel", "mlp_c128_kernel"), "linear": ("linear_ts_bf16_kernel", "gemm_bf16_kernel<128, 128, 64, 64, false>"),
                "attn_block": ("attn_block_c128_kernel",), "window_attn": ("window_attn_pw_kernel", "window_attn_bf16_kernel"),
                "conv3x3": ("conv_ring_kernel", "conv_halo_bf16_kernel", "gemm_bf16_kernel<128, 128, 64, 64, true>", "gemm_bf16_kernel<128, 64, 64, 32, true>",
                            "gemm_bf16_kernel<256, 32, 64, 32, true>"),

@@ -371,11 +371,8 @@ int attn_block_bf16(const bf16_t* x, const float* ln_g, const float* ln_b, const
     const int R = (nW + WMAX - 1) / WMAX, wchunk = (nW + R - 1) / R;
     const int LDS_BYTES = TABLES + wchunk * 64 * 5;
     BlockArgs p{x, ln_g, ln_b, wqkv, bqkv, wproj, bproj, bias64, src, region, out, B, T, nW, N, eps, scale, wchunk, R};
-    static int attr_set = 0;
-    if (attr_set < LDS_BYTES) {
-        (void)hipFuncSetAttribute((const void*)attn_block_c128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = LDS_BYTES;
-    }
+    static LdsLimit lds_limit;
+    lds_limit.ensure((const void*)attn_block_c128_kernel, (int)(LDS_BYTES));
     int grid = B * nW;
     if (grid > 256) grid = 256;                      // persistent: one workgroup per CU walks the windows
     if (grid < R) grid = R;                          // every slice needs a workgroup

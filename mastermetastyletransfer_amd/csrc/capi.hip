@@ -49,8 +49,6 @@ int resize_plan_host(int, int, int32_t*, int32_t*, int*);
 int preprocess_launch(const uint8_t*, int, int, int, float*, int, int, const int32_t*, const int32_t*, int, const int32_t*, const int32_t*, int,
                       uint8_t*, const float*, const float*, hipStream_t);
 int postprocess_launch(const float*, uint8_t*, int, int, int, hipStream_t);
-int mlp_pc_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const float*,
-                const bf16_t*, bf16_t*, int, int, int, int, int, int, float, hipStream_t);
 int mlp_c128_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const float*,
                   const bf16_t*, bf16_t*, int, int, int, int, int, int, float, hipStream_t);
 
@@ -209,16 +207,11 @@ int master_mlp_fwd(const void* x, const float* ln_gamma, const float* ln_beta, c
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_MLP, s);
     // forms of the same kernel.  Default: the 256-token specialisation for C = 128 (mlp_c128_bf16.hip), else the one-wave-per-SIMD
-    // form (mlp_bf16.hip).  MASTER_MLP_FORM=mono forces the generic form, =pc the producer/consumer one (mlp_pc_bf16.hip).
+    // form (mlp_bf16.hip).  MASTER_MLP_FORM=mono forces the generic form.
     const char* form = getenv("MASTER_MLP_FORM");              // read per call: tests cover every form in one process
-    if (!form || (strcmp(form, "mono") && strcmp(form, "pc"))) {
+    if (!form || strcmp(form, "mono")) {
         const int rc = mlp_c128_bf16((const bf16_t*)x, ln_gamma, ln_beta, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, (const bf16_t*)res,
                                      (bf16_t*)out, M, C, HID, ldx, ldr, ldo, eps, s);
-        if (rc != MASTER_ERR_UNSUPPORTED) return rc;
-    }
-    if (form && !strcmp(form, "pc")) {
-        const int rc = mlp_pc_bf16((const bf16_t*)x, ln_gamma, ln_beta, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, (const bf16_t*)res,
-                                   (bf16_t*)out, M, C, HID, ldx, ldr, ldo, eps, s);
         if (rc != MASTER_ERR_UNSUPPORTED) return rc;
     }
     return mlp_bf16((const bf16_t*)x, ln_gamma, ln_beta, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, (const bf16_t*)res,

@@ -64,6 +64,25 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// ---- host side: per-device "raise the dynamic-LDS limit" cache --------------------------------------------------
+// hipFuncSetAttribute acts on the CURRENT device's copy of the kernel, so the cache is one atomic per device (a process may
+// drive several GPUs from several threads): no lock, at worst two threads set the same value twice.
+#include <atomic>
+struct LdsLimit {
+    static constexpr int MAX_DEV = 64;
+    std::atomic<int> bytes[MAX_DEV];
+    void ensure(const void* kernel, int need) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= MAX_DEV) { (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, need); return; }
+        if (bytes[dev].load(std::memory_order_acquire) < need) {
+            (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, need);
+            int cur = bytes[dev].load(std::memory_order_relaxed);
+            while (cur < need && !bytes[dev].compare_exchange_weak(cur, need, std::memory_order_release)) {}
+        }
+    }
+};
+
 // ---- host side: error string + profiling hooks (defined in capi.hip) -------------------------
 void master_set_error(const char* fmt, ...);
 struct ProfScope {            // brackets one launch with events when profiling is on

@@ -198,11 +198,8 @@ template <int CIN, int COUT, int RPW>
 int launch(const RingArgs& p, hipStream_t s) {
     typedef Geo<CIN, RPW> G;
     const int lds = G::HALO_BYTES + G::RING * COUT * KSTEP * 2 + COUT * 4;
-    static int attr_set = 0;
-    if (attr_set < lds) {
-        (void)hipFuncSetAttribute((const void*)conv_ring_kernel<CIN, COUT, RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = lds;
-    }
+    static LdsLimit lds_limit;
+    lds_limit.ensure((const void*)conv_ring_kernel<CIN, COUT, RPW>, (int)(lds));
     hipLaunchKernelGGL((conv_ring_kernel<CIN, COUT, RPW>), dim3(p.B * (p.Hout / G::TH) * (p.Wout / TW)), dim3(256), lds, s, p);
     return master_check_launch("conv_ring_bf16");
 }

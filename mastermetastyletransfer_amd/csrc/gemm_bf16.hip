@@ -222,12 +222,8 @@ int launch(const GemmArgsB& p, hipStream_t s) {
     const int MT = (p.M + BM - 1) / BM, NTN = (p.N + BN - 1) / BN;
     const int grid = ((MT + 7) / 8) * 8 * NTN;
     const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(bf16_t);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, WM, WN, CONV>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static LdsLimit lds_limit;
+    lds_limit.ensure((const void*)gemm_bf16_kernel<BM, BN, WM, WN, CONV>, (int)((int)lds));
     hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, CONV>), dim3(grid), dim3(NT), lds, s, p);
     return master_check_launch("gemm_bf16");
 }

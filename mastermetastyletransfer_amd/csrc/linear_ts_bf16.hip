@@ -252,11 +252,8 @@ template <int K, bool RES>
 int launch(const LinArgs& p, hipStream_t s) {
     constexpr int NW = K <= 256 ? 8 : 4;
     const size_t lds = (size_t)RING * SLOT + STAGE + (size_t)(p.N + 2 * K) * sizeof(float);
-    static size_t attr_set = 0;
-    if (attr_set < lds) {
-        (void)hipFuncSetAttribute((const void*)linear_ts_bf16_kernel<K, RES, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = lds;
-    }
+    static LdsLimit lds_limit;
+    lds_limit.ensure((const void*)linear_ts_bf16_kernel<K, RES, NW>, (int)((int)lds));
     hipLaunchKernelGGL((linear_ts_bf16_kernel<K, RES, NW>), dim3((p.M + 127) / 128), dim3(NW * 64), lds, s, p);
     return master_check_launch("linear_ts_bf16");
 }

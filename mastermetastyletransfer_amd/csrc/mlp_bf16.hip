@@ -418,11 +418,8 @@ template <int C>
 int launch(const MlpArgs& p, hipStream_t s) {
     const size_t lds = (size_t)RING * SLOT + (size_t)(p.HID + 3 * C) * sizeof(float);
     if (lds > 160 * 1024) { master_set_error("mlp: hidden width %d needs %zu B of LDS", p.HID, lds); return MASTER_ERR_UNSUPPORTED; }
-    static size_t attr_set = 0;
-    if (attr_set < lds) {
-        (void)hipFuncSetAttribute((const void*)mlp_bf16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = lds;
-    }
+    static LdsLimit lds_limit;
+    lds_limit.ensure((const void*)mlp_bf16_kernel<C>, (int)((int)lds));
     hipLaunchKernelGGL((mlp_bf16_kernel<C>), dim3((p.M + 127) / 128), dim3(256), lds, s, p);
     return master_check_launch("mlp_bf16");
 }

@@ -280,11 +280,8 @@ int mlp_c128_bf16(const bf16_t* x, const float* ln_g, const float* ln_b, const b
     const size_t lds = (size_t)RING * SLOT + (size_t)(HID + 3 * C) * sizeof(float);
     if (lds > 160 * 1024) return MASTER_ERR_UNSUPPORTED;
     M128Args p{x, ln_g, ln_b, w1, b1, w2, b2, res, out, M, HID, ldx, ldr, ldo, eps};
-    static size_t attr_set = 0;
-    if (attr_set < lds) {
-        (void)hipFuncSetAttribute((const void*)mlp_c128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = lds;
-    }
+    static LdsLimit lds_limit;
+    lds_limit.ensure((const void*)mlp_c128_kernel, (int)((int)lds));
     hipLaunchKernelGGL(mlp_c128_kernel, dim3((M + 255) / 256), dim3(256), lds, s, p);
     return master_check_launch("mlp_c128_bf16");
 }

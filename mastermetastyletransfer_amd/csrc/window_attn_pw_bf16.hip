@@ -287,12 +287,12 @@ int window_attn_pw_bf16(const bf16_t* q, const bf16_t* k, const bf16_t* v0, cons
     // two workgroups (head groups) per window, two workgroups resident per CU: 512 slots; even grid so that both groups are served
     int grid = B * nW * (HEADS / HPW);
     if (grid > 512) grid = 512;
-    static int attr1 = 0, attr2 = 0;
+    static LdsLimit lim1, lim2;
     if (v1) {
-        if (attr2 < lds) { (void)hipFuncSetAttribute((const void*)window_attn_pw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr2 = lds; }
+        lim2.ensure((const void*)window_attn_pw_kernel<true>, lds);
         hipLaunchKernelGGL(window_attn_pw_kernel<true>, dim3(grid), dim3(HPW * 64), lds, s, p);
     } else {
-        if (attr1 < lds) { (void)hipFuncSetAttribute((const void*)window_attn_pw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr1 = lds; }
+        lim1.ensure((const void*)window_attn_pw_kernel<false>, lds);
         hipLaunchKernelGGL(window_attn_pw_kernel<false>, dim3(grid), dim3(HPW * 64), lds, s, p);
     }
     return master_check_launch("window_attn_pw_bf16");

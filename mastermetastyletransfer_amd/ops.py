@@ -110,7 +110,32 @@ def _p(t: Optional[torch.Tensor]):
 
 
 def _stream():
+    # every op runs under @_on_device, so the current device is the operands' device here
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _on_device(fn):
+    """Run `fn` with the operands' GPU as the current device: the launch goes to THAT device's current stream (not device 0's)
+    and the per-device kernel attributes are set on the right device.  Operands on different GPUs are rejected."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        dev = None
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if dev is None:
+                    dev = a.device
+                elif a.device != dev:
+                    raise MasterHipError(f"{fn.__name__}: operands live on different GPUs ({dev} and {a.device})")
+        for a in kwargs.values():
+            if isinstance(a, torch.Tensor) and a.is_cuda and dev is not None and a.device != dev:
+                raise MasterHipError(f"{fn.__name__}: operands live on different GPUs ({dev} and {a.device})")
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -127,6 +152,7 @@ def _dev(*ts):
             raise MasterHipError("the stylization path runs on the GPU only (got a CPU tensor); there is no CPU fallback")
 
 
+@_on_device
 def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, r1: Optional[torch.Tensor] = None,
            r2: Optional[torch.Tensor] = None, act: int = ACT_NONE, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = r1 * act(a @ w.T + bias) + r2 ; a is [M,K] (last dim contiguous, row stride free)."""
@@ -154,6 +180,7 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     return out
 
 
+@_on_device
 def linear_ln(x: torch.Tensor, ln_gamma: torch.Tensor, ln_beta: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
               r2: Optional[torch.Tensor] = None, eps: float = 1e-5) -> torch.Tensor:
     """(LayerNorm(x) @ w.T + bias) + r2.  bf16 mode: one launch when the shape is covered; otherwise LayerNorm, then Linear."""
@@ -175,6 +202,7 @@ def mlp_fused_supported(x: torch.Tensor, hidden: int) -> bool:
     return x.dtype == torch.bfloat16 and x.shape[1] in (128, 256) and hidden % 128 == 0
 
 
+@_on_device
 def mlp(x: torch.Tensor, w1, b1, w2, b2, res: Optional[torch.Tensor] = None, ln_gamma=None, ln_beta=None,
         eps: float = 1e-5) -> torch.Tensor:
     """res + fc2(gelu(fc1(LN?(x)))) in one launch (bf16 mode)."""
@@ -185,13 +213,16 @@ def mlp(x: torch.Tensor, w1, b1, w2, b2, res: Optional[torch.Tensor] = None, ln_
     assert b1.dtype == torch.float32 and b2.dtype == torch.float32
     out = torch.empty((M, C), dtype=x.dtype, device=x.device)
     if _COUNT_ON:
-        _count("mlp", flops=4.0 * M * C * HID, bytes=x.element_size() * (M * C * (2 + (res is not None)) + 2 * C * HID))
+        # compulsory bytes: x once, out once, the weights once; a residual that IS x (every call site of the path) is not a second read
+        extra_res = res is not None and res.data_ptr() != x.data_ptr()
+        _count("mlp", flops=4.0 * M * C * HID, bytes=x.element_size() * (M * C * (2 + extra_res) + 2 * C * HID))
     _check(load_library().master_mlp_fwd(_p(x), _p(ln_gamma), _p(ln_beta), _p(w1), _p(b1), _p(w2), _p(b2), _p(res), _p(out),
                                           M, C, HID, x.stride(0), res.stride(0) if res is not None else 0, out.stride(0),
                                           eps, _dt(x), _stream()), "master_mlp_fwd")
     return out
 
 
+@_on_device
 def conv3x3_reflect(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, upsample: bool, relu: bool,
                     out_nchw: bool = False) -> torch.Tensor:
     """x NHWC [B,H,W,Cin]; w_packed [Cout,3,3,Cin]; returns NHWC, or fp32 NCHW when out_nchw."""
@@ -217,6 +248,7 @@ def attn_block_supported(x: torch.Tensor, heads: int) -> bool:
     return x.dtype == torch.bfloat16 and x.shape[1] == 128 and heads == 4 and x.is_contiguous()
 
 
+@_on_device
 def attn_block(x, ln_gamma, ln_beta, wqkv, bqkv, wproj, bproj, bias64, src, region, B: int, T: int, heads: int, nW: int, N: int,
                scale: float, eps: float = 1e-5) -> torch.Tensor:
     """x + proj(window_attention(qkv(LN?(x)))) in one launch (bf16, C = 128, 4 heads)."""
@@ -237,6 +269,7 @@ def decoder_tail_supported(x: torch.Tensor, cout_mid: int) -> bool:
     return x.dtype == torch.bfloat16 and C == 32 and cout_mid == 32 and (2 * H) % 16 == 0 and (2 * W) % 32 == 0
 
 
+@_on_device
 def decoder_tail(x: torch.Tensor, w8, b8, w9, b9) -> torch.Tensor:
     """x NHWC [B,Hs,Ws,32] bf16 -> fp32 NCHW [B,3,2Hs,2Ws]: upsample, conv 32->32 + ReLU, conv 32->3 in one launch."""
     _dev(x, w8, w9)
@@ -250,6 +283,7 @@ def decoder_tail(x: torch.Tensor, w8, b8, w9, b9) -> torch.Tensor:
     return out
 
 
+@_on_device
 def window_attn(q, k, v0, v1, k_pad, v0_pad, v1_pad, bias64, src, region, B: int, T: int, heads: int, nW: int, N: int,
                 scale: float):
     """q/k/v*: [B*T, heads*32] views (row stride free).  Returns out0 (and out1 when v1 is given), [B*T, heads*32]."""
@@ -271,6 +305,7 @@ def window_attn(q, k, v0, v1, k_pad, v0_pad, v1_pad, bias64, src, region, B: int
     return out0, out1
 
 
+@_on_device
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     _dev(x)
     M, C = x.shape
@@ -283,6 +318,7 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     return out
 
 
+@_on_device
 def instnorm(x: torch.Tensor, B: int, T: int, pad_row: Optional[torch.Tensor] = None, n_pad: int = 0, eps: float = 1e-5,
              repeat: int = 1):
     """x [B*T, C].  Returns (normalised x, normalised pad rows [B,C] or None).  repeat=2: InstanceNorm applied twice."""
@@ -298,6 +334,7 @@ def instnorm(x: torch.Tensor, B: int, T: int, pad_row: Optional[torch.Tensor] = 
     return out, pad_out
 
 
+@_on_device
 def patch_embed(img: torch.Tensor, w: torch.Tensor, bias, gamma, beta, dtype: torch.dtype, eps: float = 1e-5,
                 out: Optional[torch.Tensor] = None):
     """img fp32 NCHW [B,3,H,W] -> NHWC [B,H/4,W/4,E] with LayerNorm(E) applied (into `out` when given)."""
@@ -314,6 +351,7 @@ def patch_embed(img: torch.Tensor, w: torch.Tensor, bias, gamma, beta, dtype: to
     return out
 
 
+@_on_device
 def patch_merge_ln(x: torch.Tensor, gamma, beta, eps: float = 1e-5) -> torch.Tensor:
     _dev(x)
     B, H, W, C = x.shape
@@ -324,6 +362,7 @@ def patch_merge_ln(x: torch.Tensor, gamma, beta, eps: float = 1e-5) -> torch.Ten
     return out
 
 
+@_on_device
 def patch_merge_linear(x: torch.Tensor, gamma, beta, w: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     """torchvision PatchMerging: Linear(4C, N, no bias)(LayerNorm(2x2 gather(x))); x NHWC [B,H,W,C] -> [B*H/2*W/2, N].
     bf16 mode: one launch (gather + LN in the GEMM prologue); otherwise gather+LN, then Linear."""
@@ -342,6 +381,7 @@ def patch_merge_linear(x: torch.Tensor, gamma, beta, w: torch.Tensor, eps: float
     return linear(g.view(B * (H // 2) * (W // 2), 4 * C), w)
 
 
+@_on_device
 def image_to_nhwc(img: torch.Tensor, cpad: int, dtype: torch.dtype) -> torch.Tensor:
     """fp32 NCHW [N,3,H,W] -> dtype NHWC [N,H,W,cpad] with zero channels 3..cpad-1"""
     _dev(img)
@@ -352,6 +392,7 @@ def image_to_nhwc(img: torch.Tensor, cpad: int, dtype: torch.dtype) -> torch.Ten
     return out
 
 
+@_on_device
 def conv3x3_zero(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, relu: bool = True) -> torch.Tensor:
     """nn.Conv2d(Cin, Cout, 3, padding=1) (+ReLU) on NHWC x; w_packed = [Cout,3,3,Cin]"""
     _dev(x, w_packed)
@@ -365,6 +406,7 @@ def conv3x3_zero(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, re
     return out
 
 
+@_on_device
 def maxpool2x2(x: torch.Tensor) -> torch.Tensor:
     _dev(x)
     N, H, W, C = x.shape
@@ -373,6 +415,7 @@ def maxpool2x2(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_device
 def channel_stats(x: torch.Tensor):
     """NHWC x -> (mean [N,C], biased variance [N,C]) over the positions, fp32"""
     _dev(x)
@@ -385,6 +428,7 @@ def channel_stats(x: torch.Tensor):
     return mean, var
 
 
+@_on_device
 def instnorm_distance(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, pairs: int, pair_offset: int, squared: bool,
                       eps: float = 1e-5) -> torch.Tensor:
     """mean over pairs, channels and positions of |IN(x[i]) - IN(x[i + pair_offset])| (or its square): a 0-d fp32 tensor"""
@@ -416,6 +460,7 @@ def resize_plan(in_size: int, out_size: int, device) -> tuple:
     return hit
 
 
+@_on_device
 def preprocess(img: torch.Tensor, out_h: int, out_w: int, mean=None, std=None) -> torch.Tensor:
     """uint8 [B,H,W,3] RGB -> fp32 [B,3,out_h,out_w]: Pillow-exact bilinear resize, /255, optional (x - mean) / std"""
     import ctypes
@@ -433,6 +478,7 @@ def preprocess(img: torch.Tensor, out_h: int, out_w: int, mean=None, std=None) -
     return out
 
 
+@_on_device
 def postprocess(img: torch.Tensor) -> torch.Tensor:
     """fp32 [B,3,H,W] -> uint8 [B,H,W,3] = clip(x * 255, 0, 255) truncated"""
     _dev(img)
@@ -444,6 +490,7 @@ def postprocess(img: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_device
 def convert(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     _dev(x)
     if x.dtype == dtype:

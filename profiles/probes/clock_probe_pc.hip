@@ -8,7 +8,7 @@
 __device__ unsigned long long* g_probe = nullptr;
 void master_set_error(const char*, ...) {}
 int master_check_launch(const char*) { return hipGetLastError() == hipSuccess ? 0 : -3; }
-#include "../../mastermetastyletransfer_amd/csrc/mlp_pc_bf16.hip"
+#include "mlp_pc_bf16.hip"
 
 int main(int argc, char** argv) {
     const int C = argc > 1 ? atoi(argv[1]) : 256, HID = 4 * C, M = 32768, WGS = M / 128;

@@ -1,3 +1,4 @@
+// EXPERIMENT (not in libmaster_hip.so): measured equal-or-slower than mlp_bf16.hip in round 1; kept with its clock probe for the record.
 // Fused MLP block, bf16 throughput mode, producer/consumer form:   out = res + W2 . gelu(W1 . LN?(x) + b1) + b2
 // (same contract as mlp_bf16.hip; reference style_transformer.py:366,:392,:839-841,:865-882,:991,:1125 and the Swin blocks).
 //
@@ -22,7 +23,7 @@
 // source-swizzled so that every 16-lane group of a fragment ds_read_b128 touches 16 distinct 16-B bank slots:
 //   W1 tile: rows of C*2 bytes, position p of row r holds source chunk p ^ (r & 15)          (low four bits)
 //   W2 tile: rows of 64 bytes,  position p of row r holds source chunk p ^ ((r >> 2) & 3)
-#include "common.h"
+#include "../../mastermetastyletransfer_amd/csrc/common.h"
 
 namespace {
 
@@ -444,11 +445,8 @@ template <int C>
 int launch(const PcArgs& p, hipStream_t s) {
     const size_t lds = (size_t)RING * (32 * C * 2 + C * 64) + 4 * 6144 + (size_t)(p.HID + 3 * C) * sizeof(float);
     if (lds > 160 * 1024) return MASTER_ERR_UNSUPPORTED;
-    static size_t attr_set = 0;
-    if (attr_set < lds) {
-        (void)hipFuncSetAttribute((const void*)mlp_pc_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = lds;
-    }
+    static LdsLimit lds_limit;
+    lds_limit.ensure((const void*)mlp_pc_kernel<C>, (int)((int)lds));
     hipLaunchKernelGGL((mlp_pc_kernel<C>), dim3((p.M + 127) / 128), dim3(512), lds, s, p);
     return master_check_launch("mlp_pc_bf16");
 }
