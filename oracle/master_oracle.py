@@ -187,9 +187,38 @@ def mlp(x: Tensor, p: Dict[str, Tensor], prefix: str) -> Tensor:
 
 
 # --------------------------------------------------------------------------------------
-# StyleTransformer (eval mode: StochasticDepth is the identity)
+# StyleTransformer.  Eval mode: StochasticDepth is the identity (sd=None).  Train mode: `sd` is an
+# SDMasks object that multiplies every residual branch by the next per-sample row mask, in the order
+# the reference's modules call torchvision StochasticDepth(p, "row") (style_transformer.py:390-397,
+# :865-882, :1125): noise = bernoulli(1-p) / (1-p), one value per sample.
 # --------------------------------------------------------------------------------------
-def style_encoder(key: Tensor, scale: Tensor, shift_t: Tensor, p: Dict[str, Tensor], cfg) -> Tuple[Tensor, Tensor, Tensor]:
+class SDMasks:
+    """Explicit StochasticDepth row masks, consumed in call order (the GPU and CPU RNG streams differ, so
+    parity tests draw the masks once and hand the same list to the oracle and to the HIP path)."""
+
+    def __init__(self, masks: Sequence[Tensor]):
+        self.masks, self.i = list(masks), 0
+
+    def __call__(self, x: Tensor) -> Tensor:
+        m = self.masks[self.i]
+        self.i += 1
+        return x * m.to(x.dtype).view(-1, *([1] * (x.dim() - 1)))
+
+    @staticmethod
+    def draw(count: int, batch: int, p: float, generator=None) -> List[Tensor]:
+        """torchvision.ops.stochastic_depth row mode: noise = empty([B]).bernoulli_(1-p).div_(1-p)"""
+        keep = 1.0 - p
+        return [torch.empty(batch).bernoulli_(keep, generator=generator).div_(keep) for _ in range(count)]
+
+
+SD_CALLS_PER_LAYER = 9     # encoder: attn/MLP x (Key, Scale, Shift); decoder: self-attn, its MLP, last_MLP
+
+
+def _sd(sd: Optional["SDMasks"], x: Tensor) -> Tensor:
+    return x if sd is None else sd(x)
+
+
+def style_encoder(key: Tensor, scale: Tensor, shift_t: Tensor, p: Dict[str, Tensor], cfg, sd=None) -> Tuple[Tensor, Tensor, Tensor]:
     """StyleEncoder.forward, style_transformer.py:855-912 (both orderings)."""
     a = "encoder.shared_MHA_without_MLP.attn."
     ws, sh, nh = cfg["encoder_window_size"], cfg["encoder_shift_size"], cfg["encoder_num_heads"]
@@ -198,12 +227,12 @@ def style_encoder(key: Tensor, scale: Tensor, shift_t: Tensor, p: Dict[str, Tens
         return shifted_window_attention(q, k, v, p, a, ws, sh, nh)
 
     def do_key(key):
-        key = key + attn(key, key, key)                                # residual = input_q (:383-384)
-        return key + mlp(key, p, "encoder.encoder_MLP_Key.")
+        key = key + _sd(sd, attn(key, key, key))                       # residual = input_q (:383-384), SD :395
+        return key + _sd(sd, mlp(key, p, "encoder.encoder_MLP_Key."))  # :865
 
     def do_val(key, val, name):
-        val = val + attn(key, key, val)                                # residual = input_v (:385-386)
-        return val + mlp(val, p, f"encoder.encoder_MLP_{name}.")
+        val = val + _sd(sd, attn(key, key, val))                       # residual = input_v (:385-386)
+        return val + _sd(sd, mlp(val, p, f"encoder.encoder_MLP_{name}."))
 
     if cfg.get("encoder_if_use_processed_Key_in_Scale_and_Shift_calculation", True):
         key = do_key(key)
@@ -216,21 +245,21 @@ def style_encoder(key: Tensor, scale: Tensor, shift_t: Tensor, p: Dict[str, Tens
     return key, scale, shift_t
 
 
-def style_decoder(fcs: Tensor, key: Tensor, scale: Tensor, shift_t: Tensor, p: Dict[str, Tensor], cfg) -> Tensor:
+def style_decoder(fcs: Tensor, key: Tensor, scale: Tensor, shift_t: Tensor, p: Dict[str, Tensor], cfg, sd=None) -> Tensor:
     """StyleDecoder.forward default branch, style_transformer.py:1045-1059, :1123-1128."""
     C = fcs.shape[-1]
     ws, sh, nh = cfg["decoder_window_size"], cfg["decoder_shift_size"], cfg["decoder_num_heads"]
     b = "decoder.MHA_self_attn."
     n1 = F.layer_norm(fcs, (C,), p[b + "norm1.weight"], p[b + "norm1.bias"], EPS)
-    q = fcs + shifted_window_attention(n1, n1, n1, p, b + "attn.", ws, sh, nh)          # :390
+    q = fcs + _sd(sd, shifted_window_attention(n1, n1, n1, p, b + "attn.", ws, sh, nh))  # :390
     if not cfg.get("decoder_exclude_MLP_after_Fcs_self_MHA", False):
-        q = q + mlp(F.layer_norm(q, (C,), p[b + "norm2.weight"], p[b + "norm2.bias"], EPS), p, b + "mlp.")  # :392
+        q = q + _sd(sd, mlp(F.layer_norm(q, (C,), p[b + "norm2.weight"], p[b + "norm2.bias"], EPS), p, b + "mlp."))  # :392
     q_in = instance_norm_nhwc(q)                                                         # :1056
     key_in = instance_norm_nhwc(key)                                                     # :1057
     sigma, mu = sigma_mu_attention(q_in, key_in, scale, shift_t, p,
                                    "decoder.decoder_MHA_for_sigma_and_mu.", ws, sh, nh)  # :1059
     q = q * sigma + mu                                                                   # :1123 (un-normalised Query)
-    return q + mlp(q, p, "decoder.last_MLP.")                                            # :1125
+    return q + _sd(sd, mlp(q, p, "decoder.last_MLP."))                                   # :1125
 
 
 DEFAULT_ST_CFG = dict(
@@ -240,13 +269,13 @@ DEFAULT_ST_CFG = dict(
 )
 
 
-def style_transformer(fc: Tensor, fs: Tensor, k: int, p: Dict[str, Tensor], cfg=None) -> Tensor:
+def style_transformer(fc: Tensor, fs: Tensor, k: int, p: Dict[str, Tensor], cfg=None, sd=None) -> Tensor:
     """StyleTransformer.forward, style_transformer.py:1229-1245."""
     cfg = cfg or DEFAULT_ST_CFG
     scale = shift_t = fs
     for _ in range(k):
-        fs, scale, shift_t = style_encoder(fs, scale, shift_t, p, cfg)
-        fc = style_decoder(fc, fs, scale, shift_t, p, cfg)
+        fs, scale, shift_t = style_encoder(fs, scale, shift_t, p, cfg, sd)
+        fc = style_decoder(fc, fs, scale, shift_t, p, cfg, sd)
     return fc
 
 
