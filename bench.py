@@ -32,7 +32,7 @@ def build_model(device, dtype, window=7):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         m = MasterStyleTransferModel(style_encoder_window_size=[window, window], style_decoder_window_size=[window, window],
-                                     style_encoder_shift_size=[4, 4], style_decoder_shift_size=[4, 4])
+                                     style_encoder_shift_size=[4, 4], style_decoder_shift_size=[4, 4], allow_random_swin_encoder=True)
     # biases/rel-pos tables at the scale the reference's trainer uses (trunc-normal 0.02) instead of zeros,
     # so padded-slot rows and position biases are real data
     for n, p in m.named_parameters():

@@ -197,13 +197,130 @@ int master_postprocess_fwd(const float* img, uint8_t* out, int B, int H, int W, 
 /* Element type conversion fp32 <-> bf16 for n elements (weights at load, activations at the edges). */
 int master_convert(const void* src, void* dst, size_t n, int src_dtype, int dst_dtype, master_stream_t stream);
 
+/* ======================================================================================================================================
+ * Train step (reference train_only_inner_loop.py:519-575: train-mode forward, custom_loss, total_loss.backward(), Adam.step()).
+ * The Swin encoder and VGG-19 are frozen (:254-257, loss.py:173-175): gradients flow through the VGG convolutions (data gradient
+ * only), the image decoder and the StyleTransformer.  All entry points below are MASTER_F32 (the train step runs in the fp32 mode:
+ * exact-fp32 matrix cores); MASTER_ERR_UNSUPPORTED for bf16.  Workspaces are caller-allocated device memory; every reduction adds its
+ * partial sums in a fixed order, so gradients are bitwise reproducible.
+ * ====================================================================================================================================== */
+
+/* out = act(a . w^T + bias) like master_linear_fwd, and aux (optional, [M, ldo]) receives the PRE-activation a . w^T + bias, which the
+ * GELU backward needs (torchvision MLP fc1, style_transformer.py:366). */
+int master_linear_act_fwd(const void* a, const void* w, const void* bias, void* out, void* aux, int M, int N, int K, int lda, int ldo,
+                          int act, int dtype, master_stream_t stream);
+
+/* Data gradient of out = a . w^T:  da[M,K] = g[M,N] . w[N,K]; with gelu_pre != NULL the result is multiplied by gelu'(gelu_pre[M,K])
+ * (the backward of the GELU that produced `a`).  N % 32 == 0, K % 4 == 0. */
+int master_linear_dgrad(const void* g, const void* w, void* da, const void* gelu_pre, int M, int N, int K, int ldg, int ldda,
+                        int ld_pre, int dtype, master_stream_t stream);
+
+/* Weight gradient of out = a . w^T:  dw[N,K] = g[M,N]^T . a[M,K] (dense, row stride K).  The contraction over the M tokens is split
+ * across workgroups; ws holds the partial tiles: master_gemm_workspace_floats(N, K) floats are always enough. */
+size_t master_gemm_workspace_floats(int rows, int cols);
+int master_linear_wgrad(const void* g, const void* a, void* dw, int M, int N, int K, int ldg, int lda, void* ws, size_t ws_floats,
+                        int dtype, master_stream_t stream);
+
+/* out[n] = sum_m x[m][n]  (bias gradients).  N % 4 == 0; ws: master_colsum_workspace_floats(M, N) floats. */
+size_t master_colsum_workspace_floats(int M, int N);
+int master_colsum(const void* x, void* out, void* ws, int M, int N, int ld, int dtype, master_stream_t stream);
+
+/* out[i] = sum_{k < splits} part[k * slab + i], i < n  (fixed order).  Used to add up per-window / per-workgroup partial gradients. */
+int master_reduce_slabs(const float* part, float* out, size_t n, size_t slab, int splits, master_stream_t stream);
+
+/* nn.LayerNorm backward: dx[M,C]; dgb[2][C] = dgamma | dbeta.  ws: master_layernorm_bwd_workspace_floats(M, C) floats. */
+size_t master_layernorm_bwd_workspace_floats(int M, int C);
+int master_layernorm_bwd(const void* x, const float* gamma, const void* g, void* dx, float* dgb, float* ws, int M, int C, float eps,
+                         int dtype, master_stream_t stream);
+
+/* nn.InstanceNorm2d(affine=False) backward on a token-major map (forward: master_instnorm_fwd with repeat = 1).  With n_pad > 0 the
+ * normalised set also holds n_pad copies of pad_row_in[c]; g_pad[b,c] is the sum of the upstream gradients of those copies and
+ * dpad[b,c] receives the gradient w.r.t. pad_row_in from image b (the caller adds the images: it is a bias gradient). */
+int master_instnorm_bwd(const void* x, const void* g, const void* pad_row_in, const void* g_pad, void* dx, void* dpad, int B, int T,
+                        int C, int n_pad, float eps, int dtype, master_stream_t stream);
+
+/* Backward of master_window_attn_fwd.  Inputs as in the forward plus
+ *   pad_ord   : int32 [nW, 64]; for a zero-padded slot its ordinal among the image's n_pad padded slots, -1 otherwise;
+ *   do0, do1  : upstream gradients of out0 / out1 [B*T, *] (row stride ldo).
+ * Outputs: dq, dk, dv0, dv1 token matrices (row strides lddq/lddk/lddv; every real token row is written exactly once);
+ *   dk_pad, dv0_pad, dv1_pad : [B, n_pad, heads*32] rows of the padded slots (their K/V rows are projection biases);
+ *   dbias_ws  : [B*nW, heads, 64, 64] the dS tile of every (image, window, head); master_reduce_slabs over the B*nW slabs gives the
+ *               gradient of the [heads,64,64] bias tile (NULL: skipped). */
+int master_window_attn_bwd(const void* q, const void* k, const void* v0, const void* v1, int ldq, int ldk, int ldv, const void* k_pad,
+                           const void* v0_pad, const void* v1_pad, int k_pad_bstride, int v_pad_bstride, const float* bias,
+                           const int32_t* src, const uint8_t* region, const int32_t* pad_ord, const void* do0, const void* do1, int ldo,
+                           void* dq, void* dk, void* dv0, void* dv1, int lddq, int lddk, int lddv, void* dk_pad, void* dv0_pad,
+                           void* dv1_pad, float* dbias_ws, int B, int T, int heads, int nW, int N, int n_pad, float scale, int dtype,
+                           master_stream_t stream);
+
+/* Data gradient of a 3x3 convolution: a zero-padded correlation of g [B,H,W,Cg] with the flipped, transposed weights
+ * wf [Cx][3][3][Cg] (wf[ci][ty][tx][co] = weight[co][ci][2-ty][2-tx]).  full = 0: out [B,H,W,Cx] (zero-padded convolution: VGG-19,
+ * loss.py:23-37).  full = 1: out [B,H+2,W+2,Cx] = the gradient on the padded domain (reflect-padded decoder convolutions,
+ * decoder.py:24-54), folded back by master_fold_reflect.  Optional epilogue: out = relu_src > 0 ? acc + add : 0  (relu_src, add:
+ * [.., Cx] like out; the ReLU backward of the layer below and a gradient joining there).  Cg % 32 == 0. */
+int master_conv3x3_dgrad(const void* g, const void* wf, void* out, const void* relu_src, const void* add, int B, int H, int W, int Cg,
+                         int Cx, int full, int dtype, master_stream_t stream);
+
+/* Weight gradient of the 3x3 convolutions of master_conv3x3_reflect_fwd / master_conv3x3_zero_fwd:
+ * dw[Cout][3][3][Cin] = sum over output pixels of g[pix][Cout] (row stride ldg) x the gathered input patch (x: NHWC [B,Hin,Win,Cin],
+ * same reflect / zero padding and upsample gather as the forward).  ws: master_gemm_workspace_floats(Cout, 9*Cin). */
+int master_conv3x3_wgrad(const void* g, const void* x, void* dw, int B, int Hin, int Win, int Cin, int Cout, int ldg, int upsample,
+                         int zero_pad, void* ws, size_t ws_floats, int dtype, master_stream_t stream);
+
+/* gm[b,p,c] = (c < C and (relu_out == NULL or relu_out[b,p,c] > 0)) ? g[b,p,c] : 0 for c < Cp: ReLU backward + channel padding.
+ * g is NHWC [B,HW,C] or (g_nchw) NCHW [B,C,HW]; gm is NHWC [B,HW,Cp]. */
+int master_relu_mask(const void* g, const void* relu_out, void* gm, int B, int HW, int C, int Cp, int g_nchw, int dtype,
+                     master_stream_t stream);
+
+/* Backward of ReflectionPad(1) (+ nearest x2 upsample): dxp [B,H+2,W+2,C] (gradient on the padded H x W domain) -> out
+ * [B, H>>upsample, W>>upsample, C].  C % 4 == 0, H, W >= 2. */
+int master_fold_reflect(const void* dxp, void* out, int B, int H, int W, int C, int upsample, int dtype, master_stream_t stream);
+
+/* nn.MaxPool2d(2,2) backward fused with the ReLU backward of the layer below: y [N,H,W,C] is that layer's ReLU output (the pool's
+ * input), g [N,H/2,W/2,C]; the gradient goes to the first maximum of each 2x2 block (scan order) where y > 0. */
+int master_maxpool2x2_bwd(const void* g, const void* y, void* dx, int N, int H, int W, int C, int dtype, master_stream_t stream);
+
+/* NHWC [N,HW,Cp] -> fp32 NCHW [N,3,HW]: the image gradient out of the first (channel-padded) VGG convolution. */
+int master_nhwc_to_image(const void* g, float* out, int N, int HW, int Cp, int dtype, master_stream_t stream);
+
+/* torchvision StochasticDepth(p, "row") on a residual branch (style_transformer.py:390-397, :865-882, :1125):
+ * out[m,:] = res[m,:] + scale[m / T] * x[m,:], scale [B] = bernoulli(1-p)/(1-p); res optional.  The backward of the branch is the
+ * same call with res = NULL.  C % 4 == 0. */
+int master_rowscale_add(const void* x, const void* res, const float* scale, void* out, int B, int T, int C, int dtype,
+                        master_stream_t stream);
+
+/* Query * sigma + mu (style_transformer.py:1123) and its backward (dq = g*sigma, dsigma = g*q; dmu = g).  n % 4 == 0. */
+int master_mul_add_fwd(const void* q, const void* sigma, const void* mu, void* out, size_t n, int dtype, master_stream_t stream);
+int master_mul_add_bwd(const void* g, const void* q, const void* sigma, void* dq, void* dsigma, size_t n, int dtype,
+                       master_stream_t stream);
+
+/* Perceptual-loss tap backward (codes/loss.py:112-130, 272-322).  x: features [3B,HW,C] of [content | style | output]; mean, var
+ * [3B,C] from master_channel_stats_fwd.  dx [B,HW,C] = gradient w.r.t. the OUTPUT image's features of
+ *     wc * sum |IN(x_i) - IN(x_2B+i)| (squared: (.)^2)  +  sum_p ( coefA[i,c] + coefB[i,c] * (x_2B+i - mean) )
+ * (the second term carries the style loss through mean and std; coefficients [B,C] computed by the caller from the statistics);
+ * relu_gate: zero the result where x_2B+i <= 0.  ws: master_loss_tap_workspace_floats(B, HW, C) floats. */
+size_t master_loss_tap_workspace_floats(int B, int HW, int C);
+int master_loss_tap_bwd(const void* x, const float* mean, const float* var, const float* coefA, const float* coefB, float* ws, void* dx,
+                        int B, int HW, int C, float eps, float wc, int squared, int relu_gate, int dtype, master_stream_t stream);
+
+/* Multi-tensor optimizer steps.  table: DEVICE array of ntensors records {float* param; const float* grad; float* exp_avg;
+ * float* exp_avg_sq; int64 numel; int64 first_block} (6 x 8 bytes), first_block = running sum of ceil(numel / master_adam_chunk()),
+ * nblocks = its total.  master_adam_step: torch.optim.Adam (train_only_inner_loop.py:468-478, :575), step is 1-based.
+ * master_lerp: param += eta * (grad_slot - param) - the Reptile outer update theta += eta (omega - theta) (train.py:524-534) with
+ * omega in the grad slot. */
+int master_adam_chunk(void);
+int master_adam_step(const void* table, int ntensors, long long nblocks, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int step, master_stream_t stream);
+int master_lerp(const void* table, int ntensors, long long nblocks, float eta, master_stream_t stream);
+
 /* Lightweight per-kernel timing used by bench.py's roofline leg: when enabled, every launch is
  * bracketed by hipEvents on the launch stream.  master_prof_read() synchronises those events and
  * returns, per kernel family, the launch count and the summed milliseconds. */
 enum master_kernel_family {
     MASTER_K_LINEAR = 0, MASTER_K_CONV = 1, MASTER_K_ATTN = 2, MASTER_K_LAYERNORM = 3,
     MASTER_K_INSTNORM = 4, MASTER_K_PATCH_EMBED = 5, MASTER_K_PATCH_MERGE = 6, MASTER_K_CONVERT = 7,
-    MASTER_K_MLP = 8, MASTER_K_DECODER_TAIL = 9, MASTER_K_ATTN_BLOCK = 10, MASTER_K_COUNT = 11
+    MASTER_K_MLP = 8, MASTER_K_DECODER_TAIL = 9, MASTER_K_ATTN_BLOCK = 10, MASTER_K_CONV_DGRAD = 11, MASTER_K_CONV_WGRAD = 12,
+    MASTER_K_LINEAR_BWD = 13, MASTER_K_ATTN_BWD = 14, MASTER_K_TRAIN_MISC = 15, MASTER_K_COUNT = 16
 };
 int master_prof_enable(int on);
 int master_prof_reset(void);

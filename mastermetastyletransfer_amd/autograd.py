@@ -1,0 +1,547 @@
+"""torch.autograd.Function wrappers: HIP forward + HIP backward for every op of the train step (reference
+train_only_inner_loop.py:519-575: train-mode forward, custom_loss, total_loss.backward()).
+
+PyTorch's autograd engine only orders the calls and accumulates .grad; every forward and every backward below enqueues the
+hand-written kernels of libmaster_hip.so (include/master_hip.h, "Train step").  fp32 mode only.  Shapes: activations are token-major
+[M, C] matrices (M = B*H*W), feature maps NHWC.  What is still torch arithmetic here is index plumbing on tiny tensors: weight
+repacks ([Cout,Cin,3,3] <-> [Cout,3,3,Cin]), the [heads,64,64] bias tile gathered from the relative-position table, sums of per-image
+[B,C] partial bias gradients, and the [B,C] statistics arithmetic of the style loss.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import ops
+from .ops import F32, _check, _p, _stream, load_library
+
+F = torch.float32
+
+
+def _f32c(t: Tensor) -> Tensor:
+    if t.dtype != F:
+        raise ops.MasterHipError("the train step runs in the fp32 mode (set_compute_dtype(torch.float32))")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ws(nfloats: int, dev) -> Optional[Tensor]:
+    return torch.empty((max(int(nfloats), 4),), dtype=F, device=dev)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# raw launches (device guard: the autograd engine may call backward from another thread / with another current device)
+# ---------------------------------------------------------------------------------------------------------------------------------------
+@ops._on_device
+def linear_act_fwd(a: Tensor, w: Tensor, bias: Optional[Tensor], act: int, want_pre: bool) -> Tuple[Tensor, Optional[Tensor]]:
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=F, device=a.device)
+    pre = torch.empty_like(out) if want_pre else None
+    _check(load_library().master_linear_act_fwd(_p(a), _p(w), _p(bias), _p(out), _p(pre), M, N, K, a.stride(0), N, act, F32, _stream()),
+           "master_linear_act_fwd")
+    return out, pre
+
+
+@ops._on_device
+def linear_dgrad(g: Tensor, w: Tensor, gelu_pre: Optional[Tensor] = None) -> Tensor:
+    M, N = g.shape
+    K = w.shape[1]
+    da = torch.empty((M, K), dtype=F, device=g.device)
+    _check(load_library().master_linear_dgrad(_p(g), _p(w), _p(da), _p(gelu_pre), M, N, K, g.stride(0), K, K, F32, _stream()),
+           "master_linear_dgrad")
+    return da
+
+
+@ops._on_device
+def linear_wgrad(g: Tensor, a: Tensor) -> Tensor:
+    M, N = g.shape
+    K = a.shape[1]
+    lib = load_library()
+    dw = torch.empty((N, K), dtype=F, device=g.device)
+    nws = lib.master_gemm_workspace_floats(N, K)
+    ws = _ws(nws, g.device)
+    _check(lib.master_linear_wgrad(_p(g), _p(a), _p(dw), M, N, K, g.stride(0), a.stride(0), _p(ws), ws.numel(), F32, _stream()),
+           "master_linear_wgrad")
+    return dw
+
+
+@ops._on_device
+def colsum(x: Tensor) -> Tensor:
+    M, N = x.shape
+    lib = load_library()
+    out = torch.empty((N,), dtype=F, device=x.device)
+    ws = _ws(lib.master_colsum_workspace_floats(M, N), x.device)
+    _check(lib.master_colsum(_p(x), _p(out), _p(ws), M, N, x.stride(0), F32, _stream()), "master_colsum")
+    return out
+
+
+@ops._on_device
+def reduce_slabs(part: Tensor, n: int, splits: int) -> Tensor:
+    out = torch.empty((n,), dtype=F, device=part.device)
+    _check(load_library().master_reduce_slabs(_p(part), _p(out), n, n, splits, _stream()), "master_reduce_slabs")
+    return out
+
+
+@ops._on_device
+def layernorm_bwd(x: Tensor, gamma: Tensor, g: Tensor, eps: float) -> Tuple[Tensor, Tensor, Tensor]:
+    M, C = x.shape
+    lib = load_library()
+    dx = torch.empty_like(x)
+    dgb = torch.empty((2, C), dtype=F, device=x.device)
+    ws = _ws(lib.master_layernorm_bwd_workspace_floats(M, C), x.device)
+    _check(lib.master_layernorm_bwd(_p(x), _p(gamma), _p(g), _p(dx), _p(dgb), _p(ws), M, C, eps, F32, _stream()), "master_layernorm_bwd")
+    return dx, dgb[0], dgb[1]
+
+
+@ops._on_device
+def instnorm_bwd(x: Tensor, g: Tensor, B: int, T: int, pad_row: Optional[Tensor], g_pad: Optional[Tensor], n_pad: int, eps: float):
+    C = x.shape[1]
+    dx = torch.empty_like(x)
+    dpad = torch.empty((B, C), dtype=F, device=x.device) if n_pad > 0 else None
+    _check(load_library().master_instnorm_bwd(_p(x), _p(g), _p(pad_row), _p(g_pad), _p(dx), _p(dpad), B, T, C, n_pad, eps, F32, _stream()),
+           "master_instnorm_bwd")
+    return dx, dpad
+
+
+@ops._on_device
+def rowscale_add(x: Tensor, res: Optional[Tensor], scale: Tensor, B: int, T: int) -> Tensor:
+    out = torch.empty_like(x)
+    _check(load_library().master_rowscale_add(_p(x), _p(res), _p(scale), _p(out), B, T, x.shape[1], F32, _stream()), "master_rowscale_add")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Linear / MLP / norms / elementwise
+# ---------------------------------------------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """a [M,K] @ w[N,K]^T + bias   (nn.Linear: Wq/Wk/Wv/proj, style_transformer.py:114-116,156)"""
+
+    @staticmethod
+    def forward(ctx, a: Tensor, w: Tensor, bias: Optional[Tensor]):
+        a, w = _f32c(a), _f32c(w)
+        out, _ = linear_act_fwd(a, w, bias, ops.ACT_NONE, False)
+        ctx.save_for_backward(a, w)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        a, w = ctx.saved_tensors
+        g = _f32c(g)
+        da = linear_dgrad(g, w) if ctx.needs_input_grad[0] else None
+        dw = linear_wgrad(g, a) if ctx.needs_input_grad[1] else None
+        db = colsum(g) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return da, dw, db
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, gamma: Tensor, beta: Tensor, eps: float):
+        x = _f32c(x)
+        y = ops.layernorm(x, gamma.detach(), beta.detach(), eps)
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        x, gamma = ctx.saved_tensors
+        dx, dg, db = layernorm_bwd(x, gamma.detach(), _f32c(g), ctx.eps)
+        return dx, dg, db, None
+
+
+class MLPFn(torch.autograd.Function):
+    """fc2(gelu(fc1(LayerNorm?(x))))  - torchvision MLP (+ the block's norm2), style_transformer.py:366,:392,:839-841,:991.
+    The GELU backward is the epilogue of fc2's data-gradient GEMM (gelu'(pre) on the saved pre-activation)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, ln_g, ln_b, eps: float):
+        x, w1, w2 = _f32c(x), _f32c(w1), _f32c(w2)
+        xn = ops.layernorm(x, ln_g.detach(), ln_b.detach(), eps) if ln_g is not None else x
+        h, pre = linear_act_fwd(xn, w1, b1, ops.ACT_GELU, True)
+        y, _ = linear_act_fwd(h, w2, b2, ops.ACT_NONE, False)
+        ctx.save_for_backward(x, xn, pre, h, w1, w2, ln_g)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        x, xn, pre, h, w1, w2, ln_g = ctx.saved_tensors
+        g = _f32c(g)
+        need = ctx.needs_input_grad
+        dw2 = linear_wgrad(g, h) if need[3] else None
+        db2 = colsum(g) if need[4] else None
+        dpre = linear_dgrad(g, w2, gelu_pre=pre)                        # (g . W2) * gelu'(pre)
+        dw1 = linear_wgrad(dpre, xn) if need[1] else None
+        db1 = colsum(dpre) if need[2] else None
+        dx = dg = dbeta = None
+        if need[0] or (ln_g is not None and (need[5] or need[6])):
+            dxn = linear_dgrad(dpre, w1)
+            if ln_g is not None:
+                dx, dg, dbeta = layernorm_bwd(x, ln_g.detach(), dxn, ctx.eps)
+            else:
+                dx = dxn
+        return dx, dw1, db1, dw2, db2, dg, dbeta, None
+
+
+class InstNormFn(torch.autograd.Function):
+    """nn.InstanceNorm2d(affine=False) over the T tokens of each image (+ n_pad copies of pad_row in the statistics,
+    style_transformer.py:520-530).  Returns (y, normalised pad rows [B,C] or None)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, pad_row: Optional[Tensor], B: int, T: int, n_pad: int, eps: float):
+        x = _f32c(x)
+        pr = _f32c(pad_row) if (pad_row is not None and n_pad > 0) else None
+        y, pad_out = ops.instnorm(x, B, T, pad_row=pr.detach() if pr is not None else None, n_pad=n_pad if pr is not None else 0, eps=eps)
+        ctx.save_for_backward(x, pr)
+        ctx.dims = (B, T, n_pad if pr is not None else 0, eps)
+        return y, pad_out
+
+    @staticmethod
+    def backward(ctx, gy: Tensor, gpad: Optional[Tensor]):
+        x, pr = ctx.saved_tensors
+        B, T, n_pad, eps = ctx.dims
+        gp = _f32c(gpad) if (gpad is not None and n_pad > 0) else None
+        dx, dpad = instnorm_bwd(x, _f32c(gy), B, T, pr, gp, n_pad, eps)
+        dpr = dpad.sum(0) if (dpad is not None and ctx.needs_input_grad[1]) else None
+        return dx, dpr, None, None, None, None
+
+
+class RowScaleAddFn(torch.autograd.Function):
+    """res + scale[b] * x  -  residual add with torchvision StochasticDepth(p, "row") on the branch (style_transformer.py:390-397)"""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, res: Tensor, scale: Tensor, B: int, T: int):
+        ctx.save_for_backward(scale)
+        ctx.dims = (B, T)
+        return rowscale_add(_f32c(x), _f32c(res), scale, B, T)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (scale,) = ctx.saved_tensors
+        B, T = ctx.dims
+        g = _f32c(g)
+        dx = rowscale_add(g, None, scale, B, T) if ctx.needs_input_grad[0] else None
+        return dx, (g if ctx.needs_input_grad[1] else None), None, None, None
+
+
+class MulAddFn(torch.autograd.Function):
+    """Query * sigma + mu (style_transformer.py:1123)"""
+
+    @staticmethod
+    @ops._on_device
+    def forward(ctx, q: Tensor, sigma: Tensor, mu: Tensor):
+        q, sigma, mu = _f32c(q), _f32c(sigma), _f32c(mu)
+        out = torch.empty_like(q)
+        _check(load_library().master_mul_add_fwd(_p(q), _p(sigma), _p(mu), _p(out), q.numel(), F32, _stream()), "master_mul_add_fwd")
+        ctx.save_for_backward(q, sigma)
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        q, sigma = ctx.saved_tensors
+        g = _f32c(g)
+        dq, ds = torch.empty_like(q), torch.empty_like(q)
+        with torch.cuda.device(g.device):
+            _check(load_library().master_mul_add_bwd(_p(g), _p(q), _p(sigma), _p(dq), _p(ds), q.numel(), F32, _stream()), "master_mul_add_bwd")
+        return dq, ds, g
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# windowed attention core
+# ---------------------------------------------------------------------------------------------------------------------------------------
+class WindowAttnFn(torch.autograd.Function):
+    """master_window_attn_fwd / master_window_attn_bwd.  q, k, v0 (v1) are [M, C] column blocks of their BASE matrices tq/tk/tv0/tv1
+    at column offsets oq/ok/ov0/ov1 (a fused qkv projection is passed as the same base three times): the backward writes each gradient
+    block straight into one gradient buffer per distinct base.  k_pad / v_pad: [C] or [B,C] rows of zero-padded slots.
+    bias64: [heads,64,64] (differentiable: it is gathered from the relative-position table)."""
+
+    @staticmethod
+    def forward(ctx, tq, tk, tv0, tv1, k_pad, v0_pad, v1_pad, bias64, offs, plan, B: int, T: int, heads: int, scale: float):
+        C = heads * 32
+        oq, ok, ov0, ov1 = offs
+        bases = [_f32c(tq), _f32c(tk), _f32c(tv0), _f32c(tv1) if tv1 is not None else None]
+        q, k, v0 = bases[0][:, oq:oq + C], bases[1][:, ok:ok + C], bases[2][:, ov0:ov0 + C]
+        v1 = bases[3][:, ov1:ov1 + C] if bases[3] is not None else None
+        kp, v0p = _f32c(k_pad), _f32c(v0_pad)
+        v1p = _f32c(v1_pad) if v1 is not None else None
+        o0, o1 = ops.window_attn(q, k, v0, v1, kp.detach(), v0p.detach(), v1p.detach() if v1p is not None else None, bias64.detach(),
+                                 plan.src, plan.region, B, T, heads, plan.nW, plan.N, scale)
+        ctx.save_for_backward(bases[0], bases[1], bases[2], bases[3], kp, v0p, v1p, bias64)
+        ctx.meta = (offs, plan, B, T, heads, scale, None)
+        ctx.base_ids = [id(t) if t is not None else None for t in (tq, tk, tv0, tv1)]
+        return o0, o1
+
+    @staticmethod
+    def backward(ctx, g0: Tensor, g1: Optional[Tensor]):
+        bq, bk, bv0, bv1, kp, v0p, v1p, bias64 = ctx.saved_tensors
+        (oq, ok, ov0, ov1), plan, B, T, heads, scale, _ = ctx.meta
+        C = heads * 32
+        dev = bq.device
+        dual = bv1 is not None
+        g0 = _f32c(g0)
+        g1 = _f32c(g1) if dual else None
+        if dual and g1 is None:
+            g1 = torch.zeros_like(g0)
+        # one gradient buffer per distinct base matrix; blocks not covered by q/k/v stay zero
+        bases, offsets, ids = [bq, bk, bv0, bv1], [oq, ok, ov0, ov1], ctx.base_ids
+        bufs = {}
+        for t, i in zip(bases, ids):
+            if t is not None and i not in bufs:
+                cover = sum(C for tt, ii in zip(bases, ids) if tt is not None and ii == i)
+                bufs[i] = torch.empty_like(t) if cover == t.shape[1] else torch.zeros_like(t)
+        dq = bufs[ids[0]][:, oq:oq + C]; dk = bufs[ids[1]][:, ok:ok + C]; dv0 = bufs[ids[2]][:, ov0:ov0 + C]
+        dv1 = bufs[ids[3]][:, ov1:ov1 + C] if dual else None
+        n_pad = plan.n_pad
+        dkp = torch.empty((B, max(n_pad, 1), C), dtype=F, device=dev) if n_pad > 0 else None
+        dv0p = torch.empty_like(dkp) if n_pad > 0 else None
+        dv1p = torch.empty_like(dkp) if (n_pad > 0 and dual) else None
+        need_bias = ctx.needs_input_grad[7]
+        dbws = torch.empty((B * plan.nW, heads, 64, 64), dtype=F, device=dev) if need_bias else None
+        q, k, v0 = bq[:, oq:oq + C], bk[:, ok:ok + C], bv0[:, ov0:ov0 + C]
+        v1 = bv1[:, ov1:ov1 + C] if dual else None
+        kbs = kp.stride(0) if kp.dim() == 2 else 0
+        vbs = v0p.stride(0) if v0p.dim() == 2 else 0
+        with torch.cuda.device(dev):
+            _check(load_library().master_window_attn_bwd(
+                _p(q), _p(k), _p(v0), _p(v1), q.stride(0), k.stride(0), v0.stride(0), _p(kp), _p(v0p), _p(v1p), kbs, vbs, _p(bias64),
+                _p(plan.src), _p(plan.region), _p(plan.pad_ord), _p(g0), _p(g1), g0.stride(0), _p(dq), _p(dk), _p(dv0), _p(dv1),
+                dq.stride(0), dk.stride(0), dv0.stride(0), _p(dkp), _p(dv0p), _p(dv1p), _p(dbws), B, T, heads, plan.nW, plan.N, n_pad,
+                float(scale), F32, _stream()), "master_window_attn_bwd")
+        if dual:
+            assert dv0.stride(0) == dv1.stride(0) and v0.stride(0) == v1.stride(0)
+        # gradients per input position: a base that appears several times gets its buffer once
+        outs, seen = [], set()
+        for i in ids:
+            if i is None or i in seen:
+                outs.append(None)
+            else:
+                seen.add(i); outs.append(bufs[i])
+
+        def pad_grad(rows, like):
+            if rows is None:
+                return torch.zeros_like(like)
+            return rows.sum((0, 1)) if like.dim() == 1 else rows.sum(1)
+        gkp = pad_grad(dkp, kp) if ctx.needs_input_grad[4] else None
+        gv0p = pad_grad(dv0p, v0p) if ctx.needs_input_grad[5] else None
+        gv1p = pad_grad(dv1p, v1p) if (dual and ctx.needs_input_grad[6]) else None
+        dbias = reduce_slabs(dbws, heads * 4096, B * plan.nW).view(heads, 64, 64) if need_bias else None
+        return (outs[0], outs[1], outs[2], outs[3], gkp, gv0p, gv1p, dbias, None, None, None, None, None, None)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# decoder convolution (decoder.py:24-54): Upsample? -> ReflectionPad -> Conv3x3 -> ReLU?
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def _pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+@ops._on_device
+def conv_backward(g: Tensor, y_relu: Optional[Tensor], x: Tensor, weight: Tensor, upsample: bool, reflect: bool, g_nchw: bool,
+                  need_dx: bool, need_dw: bool, need_db: bool, dgrad_relu_src: Optional[Tensor] = None, dgrad_add: Optional[Tensor] = None,
+                  premasked: bool = False):
+    """shared by the decoder (reflect) and VGG (zero padding) convolutions.  g: gradient of the conv (+ReLU) output, NHWC or NCHW;
+    y_relu: the ReLU output (None: no ReLU or g already masked); x: the conv input NHWC [B,Hin,Win,Cin]; weight [Cout,Cin,3,3].
+    Returns (dx NHWC like x, dweight, dbias)."""
+    lib = load_library()
+    B, Hin, Win, Cin = x.shape
+    Cout = weight.shape[0]
+    up = 1 if upsample else 0
+    H, W = Hin << up, Win << up
+    Cp = _pad32(Cout)
+    dev = x.device
+    if premasked and Cp == Cout and not g_nchw:
+        gm = g
+    else:
+        gm = torch.empty((B, H, W, Cp), dtype=F, device=dev)
+        _check(lib.master_relu_mask(_p(g), _p(y_relu), _p(gm), B, H * W, Cout, Cp, int(g_nchw), F32, _stream()), "master_relu_mask")
+    db = colsum(gm.view(B * H * W, Cp))[:Cout] if need_db else None
+    dw = None
+    if need_dw:
+        dwp = torch.empty((Cp, 3, 3, Cin), dtype=F, device=dev)
+        ws = _ws(lib.master_gemm_workspace_floats(Cp, 9 * Cin), dev)
+        _check(lib.master_conv3x3_wgrad(_p(gm), _p(x), _p(dwp), B, Hin, Win, Cin, Cp, Cp, up, 0 if reflect else 1, _p(ws), ws.numel(), F32,
+                                        _stream()), "master_conv3x3_wgrad")
+        dw = dwp[:Cout].permute(0, 3, 1, 2).contiguous()                               # [Cout,3,3,Cin] -> [Cout,Cin,3,3]
+    dx = None
+    if need_dx:
+        wf = weight.detach().flip(2, 3).permute(1, 2, 3, 0)                            # [Cin][3][3][Cout], taps flipped
+        if Cp != Cout:
+            wf = torch.nn.functional.pad(wf, (0, Cp - Cout))
+        wf = wf.contiguous()
+        if reflect:
+            dxp = torch.empty((B, H + 2, W + 2, Cin), dtype=F, device=dev)
+            _check(lib.master_conv3x3_dgrad(_p(gm), _p(wf), _p(dxp), None, None, B, H, W, Cp, Cin, 1, F32, _stream()), "master_conv3x3_dgrad")
+            dx = torch.empty((B, Hin, Win, Cin), dtype=F, device=dev)
+            _check(lib.master_fold_reflect(_p(dxp), _p(dx), B, H, W, Cin, up, F32, _stream()), "master_fold_reflect")
+        else:
+            dx = torch.empty((B, H, W, Cin), dtype=F, device=dev)
+            _check(lib.master_conv3x3_dgrad(_p(gm), _p(wf), _p(dx), _p(dgrad_relu_src), _p(dgrad_add), B, H, W, Cp, Cin, 0, F32, _stream()),
+                   "master_conv3x3_dgrad")
+    return dx, dw, db
+
+
+class ConvReflectFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Tensor, upsample: bool, relu: bool, out_nchw: bool):
+        x = _f32c(x)
+        wp = weight.detach().permute(0, 2, 3, 1).contiguous()
+        y = ops.conv3x3_reflect(x, wp, bias.detach().float().contiguous(), upsample=upsample, relu=relu, out_nchw=out_nchw)
+        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.flags = (upsample, relu, out_nchw)
+        return y
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        x, weight, y = ctx.saved_tensors
+        upsample, relu, out_nchw = ctx.flags
+        dx, dw, db = conv_backward(_f32c(g), y, x, weight, upsample, True, out_nchw, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                   ctx.needs_input_grad[2])
+        return dx, dw, db, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# perceptual loss (codes/loss.py:201-262): VGG-19 features of [content | style | output] + content / style terms, one Function
+# ---------------------------------------------------------------------------------------------------------------------------------------
+VGG19_CONVS = (0, 2, 5, 7, 10, 12, 14, 16, 19, 21, 23, 25, 28)
+VGG19_POOLS = (4, 9, 18, 27)
+VGG19_TAPS = (6, 11, 20, 29)
+_CPAD = 32
+EPS_IN = 1e-5
+
+
+class PerceptualLossFn(torch.autograd.Function):
+    """(content_loss, style_loss) = f(content, style, output; frozen VGG-19 weights).  Only `output` receives a gradient.
+
+    forward: the three feature extractions as one batch of 3B (conv outputs saved for the backward), per-(image, channel) statistics,
+    IN-distance (content) and mean/std distance (style) at relu2_1/3_1/4_1/5_1.
+    backward: per tap the loss gradient w.r.t. the output image's feature map (master_loss_tap_bwd), then the VGG chain in reverse on
+    the B output images only: conv data gradients with the ReLU mask of the layer below and the next tap's gradient in the GEMM
+    epilogue, max-pool backward fused with the ReLU mask; ends in the image gradient [B,3,H,W]."""
+
+    @staticmethod
+    def forward(ctx, content, style, output, squared_c: bool, squared_s: bool, *wb):
+        weights, biases = wb[0::2], wb[1::2]
+        B = output.shape[0]
+        dev = output.device
+        x = ops.image_to_nhwc(torch.cat([content, style, output.detach()], dim=0).float(), _CPAD, F)
+        acts = {}                         # conv index -> ReLU output [3B,H,W,C]
+        taps = []
+        h = x
+        ci = 0
+        packed = []
+        for i in range(30):
+            if i in VGG19_CONVS:
+                w = weights[ci].detach().permute(0, 2, 3, 1)
+                if w.shape[3] % 32:
+                    w = torch.nn.functional.pad(w, (0, _CPAD - w.shape[3]))
+                w = w.contiguous().float()
+                packed.append(w)
+                h = ops.conv3x3_zero(h, w, biases[ci].detach().float().contiguous(), relu=True)
+                acts[i] = h
+                ci += 1
+            elif i in VGG19_POOLS:
+                h = ops.maxpool2x2(h)
+            elif i in VGG19_TAPS:
+                taps.append(h)
+        content_loss = torch.zeros((), dtype=F, device=dev)
+        style_loss = torch.zeros((), dtype=F, device=dev)
+        stats = []
+        for f in taps:
+            N, H, W, C = f.shape
+            mean, var = ops.channel_stats(f)
+            stats.append((mean, var))
+            content_loss = content_loss + ops.instnorm_distance(f, mean, var, B, 2 * B, squared_c, EPS_IN)
+            std = torch.sqrt(var * (float(H * W) / float(H * W - 1)))
+            dm, ds = mean[B:2 * B] - mean[2 * B:], std[B:2 * B] - std[2 * B:]
+            if squared_s:
+                style_loss = style_loss + torch.mean(torch.square(dm)) + torch.mean(torch.square(ds))
+            else:
+                style_loss = style_loss + torch.mean(torch.abs(dm)) + torch.mean(torch.abs(ds))
+        ctx.B, ctx.flags = B, (squared_c, squared_s)
+        ctx.x0 = x
+        ctx.acts, ctx.taps, ctx.stats = acts, taps, stats
+        ctx.weights = [w.detach() for w in weights]
+        return content_loss, style_loss
+
+    @staticmethod
+    def backward(ctx, g_content: Tensor, g_style: Tensor):
+        B = ctx.B
+        squared_c, squared_s = ctx.flags
+        lib = load_library()
+        acts, taps, stats = ctx.acts, ctx.taps, ctx.stats
+        dev = taps[0].device
+        gc = float(g_content) if g_content is not None else 0.0           # scalars: one host read each (the step ends in a sync anyway)
+        gs = float(g_style) if g_style is not None else 0.0
+        with torch.cuda.device(dev):
+            # ---- loss gradient at the four taps, for the output images [2B, 3B) ------------------------------------------------------
+            tap_grads = []
+            for t, (f, (mean, var)) in enumerate(zip(taps, stats)):
+                N, H, W, C = f.shape
+                HW = H * W
+                n1 = float(HW) / float(HW - 1)
+                std = torch.sqrt(var * n1)
+                dm, ds = mean[B:2 * B] - mean[2 * B:], std[B:2 * B] - std[2 * B:]
+                cnt = float(B * C)
+                if squared_s:
+                    dmu, dsg = -2.0 * dm / cnt, -2.0 * ds / cnt
+                else:
+                    dmu, dsg = -torch.sign(dm) / cnt, -torch.sign(ds) / cnt
+                so = std[2 * B:]
+                coefA = (gs * dmu / float(HW)).contiguous()
+                coefB = torch.where(so > 0, gs * dsg / (float(HW - 1) * so), torch.zeros_like(so)).contiguous()   # torch: std' = 0 at std = 0
+                dx = torch.empty((B, H, W, C), dtype=F, device=dev)
+                ws = _ws(lib.master_loss_tap_workspace_floats(B, HW, C), dev)
+                wc = gc / float(B * C * HW)
+                _check(lib.master_loss_tap_bwd(_p(f), _p(mean), _p(var), _p(coefA), _p(coefB), _p(ws), _p(dx), B, HW, C, EPS_IN, wc,
+                                               int(squared_c), int(t == 3), F32, _stream()), "master_loss_tap_bwd")
+                tap_grads.append(dx)
+            # ---- VGG-19 backward on the output images --------------------------------------------------------------------------------
+            # layer list: conv0 conv2 pool4 conv5[tap0] conv7 pool9 conv10[tap1] conv12 conv14 conv16 pool18 conv19[tap2] conv21 conv23
+            #             conv25 pool27 conv28[tap3].  g = gradient of conv i's ReLU output, already masked by that ReLU.
+            sl = slice(2 * B, 3 * B)
+            out_of = lambda i: acts[i][sl]
+            widx = {c: n for n, c in enumerate(VGG19_CONVS)}
+            tap_of = {5: 0, 10: 1, 19: 2}                # conv whose ReLU output is tap t (joined in the epilogue of the conv above)
+            g = tap_grads[3]                             # relu5_1 = ReLU(conv28): masked inside master_loss_tap_bwd (relu_gate)
+            order = list(VGG19_CONVS)
+            for pos in range(len(order) - 1, -1, -1):
+                i = order[pos]
+                below = order[pos - 1] if pos > 0 else None
+                x_in = None
+                pooled = (i - 1) in VGG19_POOLS
+                if below is None:
+                    relu_src, add = None, None
+                elif pooled:
+                    relu_src, add = None, None           # the pool's backward applies the ReLU mask of `below`
+                else:
+                    relu_src = out_of(below)
+                    add = tap_grads[tap_of[below]] if below in tap_of else None
+                w = ctx.weights[widx[i]]
+                if w.shape[1] % 32:                       # first conv: Cin 3 -> 32 (zero weights), like the forward
+                    w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, _CPAD - w.shape[1]))
+                Bn, H, W, Cg = g.shape
+                Cx = w.shape[1]
+                wf = w.flip(2, 3).permute(1, 2, 3, 0).contiguous()                    # [Cx][3][3][Cg]
+                dx = torch.empty((Bn, H, W, Cx), dtype=F, device=dev)
+                _check(lib.master_conv3x3_dgrad(_p(g), _p(wf), _p(dx), _p(relu_src), _p(add), Bn, H, W, Cg, Cx, 0, F32, _stream()),
+                       "master_conv3x3_dgrad")
+                g = dx
+                if pooled:
+                    y = out_of(below)                     # the pool's input = ReLU output of the conv below
+                    Np, Hp, Wp, Cpp = y.shape
+                    dpool = torch.empty_like(y)
+                    if not y.is_contiguous():
+                        y = y.contiguous()
+                    _check(lib.master_maxpool2x2_bwd(_p(g), _p(y), _p(dpool), Np, Hp, Wp, Cpp, F32, _stream()), "master_maxpool2x2_bwd")
+                    g = dpool
+                    if below in tap_of:                   # not the case for VGG-19 (taps feed convolutions directly); kept for safety
+                        g = g + tap_grads[tap_of[below]] * (y > 0)
+            Bn, H, W, Cp = g.shape
+            dimg = torch.empty((Bn, 3, H, W), dtype=F, device=dev)
+            _check(lib.master_nhwc_to_image(_p(g), _p(dimg), Bn, H * W, Cp, F32, _stream()), "master_nhwc_to_image")
+        ctx.acts = ctx.taps = ctx.stats = ctx.x0 = None
+        return (None, None, dimg, None, None) + (None,) * (2 * len(ctx.weights))

@@ -10,7 +10,35 @@
 
 // ---- kernel launchers defined in the other translation units --------------------------------
 int gemm_f32_linear(const float*, const float*, const float*, const float*, const float*, float*, int, int, int, int,
-                    int, int, int, hipStream_t);
+                    int, int, int, hipStream_t, float* aux = nullptr);
+// ---- train step (gemm_f32.hip, gemm_f32_t.hip, norms_bwd.hip, window_attn_bwd_f32.hip, train_misc.hip) ----
+int gemm_f32_conv3x3_dgrad(const float*, const float*, float*, const float*, const float*, int, int, int, int, int, int, hipStream_t);
+size_t gemm_f32_t_workspace(int, int);
+int gemm_f32_dgrad(const float*, const float*, float*, const float*, int, int, int, int, int, int, hipStream_t);
+int gemm_f32_wgrad(const float*, const float*, float*, int, int, int, int, int, float*, size_t, hipStream_t);
+int gemm_f32_conv3x3_wgrad(const float*, const float*, float*, int, int, int, int, int, int, int, int, float*, size_t, hipStream_t);
+int reduce_slabs_launch(const float*, float*, size_t, size_t, int, hipStream_t);
+int colsum_slabs(int, int);
+int colsum_launch(const float*, float*, float*, int, int, int, hipStream_t);
+int relu_mask_launch(const float*, const float*, float*, int, int, int, int, int, hipStream_t);
+int fold_reflect_launch(const float*, float*, int, int, int, int, int, hipStream_t);
+int maxpool2_bwd_launch(const float*, const float*, float*, int, int, int, int, hipStream_t);
+int nhwc_to_image_launch(const float*, float*, int, int, int, hipStream_t);
+int rowscale_add_launch(const float*, const float*, const float*, float*, int, int, int, hipStream_t);
+int mul_add_launch(const float*, const float*, const float*, float*, size_t, hipStream_t);
+int mul_add_bwd_launch(const float*, const float*, const float*, float*, float*, size_t, hipStream_t);
+int adam_chunk();
+int adam_launch(const void*, int, long long, float, float, float, float, float, int, hipStream_t);
+int lerp_launch(const void*, int, long long, float, hipStream_t);
+int loss_tap_slices(int);
+int loss_tap_bwd_launch(const float*, const float*, const float*, const float*, const float*, float*, float*, int, int, int, float, float,
+                        int, int, hipStream_t);
+int layernorm_bwd_blocks(int);
+int layernorm_bwd_launch(const float*, const float*, const float*, float*, float*, float*, int, int, float, hipStream_t);
+int instnorm_bwd_launch(const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, float, hipStream_t);
+int window_attn_bwd_f32(const float*, const float*, const float*, const float*, int, int, int, const float*, const float*, const float*, int,
+                        int, const float*, const int32_t*, const uint8_t*, const int32_t*, const float*, const float*, int, float*, float*,
+                        float*, float*, int, int, int, float*, float*, float*, float*, int, int, int, int, int, int, float, hipStream_t);
 int gemm_f32_conv3x3(const float*, const float*, const float*, float*, int, int, int, int, int, int, int, int,
                      hipStream_t, int zero_pad = 0);
 template <typename T> int image_to_nhwc_launch(const float*, void*, int, int, int, int, hipStream_t);
@@ -103,6 +131,219 @@ extern "C" {
 
 int master_version(void) { return 100; }
 const char* master_last_error_string(void) { return g_err; }
+
+// ================================================ train step ==========================================================================
+#define F32_ONLY(what) do { if (dtype != MASTER_F32) { master_set_error(what ": the train step runs in the fp32 mode"); return MASTER_ERR_UNSUPPORTED; } } while (0)
+
+int master_linear_act_fwd(const void* a, const void* w, const void* bias, void* out, void* aux, int M, int N, int K, int lda, int ldo,
+                          int act, int dtype, master_stream_t stream) {
+    F32_ONLY("linear_act_fwd");
+    REQUIRE(a && w && out, "linear_act_fwd: null operand");
+    REQUIRE(M > 0 && N > 0 && K > 0 && K % 32 == 0 && lda >= K && ldo >= N, "linear_act_fwd: bad dims M=%d N=%d K=%d", M, N, K);
+    REQUIRE(al16(a) && al16(w) && lda % 4 == 0, "linear_act_fwd: a/w must be 16-byte aligned, lda %% 4 == 0");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_LINEAR, s);
+    return gemm_f32_linear((const float*)a, (const float*)w, (const float*)bias, nullptr, nullptr, (float*)out, M, N, K, lda, ldo, 0, act, s,
+                           (float*)aux);
+}
+
+int master_linear_dgrad(const void* g, const void* w, void* da, const void* gelu_pre, int M, int N, int K, int ldg, int ldda, int ld_pre,
+                        int dtype, master_stream_t stream) {
+    F32_ONLY("linear_dgrad");
+    REQUIRE(g && w && da, "linear_dgrad: null operand");
+    REQUIRE(M > 0 && N > 0 && K > 0 && N % 32 == 0 && K % 4 == 0 && ldg >= N && ldda >= K, "linear_dgrad: bad dims M=%d N=%d K=%d", M, N, K);
+    REQUIRE(al16(g) && al16(w) && ldg % 4 == 0, "linear_dgrad: g/w must be 16-byte aligned, ldg %% 4 == 0");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_LINEAR_BWD, s);
+    return gemm_f32_dgrad((const float*)g, (const float*)w, (float*)da, (const float*)gelu_pre, M, N, K, ldg, ldda, ld_pre, s);
+}
+
+size_t master_gemm_workspace_floats(int rows, int cols) {
+    size_t n = gemm_f32_t_workspace(rows, cols);
+    const size_t cap = (size_t)32 << 20;                       // 128 MB: more splits than that buy nothing
+    return n > cap ? cap : n;
+}
+
+int master_linear_wgrad(const void* g, const void* a, void* dw, int M, int N, int K, int ldg, int lda, void* ws, size_t ws_floats, int dtype,
+                        master_stream_t stream) {
+    F32_ONLY("linear_wgrad");
+    REQUIRE(g && a && dw, "linear_wgrad: null operand");
+    REQUIRE(M > 0 && N > 0 && K > 0 && K % 4 == 0 && ldg >= N && lda >= K && lda % 4 == 0, "linear_wgrad: bad dims M=%d N=%d K=%d", M, N, K);
+    REQUIRE(al16(a) && al16(dw) && (ws == nullptr || al16(ws)), "linear_wgrad: a/dw/ws must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_LINEAR_BWD, s);
+    return gemm_f32_wgrad((const float*)g, (const float*)a, (float*)dw, M, N, K, ldg, lda, (float*)ws, ws_floats, s);
+}
+
+size_t master_colsum_workspace_floats(int M, int N) { return (size_t)colsum_slabs(M, N) * (size_t)N; }
+int master_colsum(const void* x, void* out, void* ws, int M, int N, int ld, int dtype, master_stream_t stream) {
+    F32_ONLY("colsum");
+    REQUIRE(x && out && M > 0 && N > 0 && N % 4 == 0 && ld >= N && ld % 4 == 0 && al16(x), "colsum: bad arguments (M=%d N=%d ld=%d)", M, N, ld);
+    REQUIRE(ws || colsum_slabs(M, N) == 1, "colsum: workspace required");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_TRAIN_MISC, s);
+    return colsum_launch((const float*)x, (float*)out, (float*)ws, M, N, ld, s);
+}
+
+int master_reduce_slabs(const float* part, float* out, size_t n, size_t slab, int splits, master_stream_t stream) {
+    REQUIRE(part && out && n > 0 && splits >= 1, "reduce_slabs: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_TRAIN_MISC, s);
+    return reduce_slabs_launch(part, out, n, slab, splits, s);
+}
+
+size_t master_layernorm_bwd_workspace_floats(int M, int C) { return (size_t)layernorm_bwd_blocks(M) * 2 * (size_t)C; }
+int master_layernorm_bwd(const void* x, const float* gamma, const void* g, void* dx, float* dgb, float* ws, int M, int C, float eps, int dtype,
+                         master_stream_t stream) {
+    F32_ONLY("layernorm_bwd");
+    REQUIRE(x && gamma && g && dx && dgb && ws && M > 0, "layernorm_bwd: null operand");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_LAYERNORM, s);
+    return layernorm_bwd_launch((const float*)x, gamma, (const float*)g, (float*)dx, dgb, ws, M, C, eps, s);
+}
+
+int master_instnorm_bwd(const void* x, const void* g, const void* pad_row_in, const void* g_pad, void* dx, void* dpad, int B, int T, int C,
+                        int n_pad, float eps, int dtype, master_stream_t stream) {
+    F32_ONLY("instnorm_bwd");
+    REQUIRE(x && g && dx && B > 0 && T > 0 && n_pad >= 0, "instnorm_bwd: bad arguments");
+    REQUIRE(n_pad == 0 || pad_row_in, "instnorm_bwd: n_pad > 0 needs pad_row_in");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_INSTNORM, s);
+    return instnorm_bwd_launch((const float*)x, (const float*)g, (const float*)pad_row_in, (const float*)g_pad, (float*)dx, (float*)dpad, B, T, C,
+                               n_pad, eps, s);
+}
+
+int master_window_attn_bwd(const void* q, const void* k, const void* v0, const void* v1, int ldq, int ldk, int ldv, const void* k_pad,
+                           const void* v0_pad, const void* v1_pad, int k_pad_bstride, int v_pad_bstride, const float* bias,
+                           const int32_t* src, const uint8_t* region, const int32_t* pad_ord, const void* do0, const void* do1, int ldo,
+                           void* dq, void* dk, void* dv0, void* dv1, int lddq, int lddk, int lddv, void* dk_pad, void* dv0_pad,
+                           void* dv1_pad, float* dbias_ws, int B, int T, int heads, int nW, int N, int n_pad, float scale, int dtype,
+                           master_stream_t stream) {
+    F32_ONLY("window_attn_bwd");
+    REQUIRE(q && k && v0 && bias && src && pad_ord && do0 && dq && dk && dv0, "window_attn_bwd: null operand");
+    REQUIRE((v1 == nullptr) == (do1 == nullptr) && (v1 == nullptr) == (dv1 == nullptr), "window_attn_bwd: v1, do1 and dv1 come together");
+    REQUIRE(B > 0 && T > 0 && heads > 0 && nW > 0 && N > 0 && N <= 64 && n_pad >= 0, "window_attn_bwd: bad dims");
+    REQUIRE(n_pad == 0 || (k_pad && v0_pad && dk_pad && dv0_pad && (!v1 || (v1_pad && dv1_pad))), "window_attn_bwd: padded slots need the pad rows and their gradient buffers");
+    const int C = heads * 32;
+    REQUIRE(ldq >= C && ldk >= C && ldv >= C && ldo >= C && lddq >= C && lddk >= C && lddv >= C, "window_attn_bwd: row strides < heads*32");
+    REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0 &&
+            al16(q) && al16(k) && al16(v0) && al16(do0) && al16(dq) && al16(dk) && al16(dv0), "window_attn_bwd: 16-byte alignment");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_ATTN_BWD, s);
+    return window_attn_bwd_f32((const float*)q, (const float*)k, (const float*)v0, (const float*)v1, ldq, ldk, ldv, (const float*)k_pad,
+                               (const float*)v0_pad, (const float*)v1_pad, k_pad_bstride, v_pad_bstride, bias, src, region, pad_ord,
+                               (const float*)do0, (const float*)do1, ldo, (float*)dq, (float*)dk, (float*)dv0, (float*)dv1, lddq, lddk, lddv,
+                               (float*)dk_pad, (float*)dv0_pad, (float*)dv1_pad, dbias_ws, B, T, heads, nW, N, n_pad, scale, s);
+}
+
+int master_conv3x3_dgrad(const void* g, const void* wf, void* out, const void* relu_src, const void* add, int B, int H, int W, int Cg, int Cx,
+                         int full, int dtype, master_stream_t stream) {
+    F32_ONLY("conv3x3_dgrad");
+    REQUIRE(g && wf && out, "conv3x3_dgrad: null operand");
+    REQUIRE(B > 0 && H > 0 && W > 0 && Cg > 0 && Cg % 32 == 0 && Cx > 0 && (full == 0 || full == 1), "conv3x3_dgrad: bad dims (Cg=%d)", Cg);
+    REQUIRE(al16(g) && al16(wf), "conv3x3_dgrad: g/wf must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_CONV_DGRAD, s);
+    return gemm_f32_conv3x3_dgrad((const float*)g, (const float*)wf, (float*)out, (const float*)relu_src, (const float*)add, B, H, W, Cg, Cx,
+                                  full, s);
+}
+
+int master_conv3x3_wgrad(const void* g, const void* x, void* dw, int B, int Hin, int Win, int Cin, int Cout, int ldg, int upsample,
+                         int zero_pad, void* ws, size_t ws_floats, int dtype, master_stream_t stream) {
+    F32_ONLY("conv3x3_wgrad");
+    REQUIRE(g && x && dw, "conv3x3_wgrad: null operand");
+    REQUIRE(B > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cin % 4 == 0 && Cout > 0 && ldg >= Cout && (upsample == 0 || upsample == 1),
+            "conv3x3_wgrad: bad dims");
+    REQUIRE(al16(x) && al16(dw) && (ws == nullptr || al16(ws)), "conv3x3_wgrad: x/dw/ws must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_CONV_WGRAD, s);
+    return gemm_f32_conv3x3_wgrad((const float*)g, (const float*)x, (float*)dw, B, Hin, Win, Cin, Cout, ldg, upsample, zero_pad, (float*)ws,
+                                  ws_floats, s);
+}
+
+int master_relu_mask(const void* g, const void* relu_out, void* gm, int B, int HW, int C, int Cp, int g_nchw, int dtype, master_stream_t stream) {
+    F32_ONLY("relu_mask");
+    REQUIRE(g && gm && B > 0 && HW > 0 && C > 0 && Cp >= C, "relu_mask: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_TRAIN_MISC, s);
+    return relu_mask_launch((const float*)g, (const float*)relu_out, (float*)gm, B, HW, C, Cp, g_nchw, s);
+}
+
+int master_fold_reflect(const void* dxp, void* out, int B, int H, int W, int C, int upsample, int dtype, master_stream_t stream) {
+    F32_ONLY("fold_reflect");
+    REQUIRE(dxp && out && B > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0 && (upsample == 0 || (upsample == 1 && H % 2 == 0 && W % 2 == 0)),
+            "fold_reflect: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_TRAIN_MISC, s);
+    return fold_reflect_launch((const float*)dxp, (float*)out, B, H, W, C, upsample, s);
+}
+
+int master_maxpool2x2_bwd(const void* g, const void* y, void* dx, int N, int H, int W, int C, int dtype, master_stream_t stream) {
+    F32_ONLY("maxpool2x2_bwd");
+    REQUIRE(g && y && dx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0, "maxpool2x2_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_TRAIN_MISC, s);
+    return maxpool2_bwd_launch((const float*)g, (const float*)y, (float*)dx, N, H, W, C, s);
+}
+
+int master_nhwc_to_image(const void* g, float* out, int N, int HW, int Cp, int dtype, master_stream_t stream) {
+    F32_ONLY("nhwc_to_image");
+    REQUIRE(g && out && N > 0 && HW > 0 && Cp >= 3, "nhwc_to_image: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_TRAIN_MISC, s);
+    return nhwc_to_image_launch((const float*)g, out, N, HW, Cp, s);
+}
+
+int master_rowscale_add(const void* x, const void* res, const float* scale, void* out, int B, int T, int C, int dtype, master_stream_t stream) {
+    F32_ONLY("rowscale_add");
+    REQUIRE(x && scale && out && B > 0 && T > 0 && C > 0 && C % 4 == 0 && al16(x) && al16(out) && (res == nullptr || al16(res)),
+            "rowscale_add: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_TRAIN_MISC, s);
+    return rowscale_add_launch((const float*)x, (const float*)res, scale, (float*)out, B, T, C, s);
+}
+
+int master_mul_add_fwd(const void* q, const void* sigma, const void* mu, void* out, size_t n, int dtype, master_stream_t stream) {
+    F32_ONLY("mul_add_fwd");
+    REQUIRE(q && sigma && mu && out && n > 0 && n % 4 == 0 && al16(q) && al16(sigma) && al16(mu) && al16(out), "mul_add_fwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_TRAIN_MISC, s);
+    return mul_add_launch((const float*)q, (const float*)sigma, (const float*)mu, (float*)out, n, s);
+}
+int master_mul_add_bwd(const void* g, const void* q, const void* sigma, void* dq, void* dsigma, size_t n, int dtype, master_stream_t stream) {
+    F32_ONLY("mul_add_bwd");
+    REQUIRE(g && q && sigma && dq && dsigma && n > 0 && n % 4 == 0 && al16(g) && al16(q) && al16(sigma) && al16(dq) && al16(dsigma),
+            "mul_add_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_TRAIN_MISC, s);
+    return mul_add_bwd_launch((const float*)g, (const float*)q, (const float*)sigma, (float*)dq, (float*)dsigma, n, s);
+}
+
+size_t master_loss_tap_workspace_floats(int B, int HW, int C) { return (size_t)B * (size_t)(loss_tap_slices(HW) + 1) * 2 * (size_t)C; }
+int master_loss_tap_bwd(const void* x, const float* mean, const float* var, const float* coefA, const float* coefB, float* ws, void* dx, int B,
+                        int HW, int C, float eps, float wc, int squared, int relu_gate, int dtype, master_stream_t stream) {
+    F32_ONLY("loss_tap_bwd");
+    REQUIRE(x && mean && var && coefA && coefB && ws && dx && B > 0 && HW > 0, "loss_tap_bwd: null operand");
+    REQUIRE(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0, "loss_tap_bwd: C/4 must divide 256 (C=%d)", C);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_TRAIN_MISC, s);
+    return loss_tap_bwd_launch((const float*)x, mean, var, coefA, coefB, ws, (float*)dx, B, HW, C, eps, wc, squared, relu_gate, s);
+}
+
+int master_adam_chunk(void) { return adam_chunk(); }
+int master_adam_step(const void* table, int ntensors, long long nblocks, float lr, float beta1, float beta2, float eps, float weight_decay,
+                     int step, master_stream_t stream) {
+    REQUIRE(table && ntensors > 0 && nblocks > 0 && nblocks < 0x7fffffffLL && step >= 1, "adam_step: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_TRAIN_MISC, s);
+    return adam_launch(table, ntensors, nblocks, lr, beta1, beta2, eps, weight_decay, step, s);
+}
+int master_lerp(const void* table, int ntensors, long long nblocks, float eta, master_stream_t stream) {
+    REQUIRE(table && ntensors > 0 && nblocks > 0 && nblocks < 0x7fffffffLL, "lerp: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_TRAIN_MISC, s);
+    return lerp_launch(table, ntensors, nblocks, eta, s);
+}
 
 int master_prof_enable(int on) { prof_drain(); g_prof_on = on != 0; return MASTER_OK; }
 int master_prof_reset(void) {

@@ -22,6 +22,11 @@ struct GemmArgs {
     const float* a; const float* w; const float* bias; const float* r1; const float* r2; float* out;
     int M, N, K, lda, ldo, ldr, act;
     int Hin, Win, Cin, Hout, Wout, up, out_nchw, zero_pad;   // conv gather only (zero_pad: out-of-image taps read 0 instead of the mirror pixel)
+    // training extras.  aux: the pre-activation acc + bias is also stored there (same layout as out; saved for the GELU backward).
+    // off = 1 (zero_pad only): "full" correlation - the output domain is (Hsrc+2) x (Wsrc+2) and output pixel (y, x) reads source
+    // pixels (y - 2 + ty, x - 2 + tx): the data-gradient of a padded 3x3 convolution on the padded domain.
+    // mask_relu: r1 is not a multiplier but a ReLU output whose sign gates the result:  out = r1 > 0 ? acc + r2 : 0
+    float* aux; int off, mask_relu;
 };
 
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
@@ -85,11 +90,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(Ge
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
 #pragma unroll
             for (int i = 0; i < ACH; ++i) {
-                const int yy = cy[i] + dy, xx = cx[i] + dx;
-                int sy = reflect1(yy, p.Hout) >> p.up;
-                int sx = reflect1(xx, p.Wout) >> p.up;
+                const int yy = cy[i] + dy - p.off, xx = cx[i] + dx - p.off;
+                const int Hs = p.Hin << p.up, Ws = p.Win << p.up;            // source domain (= output domain unless off)
+                int sy = reflect1(yy, Hs) >> p.up;
+                int sx = reflect1(xx, Ws) >> p.up;
+                if (p.zero_pad) {                                            // clamp: the value is discarded below
+                    sy = sy < 0 ? 0 : (sy >= p.Hin ? p.Hin - 1 : sy);
+                    sx = sx < 0 ? 0 : (sx >= p.Win ? p.Win - 1 : sx);
+                }
                 a_st[i] = *(const f32x4*)(p.a + ((size_t)(cb[i] * p.Hin + sy) * p.Win + sx) * p.Cin + c0);
-                if (p.zero_pad && ((unsigned)yy >= (unsigned)p.Hout || (unsigned)xx >= (unsigned)p.Wout)) a_st[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.zero_pad && ((unsigned)yy >= (unsigned)Hs || (unsigned)xx >= (unsigned)Ws)) a_st[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         } else {
 #pragma unroll
@@ -158,10 +168,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(Ge
                 const int m = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m >= p.M) continue;
                 float v = acc[i][jn][e] + bv;
+                if (p.aux) p.aux[(size_t)m * p.ldo + n] = v;
                 if (p.act == MASTER_ACT_GELU) v = gelu_erf(v);
                 else if (p.act == MASTER_ACT_RELU) v = fmaxf(v, 0.0f);
-                if (p.r1) v *= p.r1[(size_t)m * p.ldr + n];
-                if (p.r2) v += p.r2[(size_t)m * p.ldr + n];
+                if (p.mask_relu) {
+                    if (p.r2) v += p.r2[(size_t)m * p.ldr + n];
+                    if (!(p.r1[(size_t)m * p.ldr + n] > 0.0f)) v = 0.0f;
+                } else {
+                    if (p.r1) v *= p.r1[(size_t)m * p.ldr + n];
+                    if (p.r2) v += p.r2[(size_t)m * p.ldr + n];
+                }
                 if (CONV && p.out_nchw) {
                     const int b = m / hw_out, pix = m - b * hw_out;
                     p.out[((size_t)b * p.N + n) * hw_out + pix] = v;
@@ -195,8 +211,8 @@ int dispatch(const GemmArgs& p, hipStream_t s) {
 }  // namespace
 
 int gemm_f32_linear(const float* a, const float* w, const float* bias, const float* r1, const float* r2, float* out,
-                    int M, int N, int K, int lda, int ldo, int ldr, int act, hipStream_t s) {
-    GemmArgs p{a, w, bias, r1, r2, out, M, N, K, lda, ldo, ldr, act, 0, 0, 0, 1, 1, 0, 0, 0};
+                    int M, int N, int K, int lda, int ldo, int ldr, int act, hipStream_t s, float* aux = nullptr) {
+    GemmArgs p{a, w, bias, r1, r2, out, M, N, K, lda, ldo, ldr, act, 0, 0, 0, 1, 1, 0, 0, 0, aux, 0, 0};
     return dispatch<false>(p, s);
 }
 
@@ -204,6 +220,18 @@ int gemm_f32_conv3x3(const float* x, const float* w, const float* bias, float* o
                      int Cout, int up, int relu, int out_nchw, hipStream_t s, int zero_pad = 0) {
     const int Hout = Hin << up, Wout = Win << up;
     GemmArgs p{x, w, bias, nullptr, nullptr, out, B * Hout * Wout, Cout, 9 * Cin, 0, Cout, 0,
-               relu ? MASTER_ACT_RELU : MASTER_ACT_NONE, Hin, Win, Cin, Hout, Wout, up, out_nchw, zero_pad};
+               relu ? MASTER_ACT_RELU : MASTER_ACT_NONE, Hin, Win, Cin, Hout, Wout, up, out_nchw, zero_pad, nullptr, 0, 0};
+    return dispatch<true>(p, s);
+}
+
+// Data gradient of a 3x3 convolution as a zero-padded 3x3 correlation of the output gradient g [B,H,W,Cg] with the flipped,
+// transposed weights wf [Cx][3][3][Cg]:  full = 0: out [B,H,W,Cx] (the convolution had zero padding: VGG);  full = 1: out
+// [B,H+2,W+2,Cx] = the gradient on the padded domain (reflect-padded decoder convolutions; folded back by fold_reflect).
+// Optional epilogue  out = relu_src > 0 ? acc + add : 0  (the ReLU backward of the layer below and a tap gradient joining there).
+int gemm_f32_conv3x3_dgrad(const float* g, const float* wf, float* out, const float* relu_src, const float* add, int B, int H,
+                           int W, int Cg, int Cx, int full, hipStream_t s) {
+    const int Ho = H + 2 * full, Wo = W + 2 * full;
+    GemmArgs p{g, wf, nullptr, relu_src, add, out, B * Ho * Wo, Cx, 9 * Cg, 0, Cx, Cx, MASTER_ACT_NONE, H, W, Cg, Ho, Wo, 0, 0, 1,
+               nullptr, full, relu_src != nullptr};
     return dispatch<true>(p, s);
 }

@@ -1,0 +1,290 @@
+// fp32 GEMMs of the backward pass on the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32): operands that are NOT contraction-contiguous.
+//
+//   data gradient of a Linear    dX[M,K'] = G[M,N'] . W[N',K']          A = G  row-major (contraction contiguous), B = W  [contraction][n]
+//   weight gradient of a Linear  dW[N',K'] = G[M,N']^T . X[M,K']        A = G  [contraction][m],                   B = X  [contraction][n]
+//   weight gradient of a 3x3 conv dW[Cout][tap][Cin] = sum_pixels G[pix][Cout] . gather(X)[pix][tap][Cin]          B = implicit gather
+//
+// (the forward kernel gemm_f32.hip has both operands contraction-contiguous.)  A contraction-major operand is staged the way it lies in
+// memory - 16-byte loads along m (or n), LDS tile [32 k][BM + 4] - and its MFMA fragments are single-float LDS reads with the lane on
+// m: 32 consecutive words per half-wave, conflict-free.  MFMA k-step s pairs contraction index s (lanes 0-31) with 16 + s (lanes 32-63),
+// the pairing of gemm_f32.hip, so a row-major A keeps its ds_read_b128 path.
+//
+// Weight gradients contract over all tokens / pixels of the batch (8 192 ... 524 288) into a small output, so the contraction is split
+// over blockIdx.y: every split writes its partial tile to a workspace slab and splitk_reduce_kernel adds the slabs in a fixed order
+// (deterministic, no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = 36;     // row-major A: padded LDS row (floats)
+constexpr int PADT = 4;     // contraction-major tiles: row = BM + PADT floats
+
+struct TArgs {
+    const float* a; const float* w; float* out;
+    int M, N, K;                 // out is [M][N]; K = contraction length
+    int lda, ldw, ldo;
+    int chunks_per_split;        // BK-chunks per blockIdx.y
+    size_t slab;                 // elements between split slabs of `out` (0: one split, final result)
+    // epilogue of the data-gradient form (one split only):  out *= gelu'(aux)   (aux = pre-activation of the layer below)
+    const float* aux; int ld_aux;
+    // conv weight gradient: w = x NHWC [B,Hin,Win,Cin]; contraction index = output pixel of the Hout x Wout map; column n = tap*Cin + ci
+    int Hin, Win, Cin, Hout, Wout, up, zero_pad;
+};
+
+__device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+__device__ __forceinline__ float gelu_grad(float x) {
+    // d/dx [ x Phi(x) ] = Phi(x) + x phi(x)
+    const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f));
+    const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.5f * x * x * 1.4426950408889634f);
+    return fmaf(x, pdf, cdf);
+}
+
+template <int BM, int BN, int WM, int WN, bool AT, bool GATHER>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_t_kernel(TArgs p) {
+    constexpr int NWN = BN / WN;
+    constexpr int NT = (BM / WM) * NWN * 64;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int LDA_T = BM + PADT, LDW_T = BN + PADT;
+    constexpr int A_ELEMS = AT ? BK * LDA_T : BM * LDK;
+    constexpr int W_ELEMS = BK * LDW_T;
+    constexpr int ACH = AT ? (BK * BM / 4 + NT - 1) / NT : BM * 8 / NT;     // 16-byte chunks per thread and stage
+    constexpr int WCH = (BK * BN / 4 + NT - 1) / NT;
+    static_assert(AT || (BM * 8) % NT == 0, "A chunks must divide evenly");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                       // [2][A_ELEMS]
+    float* Ws = smem + 2 * A_ELEMS;         // [2][W_ELEMS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave / NWN) * WM, wn = (wave % NWN) * WN;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int NTN = (p.N + BN - 1) / BN;
+    const int mt = blockIdx.x / NTN, nt = blockIdx.x % NTN;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int kt0 = blockIdx.y * p.chunks_per_split;
+    int kt1 = kt0 + p.chunks_per_split; if (kt1 > nk_all) kt1 = nk_all;
+    float* outp = p.out + (size_t)blockIdx.y * p.slab;
+
+    const bool a_vec = (p.lda & 3) == 0 && (((uintptr_t)p.a) & 15) == 0;      // else scalar loads (e.g. a 3-channel gradient)
+
+    // ---- W^T gather descriptors (conv weight gradient): column group -> (tap, ci) is fixed per thread and chunk slot ----------------
+    int g_dy[WCH], g_dx[WCH], g_ci[WCH];
+    if (GATHER) {
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int c = tid + i * NT;
+            int n = n0 + (c % (BN / 4)) * 4;
+            if (n >= p.N) n = 0;
+            const int tap = n / p.Cin;
+            g_ci[i] = n - tap * p.Cin; g_dy[i] = tap / 3 - 1; g_dx[i] = tap % 3 - 1;
+        }
+    }
+
+    f32x4 a_st[ACH], w_st[WCH];
+    auto stage_load = [&](int kt) {
+        const int k0 = kt * BK;
+        if (AT) {
+#pragma unroll
+            for (int i = 0; i < ACH; ++i) {
+                const int c = tid + i * NT;
+                const int kr = c / (BM / 4), m = m0 + (c % (BM / 4)) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (c < BK * BM / 4 && k0 + kr < p.K) {
+                    const float* src = p.a + (size_t)(k0 + kr) * p.lda + m;
+                    if (a_vec && m + 3 < p.M) v = *(const f32x4*)src;
+                    else
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (m + e < p.M) v[e] = src[e];
+                }
+                a_st[i] = v;
+            }
+        } else {
+            const int kc = (tid & 7) * 4;
+#pragma unroll
+            for (int i = 0; i < ACH; ++i) {
+                int m = m0 + (tid >> 3) + i * (NT / 8);
+                m = m < p.M ? m : p.M - 1;
+                a_st[i] = *(const f32x4*)(p.a + (size_t)m * p.lda + k0 + kc);        // K % 32 == 0 in this form
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int c = tid + i * NT;
+            const int kr = c / (BN / 4), n = n0 + (c % (BN / 4)) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (c < BK * BN / 4 && k0 + kr < p.K && n < p.N) {             // N % 4 == 0 (checked by the launcher)
+                if (GATHER) {
+                    const int pix = k0 + kr, hw = p.Hout * p.Wout;
+                    const int b = pix / hw, rem = pix - b * hw, y = rem / p.Wout, x = rem - y * p.Wout;
+                    const int yy = y + g_dy[i], xx = x + g_dx[i];
+                    const bool inside = (unsigned)yy < (unsigned)p.Hout && (unsigned)xx < (unsigned)p.Wout;
+                    if (inside || !p.zero_pad) {
+                        const int sy = reflect1(yy, p.Hout) >> p.up, sx = reflect1(xx, p.Wout) >> p.up;
+                        v = *(const f32x4*)(p.w + ((size_t)(b * p.Hin + sy) * p.Win + sx) * p.Cin + g_ci[i]);
+                    }
+                } else {
+                    v = *(const f32x4*)(p.w + (size_t)(k0 + kr) * p.ldw + n);
+                }
+            }
+            w_st[i] = v;
+        }
+    };
+    auto stage_store = [&](int buf) {
+        if (AT) {
+#pragma unroll
+            for (int i = 0; i < ACH; ++i) {
+                const int c = tid + i * NT;
+                if (c < BK * BM / 4) *(f32x4*)(As + buf * A_ELEMS + (c / (BM / 4)) * LDA_T + (c % (BM / 4)) * 4) = a_st[i];
+            }
+        } else {
+            const int kc = (tid & 7) * 4;
+#pragma unroll
+            for (int i = 0; i < ACH; ++i) *(f32x4*)(As + buf * A_ELEMS + ((tid >> 3) + i * (NT / 8)) * LDK + kc) = a_st[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int c = tid + i * NT;
+            if (c < BK * BN / 4) *(f32x4*)(Ws + buf * W_ELEMS + (c / (BN / 4)) * LDW_T + (c % (BN / 4)) * 4) = w_st[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.0f;
+
+    if (kt0 < kt1) {
+        stage_load(kt0);
+        stage_store(0);
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int buf = (kt - kt0) & 1;
+            if (kt + 1 < kt1) stage_load(kt + 1);
+            const float* ab = As + buf * A_ELEMS;
+            const float* wb = Ws + buf * W_ELEMS;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 av[TM];
+                if (!AT) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) av[i] = *(const f32x4*)(ab + (wm + i * 32 + r) * LDK + 16 * h + 4 * q);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kk = 16 * h + 4 * q + e;
+                    float a1[TM], w1[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a1[i] = AT ? ab[kk * LDA_T + wm + i * 32 + r] : av[i][e];
+#pragma unroll
+                    for (int jn = 0; jn < TN; ++jn) w1[jn] = wb[kk * LDW_T + wn + jn * 32 + r];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int jn = 0; jn < TN; ++jn)
+                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], w1[jn], acc[i][jn], 0, 0, 0);
+                }
+            }
+            if (kt + 1 < kt1) stage_store(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ------------------------------------------------
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int n = n0 + wn + jn * 32 + r;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m >= p.M) continue;
+                float v = acc[i][jn][e];
+                if (p.aux) v *= gelu_grad(p.aux[(size_t)m * p.ld_aux + n]);
+                outp[(size_t)m * p.ldo + n] = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n4,
+                                                            size_t slab, int splits) {
+    // n4 = element count / 4; slabs are 16-byte aligned
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 s = *(const f32x4*)(part + 4 * i);
+        for (int k = 1; k < splits; ++k) s += *(const f32x4*)(part + (size_t)k * slab + 4 * i);
+        *(f32x4*)(out + 4 * i) = s;
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool AT, bool GATHER>
+int launch_t(TArgs p, float* final_out, float* ws, size_t ws_floats, int want_splits, hipStream_t s) {
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    constexpr int A_ELEMS = AT ? BK * (BM + PADT) : BM * LDK;
+    constexpr int W_ELEMS = BK * (BN + PADT);
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const int nk = (p.K + BK - 1) / BK;
+    int splits = want_splits;
+    if (splits <= 0) {                                       // fill >= 2 waves of workgroups per CU
+        splits = (1024 + tiles - 1) / tiles;
+        if (splits > nk / 4) splits = nk / 4;                // keep >= 4 chunks per split
+    }
+    if (splits < 1) splits = 1;
+    const size_t slab = ((size_t)p.M * p.ldo + 3) & ~(size_t)3;
+    if (splits > 1 && (ws == nullptr || ws_floats < slab * splits)) {
+        splits = ws ? (int)(ws_floats / slab) : 1;
+        if (splits < 1) splits = 1;
+    }
+    p.chunks_per_split = (nk + splits - 1) / splits;
+    splits = (nk + p.chunks_per_split - 1) / p.chunks_per_split;
+    if (splits > 1) { p.out = ws; p.slab = slab; } else { p.out = final_out; p.slab = 0; }
+    const size_t lds = (size_t)2 * (A_ELEMS + W_ELEMS) * sizeof(float);
+    static LdsLimit lds_limit;
+    lds_limit.ensure((const void*)gemm_f32_t_kernel<BM, BN, WM, WN, AT, GATHER>, (int)lds);
+    hipLaunchKernelGGL((gemm_f32_t_kernel<BM, BN, WM, WN, AT, GATHER>), dim3(tiles, splits), dim3(NT), lds, s, p);
+    if (splits > 1) {
+        const size_t n4 = slab / 4;
+        int blocks = (int)((n4 + 255) / 256); if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, final_out, n4, slab, splits);
+    }
+    return master_check_launch("gemm_f32_t");
+}
+
+}  // namespace
+
+// number of floats of workspace that lets a weight-gradient GEMM use its preferred split count
+size_t gemm_f32_t_workspace(int M, int N) { return (((size_t)M * N + 3) & ~(size_t)3) * 64; }
+
+// dX[M,Kc] = G[M,Nc] . W[Nc,Kc] (* gelu'(aux) when aux != NULL)
+int gemm_f32_dgrad(const float* g, const float* w, float* out, const float* aux, int M, int Nc, int Kc, int ldg, int ldo, int ld_aux,
+                   hipStream_t s) {
+    TArgs p{g, w, out, M, Kc, Nc, ldg, Kc, ldo, 0, 0, aux, ld_aux, 0, 0, 0, 0, 0, 0, 0};
+    if (Kc > 64) return launch_t<128, 128, 64, 64, false, false>(p, out, nullptr, 0, 1, s);
+    return launch_t<128, 64, 64, 32, false, false>(p, out, nullptr, 0, 1, s);
+}
+
+// dW[Nc,Kc] = G[M,Nc]^T . X[M,Kc]      (dense output, ldo = Kc)
+int gemm_f32_wgrad(const float* g, const float* x, float* out, int M, int Nc, int Kc, int ldg, int ldx, float* ws, size_t ws_floats,
+                   hipStream_t s) {
+    TArgs p{g, x, out, Nc, Kc, M, ldg, ldx, Kc, 0, 0, nullptr, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (Nc > 64) return launch_t<128, 128, 64, 64, true, false>(p, out, ws, ws_floats, 0, s);
+    return launch_t<32, 256, 32, 64, true, false>(p, out, ws, ws_floats, 0, s);
+}
+
+// dWpacked[Cout][3][3][Cin] = sum over the B*Hout*Wout output pixels of G[pix][Cout] (x) gather(X)[pix][tap][Cin]
+int gemm_f32_conv3x3_wgrad(const float* g, const float* x, float* out, int B, int Hin, int Win, int Cin, int Cout, int ldg, int up,
+                           int zero_pad, float* ws, size_t ws_floats, hipStream_t s) {
+    const int Hout = Hin << up, Wout = Win << up;
+    TArgs p{g, x, out, Cout, 9 * Cin, B * Hout * Wout, ldg, 0, 9 * Cin, 0, 0, nullptr, 0, Hin, Win, Cin, Hout, Wout, up, zero_pad};
+    if (Cout > 64) return launch_t<128, 128, 64, 64, true, true>(p, out, ws, ws_floats, 0, s);
+    if (Cout > 32) return launch_t<64, 128, 32, 64, true, true>(p, out, ws, ws_floats, 0, s);
+    return launch_t<32, 256, 32, 64, true, true>(p, out, ws, ws_floats, 0, s);
+}

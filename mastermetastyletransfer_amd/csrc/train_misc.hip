@@ -1,0 +1,341 @@
+// HBM-bound pieces of the train step (reference train_only_inner_loop.py:519-575): bias gradients (column sums), the ReLU / reflect-pad /
+// upsample / max-pool backward maps of the convolutions, StochasticDepth row scaling, the sigma*Query+mu combine and its backward, the
+// perceptual-loss tap gradient, multi-tensor Adam and the Reptile interpolation.  fp32 (the train step runs in the fp32 mode).
+// Every reduction adds partial sums in a fixed order: results are bitwise reproducible.
+#include "common.h"
+
+int reduce_slabs_launch(const float* part, float* out, size_t n, size_t slab, int splits, hipStream_t s);
+
+namespace {
+
+// ---- slab reduce: out[i] = sum_k part[k*slab + i] -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, size_t slab,
+                                                           int splits) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float s = part[i];
+        for (int k = 1; k < splits; ++k) s += part[(size_t)k * slab + i];
+        out[i] = s;
+    }
+}
+
+// ---- column sums: part[slab][n] = sum over the slab's rows of x[m][n]   (bias gradients; N % 4 == 0).  tpr = min(N/4, 64) threads
+//      cover a row chunk of 16-byte vectors, the other 256/tpr thread rows walk the slab's rows. ---------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ part, int M, int N, int ld, int rows_per_slab,
+                                                     int tpr) {
+    __shared__ f32x4 red[256];
+    const int lanes = 256 / tpr;
+    const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr;
+    const int n = (blockIdx.x * tpr + tx) * 4;
+    const int r0 = blockIdx.y * rows_per_slab, r1 = min(r0 + rows_per_slab, M);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (n < N && ty < lanes)
+        for (int r = r0 + ty; r < r1; r += lanes) acc += *(const f32x4*)(x + (size_t)r * ld + n);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (ty == 0 && n < N) {
+        f32x4 t = red[tx];
+        for (int k = 1; k < lanes; ++k) t += red[k * tpr + tx];
+        *(f32x4*)(part + (size_t)blockIdx.y * N + n) = t;
+    }
+}
+
+// ---- ReLU backward + layout: gm[b,y,x,c] = (c < C && (relu_out == NULL || relu_out[..c] > 0)) ? g : 0, Cp >= C output channels.
+//      g is NHWC [.., C] or, with g_nchw, NCHW [B,C,H,W] (the gradient of the output image). ---------------------------------------------
+__global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict__ g, const float* __restrict__ relu_out, float* __restrict__ gm,
+                                                        int HW, int C, int Cp, int g_nchw, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;             // (pixel, padded channel)
+    if (i >= total) return;
+    const int c = (int)(i % Cp); const size_t px = i / Cp;
+    float v = 0.f;
+    if (c < C) {
+        const size_t n = px / HW, q = px - n * HW;
+        v = g_nchw ? g[(n * C + c) * (size_t)HW + q] : g[px * C + c];
+        if (relu_out && !(relu_out[px * C + c] > 0.f)) v = 0.f;
+    }
+    gm[i] = v;
+}
+
+// ---- backward of ReflectionPad(1) (+ nearest x2 upsample): dxp is the gradient on the padded domain [B,H+2,W+2,C] of the H x W map the
+//      convolution read; pad row -1 mirrors row 1 and pad row H mirrors row H-2 (same for columns), and with `up` each source pixel
+//      collects its 2x2 block.  out [B, H>>up, W>>up, C]. ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fold_reflect_kernel(const float* __restrict__ dxp, float* __restrict__ out, int H, int W, int C, int up,
+                                                           size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;             // (source pixel, channel group of 4)
+    if (i >= total) return;
+    const int C4 = C >> 2;
+    const int c = (int)(i % C4) * 4; size_t t = i / C4;
+    const int Ws = W >> up, Hs = H >> up;
+    const int sx = (int)(t % Ws); t /= Ws; const int sy = (int)(t % Hs); const size_t b = t / Hs;
+    const int Wp = W + 2;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int reps = up ? 2 : 1;
+    for (int uy = 0; uy < reps; ++uy) {
+        const int Y = (sy << up) + uy;
+        int ry[3], ny = 0;
+        ry[ny++] = Y + 1;
+        if (Y == 1) ry[ny++] = 0;
+        if (Y == H - 2) ry[ny++] = H + 1;
+        for (int ux = 0; ux < reps; ++ux) {
+            const int X = (sx << up) + ux;
+            int rx[3], nx = 0;
+            rx[nx++] = X + 1;
+            if (X == 1) rx[nx++] = 0;
+            if (X == W - 2) rx[nx++] = W + 1;
+            for (int a = 0; a < ny; ++a)
+                for (int e = 0; e < nx; ++e)
+                    acc += *(const f32x4*)(dxp + ((b * (H + 2) + ry[a]) * (size_t)Wp + rx[e]) * C + c);
+        }
+    }
+    *(f32x4*)(out + i * 4) = acc;
+}
+
+// ---- MaxPool2d(2,2) backward fused with the ReLU backward of the layer below: y is that layer's ReLU output [N,H,W,C]; the gradient of
+//      a pooled value goes to the first maximum of its 2x2 block (scan order, like torch) and only where y > 0. ---------------------------
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ dx, int H,
+                                                           int W, int C, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;             // (pooled pixel, channel)
+    if (i >= total) return;
+    const int c = (int)(i % C); size_t t = i / C;
+    const int W2 = W >> 1, H2 = H >> 1;
+    const int ox = (int)(t % W2); t /= W2; const int oy = (int)(t % H2); const size_t n = t / H2;
+    const size_t base = ((n * H + 2 * oy) * (size_t)W + 2 * ox) * C + c;
+    const size_t o[4] = {base, base + C, base + (size_t)W * C, base + (size_t)W * C + C};
+    float best = y[o[0]]; int arg = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { const float v = y[o[k]]; if (v > best) { best = v; arg = k; } }
+    const float gv = best > 0.f ? g[i] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dx[o[k]] = k == arg ? gv : 0.f;
+}
+
+// NHWC [N,H,W,Cp] -> NCHW [N,3,H,W] (the gradient of the image that image_to_nhwc padded to Cp channels)
+__global__ __launch_bounds__(256) void nhwc_to_image_kernel(const float* __restrict__ g, float* __restrict__ out, int HW, int Cp, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;             // (n, c, pixel)
+    if (i >= total) return;
+    const size_t q = i % HW, nc = i / HW, n = nc / 3; const int c = (int)(nc - n * 3);
+    out[i] = g[(n * HW + q) * Cp + c];
+}
+
+// ---- StochasticDepth row mode:  out[m,:] = res[m,:] + scale[m / T] * x[m,:]   (res optional) ------------------------------------------
+__global__ __launch_bounds__(256) void rowscale_add_kernel(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ scale,
+                                                           float* __restrict__ out, int T, int C4, size_t total4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const size_t m = i / C4;
+        const float sc = scale[m / T];
+        f32x4 v = *(const f32x4*)(x + 4 * i) * sc;
+        if (res) v += *(const f32x4*)(res + 4 * i);
+        *(f32x4*)(out + 4 * i) = v;
+    }
+}
+
+// ---- Query * sigma + mu (style_transformer.py:1123) and its backward ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mul_add_kernel(const float* __restrict__ q, const float* __restrict__ sg, const float* __restrict__ mu,
+                                                      float* __restrict__ out, size_t total4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256)
+        *(f32x4*)(out + 4 * i) = *(const f32x4*)(q + 4 * i) * *(const f32x4*)(sg + 4 * i) + *(const f32x4*)(mu + 4 * i);
+}
+__global__ __launch_bounds__(256) void mul_add_bwd_kernel(const float* __restrict__ g, const float* __restrict__ q, const float* __restrict__ sg,
+                                                          float* __restrict__ dq, float* __restrict__ dsg, size_t total4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const f32x4 gv = *(const f32x4*)(g + 4 * i);
+        *(f32x4*)(dq + 4 * i) = gv * *(const f32x4*)(sg + 4 * i);
+        *(f32x4*)(dsg + 4 * i) = gv * *(const f32x4*)(q + 4 * i);
+    }
+}
+
+// ---- multi-tensor Adam (torch.optim.Adam semantics, train_only_inner_loop.py:468-478, :575) and Reptile interpolation -----------------
+// table[t] = {param, grad, exp_avg, exp_avg_sq, numel, first_block}; a block finds its tensor by binary search over first_block.
+struct TensorRec { float* p; const float* g; float* m; float* v; long long numel; long long first_block; };
+constexpr int ADAM_CHUNK = 256 * 4 * 4;                                   // elements per block
+
+__device__ __forceinline__ int find_tensor(const TensorRec* __restrict__ table, int n, long long block) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (table[mid].first_block <= block) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(const TensorRec* __restrict__ table, int ntensors, float lr, float b1, float b2, float eps,
+                                                   float wd, float bc1, float bc2_sqrt) {
+    const int t = find_tensor(table, ntensors, blockIdx.x);
+    const TensorRec rec = table[t];
+    const long long e0 = ((long long)blockIdx.x - rec.first_block) * ADAM_CHUNK;
+    const float step = lr / bc1;
+#pragma unroll
+    for (int k = 0; k < ADAM_CHUNK / 256; ++k) {
+        const long long i = e0 + k * 256 + threadIdx.x;
+        if (i >= rec.numel) break;
+        float p = rec.p[i], g = rec.g[i];
+        if (wd != 0.f) g = fmaf(wd, p, g);
+        const float m = fmaf(b1, rec.m[i], (1.f - b1) * g);
+        const float v = fmaf(b2, rec.v[i], (1.f - b2) * g * g);
+        rec.m[i] = m; rec.v[i] = v;
+        rec.p[i] = p - step * (m / (sqrtf(v) / bc2_sqrt + eps));
+    }
+}
+
+// Reptile outer update (reference train.py:524-534): theta += eta * (omega - theta);  table: p = theta, g = omega
+__global__ __launch_bounds__(256) void lerp_kernel(const TensorRec* __restrict__ table, int ntensors, float eta) {
+    const int t = find_tensor(table, ntensors, blockIdx.x);
+    const TensorRec rec = table[t];
+    const long long e0 = ((long long)blockIdx.x - rec.first_block) * ADAM_CHUNK;
+#pragma unroll
+    for (int k = 0; k < ADAM_CHUNK / 256; ++k) {
+        const long long i = e0 + k * 256 + threadIdx.x;
+        if (i >= rec.numel) break;
+        const float th = rec.p[i];
+        rec.p[i] = fmaf(eta, rec.g[i] - th, th);
+    }
+}
+
+// ---- perceptual-loss tap backward (codes/loss.py:112-130, 272-322): gradient w.r.t. the OUTPUT image's feature map ---------------------
+// x holds the features of [content | style | output] images (3B maps of HW x C).  For output image j = 2B + i:
+//   content term  mean |IN(x_i) - IN(x_j)| (or squared)   ->  gy[p,c] = -wc * sgn(yi - yj)  (or -wc * 2 (yi - yj)),  wc = g_content / (B*C*HW)
+//                 and through InstanceNorm:  rstd_j * (gy - mean_p gy - yj * mean_p(gy * yj))
+//   style term    through mean and unbiased std: coefA[i,c] + coefB[i,c] * (x_j - mean_j)     (coefficients from the [B,C] statistics)
+// Pass 1 (MODE 0) writes per-slice partial sums of gy and gy*yj; pass 2 (MODE 1) adds them up per channel and writes the gradient,
+// gated by x_j > 0 when relu_gate (the tap is a ReLU output and nothing else consumes it: relu5_1).
+constexpr int SLICE_ROWS = 256;
+template <int MODE>
+__global__ __launch_bounds__(256) void loss_tap_bwd_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ var,
+                                                           const float* __restrict__ coefA, const float* __restrict__ coefB, float* __restrict__ partial,
+                                                           const float* __restrict__ sums, float* __restrict__ dx, int B, int HW, int C, float eps, float wc, int squared,
+                                                           int relu_gate, int nslice) {
+    extern __shared__ float red[];                              // MODE 0: [2][RPB][C]
+    const int TPR = C / 4, RPB = 256 / TPR;
+    const int tc = threadIdx.x % TPR, tr = threadIdx.x / TPR, i = blockIdx.y, j = 2 * B + i, sl = blockIdx.x;
+    const int r0 = sl * SLICE_ROWS, r1 = min(r0 + SLICE_ROWS, HW);
+    float mi[4], ri[4], mj[4], rj[4], s1[4], s2[4], ca[4], cb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = tc * 4 + e;
+        mi[e] = mean[(size_t)i * C + c]; ri[e] = rsqrtf(var[(size_t)i * C + c] + eps);
+        mj[e] = mean[(size_t)j * C + c]; rj[e] = rsqrtf(var[(size_t)j * C + c] + eps);
+        s1[e] = 0.f; s2[e] = 0.f;
+        if (MODE == 1) {                                           // sums[i][2][C]: the slice partials added up by loss_tap_finalize_kernel
+            s1[e] = sums[((size_t)i * 2 + 0) * C + c]; s2[e] = sums[((size_t)i * 2 + 1) * C + c];
+            ca[e] = coefA[(size_t)i * C + c]; cb[e] = coefB[(size_t)i * C + c];
+        }
+    }
+    if (tr < RPB)
+        for (int r = r0 + tr; r < r1; r += RPB) {
+            const f32x4 va = *(const f32x4*)(x + ((size_t)i * HW + r) * C + tc * 4);
+            const f32x4 vb = *(const f32x4*)(x + ((size_t)j * HW + r) * C + tc * 4);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float yi = (va[e] - mi[e]) * ri[e], yj = (vb[e] - mj[e]) * rj[e], d = yi - yj;
+                const float gy = squared ? -2.f * wc * d : (d > 0.f ? -wc : (d < 0.f ? wc : 0.f));
+                if (MODE == 0) { s1[e] += gy; s2[e] += gy * yj; }
+                else {
+                    float gx = ca[e] + cb[e] * (vb[e] - mj[e]) + rj[e] * (gy - s1[e] - yj * s2[e]);
+                    if (relu_gate && !(vb[e] > 0.f)) gx = 0.f;
+                    o[e] = gx;
+                }
+            }
+            if (MODE == 1) *(f32x4*)(dx + ((size_t)i * HW + r) * C + tc * 4) = o;
+        }
+    if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[tr * C + tc * 4 + e] = s1[e]; red[(RPB + tr) * C + tc * 4 + e] = s2[e]; }
+        __syncthreads();
+        for (int c = threadIdx.x; c < 2 * C; c += 256) {
+            const int which = c / C, cc = c - which * C;
+            float t = 0.f;
+            for (int k = 0; k < RPB; ++k) t += red[(which * RPB + k) * C + cc];
+            partial[(((size_t)i * nslice + sl) * 2 + which) * C + cc] = t;
+        }
+    }
+}
+
+// sums[i][which][c] = (sum over slices of partial[i][slice][which][c]) / HW
+__global__ __launch_bounds__(256) void loss_tap_finalize_kernel(const float* __restrict__ partial, float* __restrict__ sums, int HW, int C, int nslice,
+                                                                int total) {
+    const int t = blockIdx.x * 256 + threadIdx.x;               // (i, which, c)
+    if (t >= total) return;
+    const int c = t % C, iw = t / C, which = iw & 1, i = iw >> 1;
+    float s = 0.f;
+    for (int k = 0; k < nslice; ++k) s += partial[(((size_t)i * nslice + k) * 2 + which) * C + c];
+    sums[t] = s / (float)HW;
+}
+
+inline unsigned blocks_for(size_t n, unsigned cap = 0x7fffffffu) { size_t b = (n + 255) / 256; return (unsigned)(b > cap ? cap : (b ? b : 1)); }
+
+}  // namespace
+
+int reduce_slabs_launch(const float* part, float* out, size_t n, size_t slab, int splits, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, s, part, out, n, slab, splits);
+    return master_check_launch("reduce_slabs");
+}
+
+static int colsum_tpr(int N) { return N / 4 >= 64 ? 64 : N / 4; }
+int colsum_slabs(int M, int N) {                      // row slabs such that the grid has ~512 workgroups, >= 64 rows each
+    const int tpr = colsum_tpr(N), gx = (N / 4 + tpr - 1) / tpr;
+    int slabs = (512 + gx - 1) / gx;
+    if (slabs > (M + 63) / 64) slabs = (M + 63) / 64;
+    return slabs < 1 ? 1 : slabs;
+}
+// ws: colsum_slabs(M, N) * N floats
+int colsum_launch(const float* x, float* out, float* ws, int M, int N, int ld, hipStream_t s) {
+    const int slabs = colsum_slabs(M, N), rps = (M + slabs - 1) / slabs, tpr = colsum_tpr(N);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N / 4 + tpr - 1) / tpr, slabs), dim3(256), 0, s, x, slabs == 1 ? out : ws, M, N, ld, rps, tpr);
+    if (slabs > 1) return reduce_slabs_launch(ws, out, (size_t)N, (size_t)N, slabs, s);
+    return master_check_launch("colsum");
+}
+int relu_mask_launch(const float* g, const float* relu_out, float* gm, int B, int HW, int C, int Cp, int g_nchw, hipStream_t s) {
+    const size_t total = (size_t)B * HW * Cp;
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(blocks_for(total)), dim3(256), 0, s, g, relu_out, gm, HW, C, Cp, g_nchw, total);
+    return master_check_launch("relu_mask");
+}
+int fold_reflect_launch(const float* dxp, float* out, int B, int H, int W, int C, int up, hipStream_t s) {
+    const size_t total = (size_t)B * (H >> up) * (W >> up) * (C / 4);
+    hipLaunchKernelGGL(fold_reflect_kernel, dim3(blocks_for(total)), dim3(256), 0, s, dxp, out, H, W, C, up, total);
+    return master_check_launch("fold_reflect");
+}
+int maxpool2_bwd_launch(const float* g, const float* y, float* dx, int N, int H, int W, int C, hipStream_t s) {
+    const size_t total = (size_t)N * (H / 2) * (W / 2) * C;
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, s, g, y, dx, H, W, C, total);
+    return master_check_launch("maxpool2_bwd");
+}
+int nhwc_to_image_launch(const float* g, float* out, int N, int HW, int Cp, hipStream_t s) {
+    const size_t total = (size_t)N * 3 * HW;
+    hipLaunchKernelGGL(nhwc_to_image_kernel, dim3(blocks_for(total)), dim3(256), 0, s, g, out, HW, Cp, total);
+    return master_check_launch("nhwc_to_image");
+}
+int rowscale_add_launch(const float* x, const float* res, const float* scale, float* out, int B, int T, int C, hipStream_t s) {
+    const size_t total4 = (size_t)B * T * (C / 4);
+    hipLaunchKernelGGL(rowscale_add_kernel, dim3(blocks_for(total4, 2048)), dim3(256), 0, s, x, res, scale, out, T, C / 4, total4);
+    return master_check_launch("rowscale_add");
+}
+int mul_add_launch(const float* q, const float* sg, const float* mu, float* out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(mul_add_kernel, dim3(blocks_for(n / 4, 2048)), dim3(256), 0, s, q, sg, mu, out, n / 4);
+    return master_check_launch("mul_add");
+}
+int mul_add_bwd_launch(const float* g, const float* q, const float* sg, float* dq, float* dsg, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(mul_add_bwd_kernel, dim3(blocks_for(n / 4, 2048)), dim3(256), 0, s, g, q, sg, dq, dsg, n / 4);
+    return master_check_launch("mul_add_bwd");
+}
+int adam_chunk() { return ADAM_CHUNK; }
+int adam_launch(const void* table, int ntensors, long long nblocks, float lr, float b1, float b2, float eps, float wd, int step, hipStream_t s) {
+    const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);     // in double, like torch's Python floats
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, (const TensorRec*)table, ntensors, lr, b1, b2, eps, wd, (float)bc1,
+                       (float)sqrt(bc2));
+    return master_check_launch("adam");
+}
+int lerp_launch(const void* table, int ntensors, long long nblocks, float eta, hipStream_t s) {
+    hipLaunchKernelGGL(lerp_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, (const TensorRec*)table, ntensors, eta);
+    return master_check_launch("lerp");
+}
+int loss_tap_slices(int HW) { return (HW + SLICE_ROWS - 1) / SLICE_ROWS; }
+// partial: B * (slices + 1) * 2 * C floats of workspace (slice partials, then their sums); dx: [B, HW, C]
+int loss_tap_bwd_launch(const float* x, const float* mean, const float* var, const float* coefA, const float* coefB, float* partial, float* dx,
+                        int B, int HW, int C, float eps, float wc, int squared, int relu_gate, hipStream_t s) {
+    const int ns = loss_tap_slices(HW);
+    float* sums = partial + (size_t)B * ns * 2 * C;
+    const size_t lds = (size_t)2 * (256 / (C / 4)) * C * sizeof(float);
+    hipLaunchKernelGGL((loss_tap_bwd_kernel<0>), dim3(ns, B), dim3(256), lds, s, x, mean, var, coefA, coefB, partial, (const float*)nullptr, dx, B, HW,
+                       C, eps, wc, squared, relu_gate, ns);
+    hipLaunchKernelGGL(loss_tap_finalize_kernel, dim3((B * 2 * C + 255) / 256), dim3(256), 0, s, (const float*)partial, sums, HW, C, ns, B * 2 * C);
+    hipLaunchKernelGGL((loss_tap_bwd_kernel<1>), dim3(ns, B), dim3(256), 0, s, x, mean, var, coefA, coefB, partial, (const float*)sums, dx, B, HW, C,
+                       eps, wc, squared, relu_gate, ns);
+    return master_check_launch("loss_tap_bwd");
+}

@@ -4,8 +4,9 @@ zero-padded implicit-GEMM convolutions - then
     content = sum_l mean |IN(Fc_l) - IN(Fcs_l)|                      (loss.py:112-118, 272-296)
     style   = sum_l mean |mu(Fs_l) - mu(Fcs_l)| + mean |sigma(Fs_l) - sigma(Fcs_l)|     (loss.py:121-130, 300-322; unbiased sigma)
     total   = content + lambda * style                                 (loss.py:246)
-Same class name, constructor keywords, forward signature and return tuples as the reference.  Backward is not implemented (the
-train step is SURVEY 8f-1): calling it with tensors that require grad raises.
+Same class name, constructor keywords, forward signature and return tuples as the reference.  When the output image carries a
+gradient (train step, train_only_inner_loop.py:529-575) the loss is one autograd Function (autograd.PerceptualLossFn) whose backward
+runs the loss-tap gradient, the VGG-19 data-gradient chain and the max-pool / ReLU backward on the HIP kernels (fp32 mode).
 """
 from __future__ import annotations
 
@@ -117,11 +118,25 @@ class custom_loss(nn.Module):
         assert content_image.shape == style_image.shape == output_image.shape, "All images should be in the exact same shape"
         assert content_image.requires_grad == False, "Content image should not require gradient"
         assert style_image.requires_grad == False, "Style image should not require gradient"
-        if output_image.requires_grad and torch.is_grad_enabled():
-            raise NotImplementedError("the loss backward (train step, SURVEY 8f-1) is not built: call under torch.no_grad()")
         if loss_weight is None:
             loss_weight = self.lambda_value
         B = content_image.shape[0]
+        if output_image.requires_grad and torch.is_grad_enabled():
+            if self.feature_extractor_model.compute_dtype != torch.float32:
+                raise NotImplementedError("the loss backward runs in the fp32 mode: custom_loss.set_compute_dtype(torch.float32)")
+            from .autograd import PerceptualLossFn, VGG19_CONVS as _ORDER
+            wb = []
+            for i in _ORDER:
+                conv = self.feature_extractor_model.features[i]
+                wb += [conv.weight, conv.bias]
+            content_loss, style_loss = PerceptualLossFn.apply(content_image, style_image, output_image,
+                                                              self.distance_content == "euclidian_squared",
+                                                              self.distance_style == "euclidian_squared", *wb)
+            total_loss = content_loss + loss_weight * style_loss
+            if output_similarity_loss:
+                similarity_loss = torch.zeros((), dtype=torch.float32, device=content_image.device)
+                return (total_loss, content_loss, style_loss, similarity_loss) if output_content_and_style_loss else (total_loss, similarity_loss)
+            return (total_loss, content_loss, style_loss) if output_content_and_style_loss else total_loss
         # the three feature extractions of loss.py:227-229 are independent: one batch [content | style | output]
         taps = self.feature_extractor_model(torch.cat([content_image, style_image, output_image], dim=0))
         content_loss, style_loss = 0.0, 0.0

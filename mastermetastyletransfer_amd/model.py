@@ -15,30 +15,35 @@ import torch
 from torch import nn, Tensor
 
 from . import ops
-from .modules import Decoder, StyleTransformer, SwinEncoder, _HipModule, _inference_only
+from .modules import Decoder, StyleTransformer, SwinEncoder, _HipModule, _train_mode
 
 project_absolute_path = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
-_SWIN_VARIANTS = {  # embed_dim, heads of the first two stages (torchvision swin_t/s/b), depths of those stages
-    "swin_T": (96, (3, 6), (2, 2)), "swin_S": (96, (3, 6), (2, 2)), "swin_B": (128, (4, 8), (2, 2)),
+_SWIN_VARIANTS = {  # embed_dim, heads and depths of the first two stages, (stochastic_depth_prob, total blocks) of the full torchvision backbone
+    "swin_T": (96, (3, 6), (2, 2), (0.2, 12)), "swin_S": (96, (3, 6), (2, 2), (0.3, 24)), "swin_B": (128, (4, 8), (2, 2), (0.5, 24)),
 }
 
 
-def _load_swin_encoder(path: Optional[str], variant: str) -> SwinEncoder:
+def _load_swin_encoder(path: Optional[str], variant: str, allow_random: bool = False) -> SwinEncoder:
     if variant not in _SWIN_VARIANTS:        # same message as codes/utils.py:71-72
         raise ValueError("Invalid Swin Transformer variant. Please choose one of the following: swin_T, swin_S, swin_B")
-    embed, heads, depths = _SWIN_VARIANTS[variant]
+    embed, heads, depths, (sd_prob, total) = _SWIN_VARIANTS[variant]
     if variant != "swin_B":
-        raise NotImplementedError(f"{variant}: head_dim-32 kernels are built for swin_B (embed 128) only")
-    enc = SwinEncoder(embed_dim=embed, depths=depths, num_heads=heads)
+        # embed 96 is head_dim 32 too (96/3, 192/6), but the patch-embed and row-norm kernels are built for power-of-two widths
+        raise NotImplementedError(f"{variant}: the encoder kernels are built for swin_B (embed 128); swin_T / swin_S (embed 96) are not")
+    enc = SwinEncoder(embed_dim=embed, depths=depths, num_heads=heads, stochastic_depth_prob=sd_prob, total_blocks=total)
     if path and os.path.exists(path):
         # the reference pickles the whole torchvision nn.Sequential (utils.py:93-102); a plain state dict works too
         obj = torch.load(path, map_location="cpu", weights_only=False)
         sd = obj.state_dict() if isinstance(obj, nn.Module) else obj
         enc.load_state_dict(sd)
+    elif allow_random:
+        warnings.warn("no Swin encoder weights found at %r: the encoder keeps its random initialisation" % (path,))
     else:
-        warnings.warn("no Swin encoder weights found at %r: the encoder keeps its random initialisation "
-                      "(the reference would download ImageNet weights through torchvision; there is no network here)" % (path,))
+        raise FileNotFoundError(
+            "no Swin encoder weights at %r.  The reference downloads ImageNet weights through torchvision here (codes/utils.py:82-102); "
+            "this machine has no network.  Save swin_b().features[:4] (module or state dict) there, or pass "
+            "allow_random_swin_encoder=True to run with a randomly initialised encoder (benchmarks, tests)." % (path,))
     return enc
 
 
@@ -81,7 +86,8 @@ class MasterStyleTransferModel(nn.Module):
                  decoder_initializer: str = "kaiming_normal_",
                  direct_pretrained_style_transformer_path: str = '',
                  direct_pretrained_decoder_path: str = '',
-                 compute_dtype: torch.dtype = torch.float32):
+                 compute_dtype: torch.dtype = torch.float32,
+                 allow_random_swin_encoder: bool = False):
         super().__init__()
         for k, v in list(locals().items()):          # the reference mirrors every ctor argument as an attribute
             if k.startswith(("style_", "decoder_initializer", "direct_pretrained")):
@@ -92,7 +98,7 @@ class MasterStyleTransferModel(nn.Module):
             swin_path = os.path.join(project_absolute_path, swin_model_relative_path)
         else:
             swin_path = os.path.join(project_absolute_path, "models", f"{swin_variant}_first_2_stages.pt")
-        self.swin_encoder = _load_swin_encoder(swin_path, swin_variant)
+        self.swin_encoder = _load_swin_encoder(swin_path, swin_variant, allow_random_swin_encoder)
 
         self.style_transformer = StyleTransformer(
             encoder_dim=style_encoder_dim, decoder_dim=style_decoder_dim,
@@ -127,10 +133,24 @@ class MasterStyleTransferModel(nn.Module):
     def load_pretained_weights_to_style_transformer(self, pretrained_weights_path: str):
         if pretrained_weights_path is None:                          # full_model.py:160-161
             raise ValueError("Please provide the path of the pretrained weights")
-        raise NotImplementedError(
-            "remapping an MS-Swin block checkpoint into the StyleTransformer (reference "
-            "codes/load_pretrained_weights_to_style_transformer.py) is init-time host code outside the hot path; "
-            "load a StyleTransformer state dict through direct_pretrained_style_transformer_path instead")
+        # full_model.py:163-193 -> load_pretrained_weights_to_style_transformer.py:688-733: one MS-Swin block copied into every
+        # attention / MLP of the StyleTransformer (host-side state-dict slicing, weights.py)
+        from .weights import remap_ms_swin_block
+        path = pretrained_weights_path
+        if not os.path.isabs(path) and not os.path.exists(path):
+            path = os.path.join(project_absolute_path, path)
+        if not os.path.exists(path):
+            raise ValueError(f"The path of the pretrained weights does not exist: {path}")
+        block_sd = torch.load(path, map_location="cpu")
+        sd = remap_ms_swin_block(
+            block_sd, self.style_transformer.state_dict(), encoder_dim=self.style_encoder_dim, decoder_dim=self.style_decoder_dim,
+            encoder_mlp_ratio=self.style_encoder_mlp_ratio, decoder_mlp_ratio=self.style_decoder_mlp_ratio,
+            encoder_window_size=list(self.style_encoder_window_size), decoder_window_size=list(self.style_decoder_window_size),
+            encoder_qkv_bias=self.style_encoder_qkv_bias, decoder_qkv_bias=self.style_decoder_qkv_bias,
+            encoder_proj_bias=self.style_encoder_proj_bias, decoder_proj_bias=self.style_decoder_proj_bias,
+            encoder_norm_layer=self.style_encoder_norm_layer, decoder_norm_layer=self.style_decoder_norm_layer,
+            decoder_exclude_MLP_after_Fcs_self_MHA=self.style_decoder_exclude_MLP_after_Fcs_self_MHA)
+        self.style_transformer.load_state_dict(sd)
 
     def set_compute_dtype(self, dtype: torch.dtype) -> "MasterStyleTransferModel":
         """torch.float32: exact-fp32 matrix cores, parity mode.  torch.bfloat16: bf16 MFMA, throughput mode."""
@@ -143,10 +163,11 @@ class MasterStyleTransferModel(nn.Module):
         return self
 
     def forward(self, content_image: Tensor, style_image: Tensor, transformer_layer_count: int = 1) -> Tensor:
-        _inference_only(self)
         if content_image.shape != style_image.shape:
             raise ValueError("content and style batches must have the same shape")
         B = content_image.shape[0]
+        if _train_mode(self):
+            return self._forward_train(content_image, style_image, transformer_layer_count)
         # the two encoder passes of full_model.py:219-220 are independent -> one batch of 2B images
         x, _, h, w = self.swin_encoder.run(content_image, style_image)
         fc, fs = x[: B * h * w], x[B * h * w:]
@@ -154,3 +175,18 @@ class MasterStyleTransferModel(nn.Module):
         # the reference permutes NHWC->NCHW here (:222); the decoder kernels read NHWC directly and the
         # last convolution writes the NCHW image
         return self.decoder.run_nhwc(fcs.view(B, h, w, -1))
+
+    def _forward_train(self, content_image: Tensor, style_image: Tensor, k: int) -> Tensor:
+        """train-mode forward (train_only_inner_loop.py:523): autograd graph over the HIP forward/backward kernels.  The Swin encoder
+        is frozen like the reference's default (:254-257): it runs without a graph (its StochasticDepth is still active in train mode);
+        gradients flow into the StyleTransformer and the image decoder."""
+        from . import train_forward as TF
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.swin_encoder.parameters()):
+            raise NotImplementedError("fine-tuning the Swin encoder is not on the HIP path: freeze it "
+                                      "(for p in model.swin_encoder.parameters(): p.requires_grad = False - the reference's default)")
+        B = content_image.shape[0]
+        with torch.no_grad():
+            x, _, h, w = self.swin_encoder.run(content_image, style_image)
+        fc, fs = x[: B * h * w], x[B * h * w:]
+        fcs = TF.style_transformer(self.style_transformer, fc, fs, k, B, h, w, TF.sd_masks)
+        return TF.image_decoder(self.decoder, fcs.view(B, h, w, -1))

@@ -26,10 +26,23 @@ EPS = 1e-5
 
 
 def _inference_only(m: nn.Module):
+    """inference entry points of modules that have no train-mode form of their own (the window attention modules are trained through
+    the blocks that own them)"""
     if m.training:
         raise NotImplementedError(
-            "train-mode forward (StochasticDepth row masks, backward) is not on the HIP path yet "
-            "(SURVEY.md section 8f item 1); call .eval()")
+            "train-mode forward of this module alone is not on the HIP path: train through StyleTransformer / Decoder / "
+            "MasterStyleTransferModel (train_forward.py), or call .eval()")
+
+
+def _train_mode(m: nn.Module) -> bool:
+    """True when the call must build an autograd graph on the HIP backward kernels (train_forward.py): the module is in train mode,
+    like the reference's trainer (`.train()`, train_only_inner_loop.py:239).  An eval-mode forward never records a graph (inference
+    kernels only), whatever torch.is_grad_enabled() says: set the stochastic-depth probabilities to 0 to train without the masks."""
+    if not m.training:
+        return False
+    if getattr(m, "compute_dtype", torch.float32) != torch.float32:
+        raise NotImplementedError("the train step runs in the fp32 mode: call set_compute_dtype(torch.float32) before .train()")
+    return True
 
 
 class _HipModule(nn.Module):
@@ -269,8 +282,17 @@ class StyleSwinTransformerBlock(_HipModule):
         return outs
 
     def forward(self, input_q: Tensor, input_k: Tensor, input_v: Tensor, calculating_Key_in_encoder: bool = None) -> Tensor:
-        _inference_only(self)
         B, H, W, C = input_q.shape
+        if _train_mode(self):
+            from . import train_forward as TF
+            memo: Dict[int, Tensor] = {}
+
+            def tk(t):
+                if id(t) not in memo:
+                    memo[id(t)] = t.reshape(B * H * W, C).float()
+                return memo[id(t)]
+            res = tk(input_q) if (calculating_Key_in_encoder is True or not self.exclude_MLP_after) else tk(input_v)
+            return TF.block(self, tk(input_q), tk(input_k), [tk(input_v)], [res], B, H, W, TF.sd_masks)[0].view(B, H, W, C)
         cache: Dict[int, Tensor] = {}
 
         def tok(t):
@@ -389,8 +411,13 @@ class StyleEncoder(_HipModule):
         return key, scale, shift
 
     def forward(self, Key: Tensor, Scale: Tensor, Shift: Tensor):
-        _inference_only(self)
         B, H, W, C = Key.shape
+        if _train_mode(self):
+            from . import train_forward as TF
+            k = Key.reshape(B * H * W, C).float()
+            s = k if Scale is Key else Scale.reshape(B * H * W, C).float()
+            sh = s if Shift is Scale else (k if Shift is Key else Shift.reshape(B * H * W, C).float())
+            return tuple(t.view(B, H, W, C) for t in TF.style_encoder(self, k, s, sh, B, H, W, TF.sd_masks))
         dt = self.compute_dtype
         k = _tokens(Key, dt)
         s = k if Scale is Key else _tokens(Scale, dt)
@@ -445,8 +472,11 @@ class StyleDecoder(_HipModule):
         return _mlp_fwd(self, "last_mlp", self.last_MLP, query, query)                         # :1125
 
     def forward(self, Fcs: Tensor, Key: Tensor, Scale: Tensor, Shift: Tensor) -> Tensor:
-        _inference_only(self)
         B, H, W, C = Fcs.shape
+        if _train_mode(self):
+            from . import train_forward as TF
+            f = lambda t: t.reshape(B * H * W, C).float()
+            return TF.style_decoder(self, f(Fcs), f(Key), f(Scale), f(Shift), B, H, W, TF.sd_masks).view(B, H, W, C)
         dt = self.compute_dtype
         return _image(self.run(_tokens(Fcs, dt), _tokens(Key, dt), _tokens(Scale, dt), _tokens(Shift, dt), B, H, W), B, H, W)
 
@@ -496,8 +526,11 @@ class StyleTransformer(_HipModule):
         return fc
 
     def forward(self, Fc: Tensor, Fs: Tensor, k: int = 1) -> Tensor:
-        _inference_only(self)
         B, H, W, C = Fc.shape
+        if _train_mode(self):
+            from . import train_forward as TF
+            return TF.style_transformer(self, Fc.reshape(B * H * W, C).float(), Fs.reshape(B * H * W, C).float(), k, B, H, W,
+                                        TF.sd_masks).view(B, H, W, C)
         dt = self.compute_dtype
         return _image(self.run(_tokens(Fc, dt), _tokens(Fs, dt), k, B, H, W), B, H, W)
 
@@ -556,7 +589,9 @@ class Decoder(_HipModule):
 
     def forward(self, x: Tensor) -> Tensor:
         """NCHW in / NCHW out like the reference (decoder.py:75-76)"""
-        _inference_only(self)
+        if _train_mode(self):
+            from . import train_forward as TF
+            return TF.image_decoder(self, x.permute(0, 2, 3, 1).contiguous().float())
         return self.run_nhwc(ops.convert(x.permute(0, 2, 3, 1).contiguous(), self.compute_dtype))
 
 
@@ -589,17 +624,27 @@ class _SwinAttention(_WindowAttentionBase):
 
 
 class SwinTransformerBlock(_HipModule):
-    def __init__(self, dim: int, num_heads: int, window_size, shift_size, mlp_ratio: float = 4.0):
+    def __init__(self, dim: int, num_heads: int, window_size, shift_size, mlp_ratio: float = 4.0, stochastic_depth_prob: float = 0.0):
         super().__init__()
         self.norm1 = nn.LayerNorm(dim, eps=EPS)
         self.attn = _SwinAttention(dim, num_heads, window_size, shift_size)
         self.norm2 = nn.LayerNorm(dim, eps=EPS)
         self.mlp = _make_mlp(dim, int(dim * mlp_ratio), 0.0)
+        self.stochastic_depth_prob = stochastic_depth_prob      # torchvision: StochasticDepth(p, "row") on both branches
         _init_mlp(self.mlp)
 
-    def run(self, x: Tensor, B, H, W) -> Tensor:
-        x = self.attn.attend(x, x, B, H, W, self.norm1)
-        return _mlp_fwd(self, "mlp", self.mlp, x, x, norm=self.norm2)
+    def run(self, x: Tensor, B, H, W, masks: Optional[Tuple[Tensor, Tensor]] = None) -> Tensor:
+        """x + SD(attn(norm1 x)); x + SD(mlp(norm2 x)).  `masks` = (attention, mlp) row masks [B] of a train-mode call (the frozen
+        encoder still runs its StochasticDepth when the model is in train mode, train_only_inner_loop.py:239); None = identity."""
+        if masks is None:
+            x = self.attn.attend(x, x, B, H, W, self.norm1)
+            return _mlp_fwd(self, "mlp", self.mlp, x, x, norm=self.norm2)
+        from .autograd import rowscale_add
+        if x.dtype != torch.float32:
+            raise NotImplementedError("train-mode StochasticDepth in the encoder runs in the fp32 mode")
+        T = H * W
+        x = rowscale_add(self.attn.attend(x, None, B, H, W, self.norm1), x, masks[0], B, T)
+        return rowscale_add(_mlp_fwd(self, "mlp", self.mlp, x, None, norm=self.norm2), x, masks[1], B, T)
 
 
 class PatchMerging(_HipModule):
@@ -621,13 +666,21 @@ class SwinEncoder(nn.Sequential):
     the reference's cut encoder (codes/utils.py:59-102) load by key.  NCHW image -> NHWC [B,H/8,W/8,2E]."""
     compute_dtype = torch.float32
 
-    def __init__(self, embed_dim: int = 128, depths=(2, 2), num_heads=(4, 8), window_size=(7, 7), mlp_ratio: float = 4.0):
+    def __init__(self, embed_dim: int = 128, depths=(2, 2), num_heads=(4, 8), window_size=(7, 7), mlp_ratio: float = 4.0,
+                 stochastic_depth_prob: float = 0.5, total_blocks: int = 24):
+        """stochastic_depth_prob / total_blocks: torchvision's schedule for the FULL backbone (swin_b: 0.5 over 24 blocks):
+        block number n (counted over all stages) gets p = stochastic_depth_prob * n / (total_blocks - 1)."""
         patch = nn.Sequential(nn.Conv2d(3, embed_dim, kernel_size=4, stride=4), nn.Identity(), nn.LayerNorm(embed_dim, eps=EPS))
+        counter = [0]
 
         def stage(dim, nh, depth):
-            return nn.Sequential(*[SwinTransformerBlock(dim, nh, window_size,
-                                                        [0, 0] if i % 2 == 0 else [w // 2 for w in window_size], mlp_ratio)
-                                   for i in range(depth)])
+            blocks = []
+            for i in range(depth):
+                p = stochastic_depth_prob * float(counter[0]) / float(max(total_blocks - 1, 1))
+                counter[0] += 1
+                blocks.append(SwinTransformerBlock(dim, nh, window_size, [0, 0] if i % 2 == 0 else [w // 2 for w in window_size],
+                                                   mlp_ratio, stochastic_depth_prob=p))
+            return nn.Sequential(*blocks)
         super().__init__(patch, stage(embed_dim, num_heads[0], depths[0]), PatchMerging(embed_dim),
                          stage(2 * embed_dim, num_heads[1], depths[1]))
         for m in self.modules():                                  # torchvision SwinTransformer init
@@ -653,17 +706,30 @@ class SwinEncoder(nn.Sequential):
                             conv.bias.detach().float(), ln.weight.detach().float(), ln.bias.detach().float(),
                             self.compute_dtype, ln.eps, out=x[b0:b0 + img.shape[0]])
             b0 += img.shape[0]
+        # train mode: torchvision's blocks apply StochasticDepth; each image batch (one reference encoder call) draws its masks
+        # in call order - all of content's, then all of style's - and the per-block masks of the 2B batch are their concatenation
+        masks = {}
+        if self.training:
+            from . import train_forward as TF
+            blocks = [b for b in list(self[1]) + list(self[3]) if b.stochastic_depth_prob > 0.0]
+            per_call = [[(TF.sd_masks.draw(int(img.shape[0]), b.stochastic_depth_prob, img.device),
+                          TF.sd_masks.draw(int(img.shape[0]), b.stochastic_depth_prob, img.device)) for b in blocks] for img in imgs]
+            for j, b in enumerate(blocks):
+                masks[id(b)] = (torch.cat([pc[j][0] for pc in per_call]), torch.cat([pc[j][1] for pc in per_call]))
         h, w = H // 4, W // 4
         x = x.view(B * h * w, -1)
         for blk in self[1]:
-            x = blk.run(x, B, h, w)
+            x = blk.run(x, B, h, w, masks.get(id(blk)))
         x = self[2].run(x, B, h, w)
         h, w = h // 2, w // 2
         for blk in self[3]:
-            x = blk.run(x, B, h, w)
+            x = blk.run(x, B, h, w, masks.get(id(blk)))
         return x, B, h, w
 
     def forward(self, img: Tensor) -> Tensor:
-        _inference_only(self)
-        x, B, h, w = self.run(img)
-        return _image(x, B, h, w)
+        if any(p.requires_grad for p in self.parameters()) and torch.is_grad_enabled() and self.training:
+            raise NotImplementedError("fine-tuning the Swin encoder is not on the HIP path: freeze it (the reference's default, "
+                                      "train_only_inner_loop.py:254-257)")
+        with torch.no_grad():
+            x, B, h, w = self.run(img)
+            return _image(x, B, h, w)

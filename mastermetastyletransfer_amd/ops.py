@@ -17,12 +17,19 @@ LIB_PATH = os.environ.get("MASTER_HIP_LIB") or os.path.join(_HERE, "csrc", "libm
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
-K_FAMILIES = ("linear", "conv3x3", "window_attn", "layernorm", "instnorm", "patch_embed", "patch_merge", "convert", "mlp", "decoder_tail", "attn_block")
+K_FAMILIES = ("linear", "conv3x3", "window_attn", "layernorm", "instnorm", "patch_embed", "patch_merge", "convert", "mlp", "decoder_tail", "attn_block",
+              "conv_dgrad", "conv_wgrad", "linear_bwd", "window_attn_bwd", "train_misc")
 
 EXPORTS = (
     "master_version", "master_last_error_string", "master_linear_fwd", "master_conv3x3_reflect_fwd",
     "master_window_attn_fwd", "master_layernorm_fwd", "master_instnorm_fwd", "master_patch_embed_fwd",
     "master_patch_merge_ln_fwd", "master_patch_merge_linear_fwd", "master_resize_plan", "master_preprocess_fwd", "master_postprocess_fwd", "master_image_to_nhwc_fwd", "master_conv3x3_zero_fwd", "master_maxpool2x2_fwd", "master_channel_stats_fwd", "master_stats_slices", "master_instnorm_distance_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_linear_ln_fwd", "master_attn_block_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
+    # train step
+    "master_linear_act_fwd", "master_linear_dgrad", "master_linear_wgrad", "master_gemm_workspace_floats", "master_colsum",
+    "master_colsum_workspace_floats", "master_reduce_slabs", "master_layernorm_bwd", "master_layernorm_bwd_workspace_floats",
+    "master_instnorm_bwd", "master_window_attn_bwd", "master_conv3x3_dgrad", "master_conv3x3_wgrad", "master_relu_mask",
+    "master_fold_reflect", "master_maxpool2x2_bwd", "master_nhwc_to_image", "master_rowscale_add", "master_mul_add_fwd",
+    "master_mul_add_bwd", "master_loss_tap_bwd", "master_loss_tap_workspace_floats", "master_adam_chunk", "master_adam_step", "master_lerp",
 )
 
 _lib = None
@@ -93,6 +100,33 @@ def load_library() -> ctypes.CDLL:
     lib.master_attn_block_fwd.argtypes = [vp] * 11 + [ci] * 6 + [cf, cf, ci, vp]
     lib.master_decoder_tail_fwd.argtypes = [vp] * 6 + [ci] * 4 + [vp]
     lib.master_prof_read.argtypes = [ci, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]
+    # ---- train step ----
+    cz, cll = ctypes.c_size_t, ctypes.c_longlong
+    lib.master_linear_act_fwd.argtypes = [vp] * 5 + [ci] * 7 + [vp]
+    lib.master_linear_dgrad.argtypes = [vp] * 4 + [ci] * 7 + [vp]
+    lib.master_gemm_workspace_floats.argtypes = [ci, ci]; lib.master_gemm_workspace_floats.restype = cz
+    lib.master_linear_wgrad.argtypes = [vp] * 3 + [ci] * 5 + [vp, cz, ci, vp]
+    lib.master_colsum_workspace_floats.argtypes = [ci, ci]; lib.master_colsum_workspace_floats.restype = cz
+    lib.master_colsum.argtypes = [vp] * 3 + [ci] * 4 + [vp]
+    lib.master_reduce_slabs.argtypes = [vp, vp, cz, cz, ci, vp]
+    lib.master_layernorm_bwd_workspace_floats.argtypes = [ci, ci]; lib.master_layernorm_bwd_workspace_floats.restype = cz
+    lib.master_layernorm_bwd.argtypes = [vp] * 6 + [ci, ci, cf, ci, vp]
+    lib.master_instnorm_bwd.argtypes = [vp] * 6 + [ci] * 4 + [cf, ci, vp]
+    lib.master_window_attn_bwd.argtypes = ([vp] * 4 + [ci] * 3 + [vp] * 3 + [ci] * 2 + [vp] * 4 + [vp] * 2 + [ci] + [vp] * 4 + [ci] * 3
+                                           + [vp] * 4 + [ci] * 6 + [cf, ci, vp])
+    lib.master_conv3x3_dgrad.argtypes = [vp] * 5 + [ci] * 7 + [vp]
+    lib.master_conv3x3_wgrad.argtypes = [vp] * 3 + [ci] * 8 + [vp, cz, ci, vp]
+    lib.master_relu_mask.argtypes = [vp] * 3 + [ci] * 6 + [vp]
+    lib.master_fold_reflect.argtypes = [vp] * 2 + [ci] * 6 + [vp]
+    lib.master_maxpool2x2_bwd.argtypes = [vp] * 3 + [ci] * 5 + [vp]
+    lib.master_nhwc_to_image.argtypes = [vp] * 2 + [ci] * 4 + [vp]
+    lib.master_rowscale_add.argtypes = [vp] * 4 + [ci] * 4 + [vp]
+    lib.master_mul_add_fwd.argtypes = [vp] * 4 + [cz, ci, vp]
+    lib.master_mul_add_bwd.argtypes = [vp] * 5 + [cz, ci, vp]
+    lib.master_loss_tap_workspace_floats.argtypes = [ci, ci, ci]; lib.master_loss_tap_workspace_floats.restype = cz
+    lib.master_loss_tap_bwd.argtypes = [vp] * 7 + [ci] * 3 + [cf, cf, ci, ci, ci, vp]
+    lib.master_adam_step.argtypes = [vp, ci, cll] + [cf] * 5 + [ci, vp]
+    lib.master_lerp.argtypes = [vp, ci, cll, cf, vp]
     _lib = lib
     return lib
 

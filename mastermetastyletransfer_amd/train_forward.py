@@ -1,0 +1,235 @@
+"""Train-mode forward of the stylization path (reference train_only_inner_loop.py:519-527: `.train()` model, StochasticDepth row
+masks active) built from the autograd Functions of autograd.py, so that `total_loss.backward()` runs the HIP backward kernels and
+fills `.grad` of the reference-named parameters.
+
+Same arithmetic as the inference `run` methods of modules.py, with two differences the reference has in train mode:
+  * every residual branch goes through torchvision StochasticDepth(p, "row") (style_transformer.py:361,:390-397,:819,:865-882,:989,:1125):
+    out = residual + mask[b] * branch with mask = bernoulli(1-p)/(1-p) per sample (master_rowscale_add);
+  * parameters are used directly (no detached/derived copies), fused projections are torch.cat views of them.
+The tensor-identity fusions that stay valid under per-call masks are kept: q = k = v -> one [3C,C] projection; q = k -> [2C,C]; the
+Scale and Shift attention calls share q, k and the softmax (two value streams in one launch), and in layer 1 (Scale is Shift is Fs) the
+attention output is computed once and only the two row masks differ.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+import torch
+from torch import Tensor, nn
+
+from . import ops
+from .autograd import (ConvReflectFn, InstNormFn, LayerNormFn, LinearFn, MLPFn, MulAddFn, RowScaleAddFn, WindowAttnFn)
+from .window_plan import window_plan
+
+HEAD_DIM = 32
+
+
+class StochasticDepthMasks:
+    """Source of the row masks.  Default: drawn on the device the way torchvision.ops.stochastic_depth does
+    (noise = empty([B]).bernoulli_(1-p).div_(1-p)), in the order the reference's modules call it.  Parity tests install an explicit
+    list with `set_masks` (CPU and GPU random streams differ), consumed in the same order."""
+
+    def __init__(self):
+        self._explicit: Optional[List[Tensor]] = None
+        self.generator: Optional[torch.Generator] = None
+
+    def set_masks(self, masks: Optional[Sequence[Tensor]]):
+        self._explicit = list(masks) if masks is not None else None
+
+    def remaining(self) -> int:
+        return len(self._explicit) if self._explicit is not None else 0
+
+    def draw(self, B: int, p: float, device) -> Tensor:
+        if self._explicit is not None:
+            if not self._explicit:
+                raise RuntimeError("StochasticDepthMasks: the explicit mask list is exhausted")
+            return self._explicit.pop(0).to(device=device, dtype=torch.float32).contiguous()
+        keep = 1.0 - p
+        noise = torch.empty((B,), dtype=torch.float32, device=device).bernoulli_(keep, generator=self.generator)
+        if keep > 0.0:
+            noise.div_(keep)
+        return noise
+
+
+sd_masks = StochasticDepthMasks()          # the process-wide source (one model per process; parity tests install explicit masks here)
+
+
+def _residual(branch: Tensor, res: Tensor, p: float, training: bool, sd: StochasticDepthMasks, B: int, T: int) -> Tensor:
+    """res + StochasticDepth(branch)   (torchvision: identity when not training or p == 0 - no random draw then)"""
+    if training and p > 0.0:
+        mask = sd.draw(B, p, branch.device)
+    else:
+        mask = _ones(B, branch.device)
+    return RowScaleAddFn.apply(branch, res, mask, B, T)
+
+
+_ONES = {}
+
+
+def _ones(B: int, device) -> Tensor:
+    key = (B, str(device))
+    if key not in _ONES:
+        _ONES[key] = torch.ones((B,), dtype=torch.float32, device=device)
+    return _ONES[key]
+
+
+def _bias64(attn) -> Tensor:
+    """differentiable [heads,64,64] bias tile from the relative-position table (style_transformer.py:21-28); key slots >= N = -1e30"""
+    N = attn.window_size[0] * attn.window_size[1]
+    t = attn.relative_position_bias_table
+    b = t[attn.relative_position_index].view(N, N, -1).permute(2, 0, 1)                  # [heads,N,N]
+    b = torch.nn.functional.pad(b, (0, 64 - N, 0, 64 - N))
+    neg = torch.zeros((64, 64), dtype=t.dtype, device=t.device)
+    neg[:, N:] = -1e30
+    return (b + neg).contiguous()
+
+
+def _mlp(mlp: nn.Sequential, x: Tensor, norm: Optional[nn.LayerNorm] = None) -> Tensor:
+    return MLPFn.apply(x, mlp[0].weight, mlp[0].bias, mlp[3].weight, mlp[3].bias,
+                       norm.weight if norm is not None else None, norm.bias if norm is not None else None,
+                       norm.eps if norm is not None else 1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# ShiftedWindowAttention (three inputs) -> projected attention outputs, one per value stream (no residual)
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def attention(attn, xq: Tensor, xk: Tensor, xvs: Sequence[Tensor], B: int, H: int, W: int, norm: Optional[nn.LayerNorm] = None) -> List[Tensor]:
+    C = xq.shape[1]
+    T = H * W
+    plan = window_plan(H, W, attn.window_size, attn.shift_size, xq.device)
+    scale = HEAD_DIM ** -0.5
+    if norm is not None:
+        memo = []
+
+        def ln(t):
+            for src, o in memo:
+                if src is t:
+                    return o
+            o = LayerNormFn.apply(t, norm.weight, norm.bias, norm.eps)
+            memo.append((t, o))
+            return o
+        xq, xk, xvs = ln(xq), ln(xk), [ln(v) for v in xvs]
+    uniq_v: List[Tensor] = []
+    vmap = []
+    for v in xvs:
+        for i, s in enumerate(uniq_v):
+            if s is v:
+                vmap.append(i)
+                break
+        else:
+            vmap.append(len(uniq_v)); uniq_v.append(v)
+    if len(uniq_v) > 2:
+        raise NotImplementedError("at most two value streams per attention call")
+    bias64 = _bias64(attn)
+    if xq is xk and len(uniq_v) == 1 and uniq_v[0] is xq:
+        w = torch.cat([attn.Wq.weight, attn.Wk.weight, attn.Wv.weight], dim=0)
+        b = torch.cat([attn.Wq.bias, attn.Wk.bias, attn.Wv.bias], dim=0)
+        qkv = LinearFn.apply(xq, w, b)
+        o0, _ = WindowAttnFn.apply(qkv, qkv, qkv, None, attn.Wk.bias, attn.Wv.bias, None, bias64, (0, C, 2 * C, 0), plan, B, T,
+                                   attn.num_heads, scale)
+        cores = [o0]
+    else:
+        if xq is xk:
+            qk = LinearFn.apply(xq, torch.cat([attn.Wq.weight, attn.Wk.weight], dim=0), torch.cat([attn.Wq.bias, attn.Wk.bias], dim=0))
+            tq, tk, oq, ok = qk, qk, 0, C
+        else:
+            tq, tk, oq, ok = LinearFn.apply(xq, attn.Wq.weight, attn.Wq.bias), LinearFn.apply(xk, attn.Wk.weight, attn.Wk.bias), 0, 0
+        vs = [LinearFn.apply(v, attn.Wv.weight, attn.Wv.bias) for v in uniq_v]
+        v1 = vs[1] if len(vs) > 1 else None
+        o0, o1 = WindowAttnFn.apply(tq, tk, vs[0], v1, attn.Wk.bias, attn.Wv.bias, attn.Wv.bias if v1 is not None else None, bias64,
+                                    (oq, ok, 0, 0), plan, B, T, attn.num_heads, scale)
+        cores = [o0] if v1 is None else [o0, o1]
+    projected = [LinearFn.apply(c, attn.proj.weight, attn.proj.bias) for c in cores]
+    return [projected[i] for i in vmap]
+
+
+def block(blk, xq: Tensor, xk: Tensor, xvs: Sequence[Tensor], residuals: Sequence[Tensor], B, H, W, sd: StochasticDepthMasks) -> List[Tensor]:
+    """StyleSwinTransformerBlock.forward (:376-398) for one q/k pair and one or two value streams"""
+    T = H * W
+    p = blk.stochastic_depth_prob
+    branches = attention(blk.attn, xq, xk, xvs, B, H, W, norm=blk.norm1 if blk.use_norm else None)
+    outs = [_residual(br, res, p, blk.training, sd, B, T) for br, res in zip(branches, residuals)]
+    if not blk.exclude_MLP_after:
+        outs = [_residual(_mlp(blk.mlp, o, blk.norm2 if blk.use_norm else None), o, p, blk.training, sd, B, T) for o in outs]
+    return outs
+
+
+def style_encoder(enc, key: Tensor, scale: Tensor, shift: Tensor, B, H, W, sd: StochasticDepthMasks):
+    """StyleEncoder.forward (:855-912).  Mask order of the default branch: attn(Key), MLP_Key, attn(Scale), MLP_Scale, attn(Shift),
+    MLP_Shift - the fused Scale/Shift attention launch draws its two masks in that order around the MLP masks."""
+    blk = enc.shared_MHA_without_MLP
+    T = H * W
+    p_blk, p_enc, tr = blk.stochastic_depth_prob, enc.encoder_stochastic_depth_prob, enc.training
+
+    def do_key(key):
+        key = block(blk, key, key, [key], [key], B, H, W, sd)[0]                                       # :859-864
+        return _residual(_mlp(enc.encoder_MLP_Key, key), key, p_enc, tr, sd, B, T)                     # :865
+
+    def do_scale_shift(key, scale, shift):
+        # :867-882: both calls use q = k = Key: one softmax, two value streams; the residual adds draw their masks in the reference's
+        # order (attn Scale, MLP Scale, attn Shift, MLP Shift)
+        br_s, br_sh = attention(blk.attn, key, key, [scale, shift], B, H, W, norm=blk.norm1 if blk.use_norm else None)
+        s = _residual(br_s, scale, p_blk, blk.training, sd, B, T)
+        s = _residual(_mlp(enc.encoder_MLP_Scale, s), s, p_enc, tr, sd, B, T)
+        sh = _residual(br_sh, shift, p_blk, blk.training, sd, B, T)
+        sh = _residual(_mlp(enc.encoder_MLP_Shift, sh), sh, p_enc, tr, sd, B, T)
+        return s, sh
+
+    if enc.if_use_processed_Key_in_Scale_and_Shift_calculation:
+        key = do_key(key)
+        scale, shift = do_scale_shift(key, scale, shift)
+    else:
+        scale, shift = do_scale_shift(key, scale, shift)
+        key = do_key(key)
+    return key, scale, shift
+
+
+def sigma_mu(att, xq: Tensor, xk: Tensor, xs: Tensor, xsh: Tensor, B, H, W):
+    """ShiftedWindowAttention_for_decoder_last_MHA (:414-611), default flags: returns (sigma, mu)"""
+    T = H * W
+    C = xq.shape[1]
+    plan = window_plan(H, W, att.window_size, att.shift_size, xq.device)
+    q, _ = InstNormFn.apply(xq, None, B, T, 0, 1e-5)                                                # :468
+    if not att.use_Key_instance_norm_after_linear_transformation:
+        xk, _ = InstNormFn.apply(xk, None, B, T, 0, 1e-5)                                           # :470-472
+    k = LinearFn.apply(xk, att.Wk.weight, att.Wk.bias)
+    k_pad = att.Wk.bias
+    if att.use_Key_instance_norm_after_linear_transformation:
+        k, k_pad_b = InstNormFn.apply(k, att.Wk.bias, B, T, plan.n_pad, 1e-5)                       # :520-530 (padded map statistics)
+        if k_pad_b is not None:
+            k_pad = k_pad_b
+    vs = LinearFn.apply(xs, att.Wv_scale.weight, att.Wv_scale.bias)
+    vsh = LinearFn.apply(xsh, att.Wv_shift.weight, att.Wv_shift.bias)
+    o_s, o_sh = WindowAttnFn.apply(q, k, vs, vsh, k_pad, att.Wv_scale.bias, att.Wv_shift.bias, _bias64(att), (0, 0, 0, 0), plan, B, T,
+                                   att.num_heads, HEAD_DIM ** -0.5)
+    return LinearFn.apply(o_s, att.proj.weight, att.proj.bias), LinearFn.apply(o_sh, att.proj.weight, att.proj.bias)   # :575-576,:594-595
+
+
+def style_decoder(dec, fcs: Tensor, key: Tensor, scale: Tensor, shift: Tensor, B, H, W, sd: StochasticDepthMasks) -> Tensor:
+    """StyleDecoder.forward (:1045-1128), Swin sigma/mu branch"""
+    T = H * W
+    query = block(dec.MHA_self_attn, fcs, fcs, [fcs], [fcs], B, H, W, sd)[0]                          # :1047
+    q_in, _ = InstNormFn.apply(query, None, B, T, 0, 1e-5)                                            # :1056
+    k_in, _ = InstNormFn.apply(key, None, B, T, 0, 1e-5)                                              # :1057
+    sigma, mu = sigma_mu(dec.decoder_MHA_for_sigma_and_mu, q_in, k_in, scale, shift, B, H, W)         # :1059
+    query = MulAddFn.apply(query, sigma, mu)                                                          # :1123
+    p = dec.MHA_self_attn.stochastic_depth_prob       # StyleDecoder.stochastic_depth uses the same decoder_stochastic_depth_prob (:989)
+    return _residual(_mlp(dec.last_MLP, query), query, p, dec.training, sd, B, T)                     # :1125
+
+
+def style_transformer(st, fc: Tensor, fs: Tensor, k: int, B, H, W, sd: StochasticDepthMasks) -> Tensor:
+    scale = shift = fs                                                                                # :1235-1236
+    for _ in range(k):
+        fs, scale, shift = style_encoder(st.encoder, fs, scale, shift, B, H, W, sd)
+        fc = style_decoder(st.decoder, fc, fs, scale, shift, B, H, W, sd)
+    return fc
+
+
+def image_decoder(dec, x_nhwc: Tensor) -> Tensor:
+    """Decoder.forward (decoder.py:23-55,75) on an NHWC map: returns the fp32 NCHW image"""
+    last = dec.CONV_IDX[-1]
+    x = x_nhwc
+    for i in dec.CONV_IDX:
+        conv = dec.decoder[i]
+        x = ConvReflectFn.apply(x, conv.weight, conv.bias, i in dec.UPSAMPLE_BEFORE, i != last, i == last)
+    return x

@@ -13,11 +13,12 @@ SLOTS = 64  # the kernels tile a window as 64 slots; N = wh*ww <= 64 of them are
 
 
 class WindowPlan:
-    __slots__ = ("src", "region", "nW", "N", "pH", "pW", "n_pad", "shift")
+    __slots__ = ("src", "region", "nW", "N", "pH", "pW", "n_pad", "shift", "pad_ord")
 
-    def __init__(self, src, region, nW, N, pH, pW, n_pad, shift):
+    def __init__(self, src, region, nW, N, pH, pW, n_pad, shift, pad_ord=None):
         self.src, self.region, self.nW, self.N = src, region, nW, N
         self.pH, self.pW, self.n_pad, self.shift = pH, pW, n_pad, shift
+        self.pad_ord = pad_ord      # int32 [nW,64]: ordinal of a zero-padded slot among the image's n_pad padded slots (backward only)
 
 
 def _plan_numpy(H: int, W: int, ws: Tuple[int, int], shift: Tuple[int, int]):
@@ -60,8 +61,13 @@ def _plan_numpy(H: int, W: int, ws: Tuple[int, int], shift: Tuple[int, int]):
 def _plan_cached(H, W, ws, shift, device_str):
     src, region, nW, N, pH, pW, n_pad, eff = _plan_numpy(H, W, ws, shift)
     dev = torch.device(device_str)
+    pad_ord = np.full(src.shape, -1, np.int32)
+    is_pad = np.zeros(src.shape, bool)
+    is_pad[:, :N] = src[:, :N] < 0
+    pad_ord[is_pad] = np.arange(int(is_pad.sum()), dtype=np.int32)
+    assert int(is_pad.sum()) == n_pad
     return WindowPlan(torch.from_numpy(src).to(dev), None if region is None else torch.from_numpy(region).to(dev),
-                      nW, N, pH, pW, n_pad, eff)
+                      nW, N, pH, pW, n_pad, eff, torch.from_numpy(pad_ord).to(dev))
 
 
 def window_plan(H: int, W: int, ws, shift, device) -> WindowPlan:

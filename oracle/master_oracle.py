@@ -315,13 +315,14 @@ def swin_window_attention(x: Tensor, p: Dict[str, Tensor], prefix: str, ws, shif
     return _from_windows(o, src, B, H, W)
 
 
-def swin_block(x: Tensor, p: Dict[str, Tensor], prefix: str, ws, shift, nh: int) -> Tensor:
-    """x + attn(norm1 x); x + mlp(norm2 x)   (layout: load_pretrained...py:29-49)."""
+def swin_block(x: Tensor, p: Dict[str, Tensor], prefix: str, ws, shift, nh: int, sd=None) -> Tensor:
+    """x + SD(attn(norm1 x)); x + SD(mlp(norm2 x))   (layout: load_pretrained...py:29-49; torchvision's block applies
+    StochasticDepth(p_block, "row") to both branches - identity in eval mode, sd=None)."""
     C = x.shape[-1]
     n = F.layer_norm(x, (C,), p[prefix + "norm1.weight"], p[prefix + "norm1.bias"], EPS)
-    x = x + swin_window_attention(n, p, prefix + "attn.", ws, shift, nh)
+    x = x + _sd(sd, swin_window_attention(n, p, prefix + "attn.", ws, shift, nh))
     n = F.layer_norm(x, (C,), p[prefix + "norm2.weight"], p[prefix + "norm2.bias"], EPS)
-    return x + mlp(n, p, prefix + "mlp.")
+    return x + _sd(sd, mlp(n, p, prefix + "mlp."))
 
 
 def patch_merging(x: Tensor, p: Dict[str, Tensor], prefix: str) -> Tensor:
@@ -333,18 +334,26 @@ def patch_merging(x: Tensor, p: Dict[str, Tensor], prefix: str) -> Tensor:
     return F.linear(x, p[prefix + "reduction.weight"])
 
 
-def swin_encoder(img: Tensor, p: Dict[str, Tensor], prefix: str = "", ws=(7, 7), heads=(4, 8), depths=(2, 2)) -> Tensor:
+SWIN_B_SD_PROBS = tuple(0.5 * n / 23.0 for n in range(4))   # torchvision swin_b: stochastic_depth_prob 0.5 spread linearly over 24 blocks
+SWIN_SD_CALLS = 6                                            # per encoder call in train mode: blocks 1, 2, 3 (block 0 has p = 0: no draw) x 2
+
+
+def swin_encoder(img: Tensor, p: Dict[str, Tensor], prefix: str = "", ws=(7, 7), heads=(4, 8), depths=(2, 2), sd=None) -> Tensor:
     """swin_b.features[:4]: NCHW image -> NHWC [B, H/8, W/8, 256] (built in reference codes/utils.py:89-93,
-    called at codes/full_model.py:219-220)."""
+    called at codes/full_model.py:219-220).  sd: train-mode StochasticDepth masks (the frozen encoder is still in train mode in the
+    reference's trainer); a block whose probability is 0 draws nothing, like torchvision."""
     x = F.conv2d(img, p[prefix + "0.0.weight"], p[prefix + "0.0.bias"], stride=4).permute(0, 2, 3, 1)
     x = F.layer_norm(x, (x.shape[-1],), p[prefix + "0.2.weight"], p[prefix + "0.2.bias"], EPS)
+    n = 0
     for i in range(depths[0]):
         sh = (0, 0) if i % 2 == 0 else (ws[0] // 2, ws[1] // 2)
-        x = swin_block(x, p, f"{prefix}1.{i}.", ws, sh, heads[0])
+        x = swin_block(x, p, f"{prefix}1.{i}.", ws, sh, heads[0], sd if n > 0 else None)
+        n += 1
     x = patch_merging(x, p, prefix + "2.")
     for i in range(depths[1]):
         sh = (0, 0) if i % 2 == 0 else (ws[0] // 2, ws[1] // 2)
-        x = swin_block(x, p, f"{prefix}3.{i}.", ws, sh, heads[1])
+        x = swin_block(x, p, f"{prefix}3.{i}.", ws, sh, heads[1], sd if n > 0 else None)
+        n += 1
     return x
 
 

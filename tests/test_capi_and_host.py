@@ -71,7 +71,7 @@ def test_state_dict_keys_and_checkpoint_roundtrip(tmp_path, lib):
     from mastermetastyletransfer_amd import MasterStyleTransferModel
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        m = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7])
+        m = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7], allow_random_swin_encoder=True)
     for sd, shapes in ((m.style_transformer.state_dict(), O.style_transformer_shapes()),
                        (m.decoder.state_dict(), O.decoder_shapes()), (m.swin_encoder.state_dict(), O.swin_shapes())):
         assert set(sd) == set(shapes)
@@ -102,15 +102,22 @@ def test_error_behaviour_mirrors_reference(lib):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         with pytest.raises(ValueError, match="path of the pretrained weights"):
-            MasterStyleTransferModel(style_transformer_load_pretrained_weights=True)
+            MasterStyleTransferModel(style_transformer_load_pretrained_weights=True, allow_random_swin_encoder=True)
         with pytest.raises(NotImplementedError):
-            MasterStyleTransferModel(style_decoder_use_regular_MHA_instead_of_Swin_at_the_end=True)
-        m = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7]).eval()
+            MasterStyleTransferModel(style_decoder_use_regular_MHA_instead_of_Swin_at_the_end=True, allow_random_swin_encoder=True)
+        m = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7], allow_random_swin_encoder=True).eval()
     from mastermetastyletransfer_amd.ops import MasterHipError
     with pytest.raises(MasterHipError, match="no CPU fallback"):
         m(torch.zeros(1, 3, 64, 64), torch.zeros(1, 3, 64, 64))
-    m.train()
-    with pytest.raises(NotImplementedError, match="train-mode"):
+    m.train()                                # the train step exists on the GPU only, in the fp32 mode, with the encoder frozen
+    with pytest.raises(NotImplementedError, match="freeze"):
+        m(torch.zeros(1, 3, 64, 64), torch.zeros(1, 3, 64, 64))
+    for p_ in m.swin_encoder.parameters():
+        p_.requires_grad = False
+    with pytest.raises(MasterHipError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 64, 64), torch.zeros(1, 3, 64, 64))
+    m.set_compute_dtype(torch.bfloat16)
+    with pytest.raises(NotImplementedError, match="fp32 mode"):
         m(torch.zeros(1, 3, 64, 64), torch.zeros(1, 3, 64, 64))
 
 
@@ -120,3 +127,41 @@ def test_product_package_never_imports_the_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+\.*oracle", src, re.M), fn
+
+
+def test_ms_swin_block_remapper_matches_reference_table(tmp_path, lib):
+    """weights.remap_ms_swin_block against the destination -> source table the imported reference loader produced
+    (tests/golden/make_golden_remap.py), and through the model constructor's reference keyword"""
+    import sys, warnings
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden_remap import seeded_block
+    from mastermetastyletransfer_amd import MasterStyleTransferModel
+    from mastermetastyletransfer_amd.weights import remap_table, split_block
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "golden_remap.npz"))
+    want = dict(zip([str(x) for x in gold["dst"]], [str(x) for x in gold["src"]]))
+    table = {k: v for k, v in remap_table(decoder_norm_layer=True).items() if not k.endswith("relative_position_index")}
+    assert table == want
+    blk = seeded_block()
+    torch.save(blk, tmp_path / "block.pth")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7], allow_random_swin_encoder=True,
+                                     style_transformer_load_pretrained_weights=True,
+                                     style_transformer_pretrained_weights_path=str(tmp_path / "block.pth"))
+    pieces = split_block(blk)
+    sd = m.style_transformer.state_dict()
+    for dst, src in want.items():
+        assert torch.equal(sd[dst], pieces[src]), dst
+    # whole-model checkpoints as the reference's trainer writes them (train_only_inner_loop.py:382-385) load back by key
+    torch.save(m.state_dict(), tmp_path / "whole.pt")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m2 = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7], allow_random_swin_encoder=True)
+    m2.load_state_dict(torch.load(tmp_path / "whole.pt"))
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+
+def test_missing_swin_weights_fail_loudly(lib):
+    from mastermetastyletransfer_amd import MasterStyleTransferModel
+    with pytest.raises(FileNotFoundError, match="allow_random_swin_encoder"):
+        MasterStyleTransferModel()

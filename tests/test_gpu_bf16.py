@@ -99,7 +99,7 @@ def test_full_forward_bf16(cuda, B, S):
     from mastermetastyletransfer_amd import MasterStyleTransferModel
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        m = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7])
+        m = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7], allow_random_swin_encoder=True)
     sds = (seeded_state_dict(O.swin_shapes(), 31), seeded_state_dict(O.style_transformer_shapes(), 32),
            seeded_state_dict(O.decoder_shapes(), 33))
     m.swin_encoder.load_state_dict(sds[0]); m.style_transformer.load_state_dict(sds[1]); m.decoder.load_state_dict(sds[2])
@@ -274,7 +274,7 @@ def test_default_constructor_window8_both_modes(cuda, S):
     from mastermetastyletransfer_amd import MasterStyleTransferModel
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        m = MasterStyleTransferModel()
+        m = MasterStyleTransferModel(allow_random_swin_encoder=True)
     assert m.style_transformer.encoder.shared_MHA_without_MLP.attn.window_size == [8, 8]
     sds = (seeded_state_dict(O.swin_shapes(), 41), seeded_state_dict(O.style_transformer_shapes(ws=(8, 8)), 42, ws=(8, 8)), seeded_state_dict(O.decoder_shapes(), 43))
     m.swin_encoder.load_state_dict(sds[0]); m.style_transformer.load_state_dict(sds[1]); m.decoder.load_state_dict(sds[2])

@@ -188,7 +188,7 @@ def full_model(dev, seed=31):
     from mastermetastyletransfer_amd import MasterStyleTransferModel
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        m = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7])
+        m = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7], allow_random_swin_encoder=True)
     sds = (seeded_state_dict(O.swin_shapes(), seed), seeded_state_dict(O.style_transformer_shapes(), seed + 1),
            seeded_state_dict(O.decoder_shapes(), seed + 2))
     m.swin_encoder.load_state_dict(sds[0]); m.style_transformer.load_state_dict(sds[1]); m.decoder.load_state_dict(sds[2])
@@ -242,7 +242,7 @@ def test_graph_replay_matches_eager(cuda, mode):
     from mastermetastyletransfer_amd import GraphedStylizer, MasterStyleTransferModel
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        m = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7])
+        m = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7], allow_random_swin_encoder=True)
     m = m.to(cuda).eval().set_compute_dtype(torch.float32 if mode == "fp32" else torch.bfloat16)
     g = torch.Generator().manual_seed(5)
     stylize = GraphedStylizer(m, 2, 64, 96, transformer_layer_count=2)
@@ -326,7 +326,7 @@ def test_harness_chain_end_to_end(cuda):
     vgg = seeded_state_dict(L.vgg19_shapes(), 34)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        m = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7])
+        m = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7], allow_random_swin_encoder=True)
     m.swin_encoder.load_state_dict(sds[0]); m.style_transformer.load_state_dict(sds[1]); m.decoder.load_state_dict(sds[2])
     m = m.to(cuda).eval()
     crit = custom_loss(vgg_state_dict=vgg).to(cuda).eval()

@@ -1,0 +1,380 @@
+"""GPU: the train step (reference train_only_inner_loop.py:519-575) on the HIP forward + backward kernels against torch autograd on the
+CPU oracle: every backward kernel alone, then the reference-pinned golden train cases (StyleTransformer + Decoder + loss), then the whole
+model step (frozen Swin encoder with its StochasticDepth, random k, Adam).  fp32 mode; bar: <= 1e-3 of each tensor's max-abs."""
+import os
+import random
+import sys
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import loss_oracle as L
+from oracle import master_oracle as O
+from oracle import train_oracle as T
+from oracle.seeded import seeded_input, seeded_state_dict
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import make_golden_train as M                                    # noqa: E402  (case definitions only; the reference is not imported)
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def rel(got, ref):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    return float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-20)
+
+
+def check(name, got, ref, tol=TOL, floor=0.0):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    err = float((got - ref).abs().max())
+    assert err <= tol * max(float(ref.abs().max()), floor), f"{name}: max|d| {err:.3e} vs max|ref| {float(ref.abs().max()):.3e}"
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# single kernels
+# ---------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(8192, 256, 256), (1000, 768, 256), (4100, 1024, 256), (333, 256, 1024), (64, 32, 64), (50, 512, 128)])
+def test_linear_backward(cuda, M, N, K):
+    from mastermetastyletransfer_amd.autograd import LinearFn
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g, requires_grad=True)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).requires_grad_(True)
+    b = torch.randn(N, generator=g).requires_grad_(True)
+    go = torch.randn(M, N, generator=g)
+    F.linear(a, w, b).backward(go)
+    ad, wd, bd = (t.detach().to(cuda).requires_grad_(True) for t in (a, w, b))
+    out = LinearFn.apply(ad, wd, bd)
+    check("out", out, F.linear(a, w, b), 1e-4)
+    out.backward(go.to(cuda))
+    check("da", ad.grad, a.grad); check("dw", wd.grad, w.grad); check("db", bd.grad, b.grad)
+
+
+@pytest.mark.parametrize("M,C,HID,ln", [(2048, 256, 1024, True), (700, 256, 1024, False), (130, 128, 512, True)])
+def test_mlp_backward(cuda, M, C, HID, ln):
+    from mastermetastyletransfer_amd.autograd import MLPFn
+    g = torch.Generator().manual_seed(M)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).requires_grad_(True)
+    x, w1, b1, w2, b2 = mk(M, C), mk(HID, C, sc=C ** -0.5), mk(HID, sc=0.3), mk(C, HID, sc=HID ** -0.5), mk(C, sc=0.3)
+    gw, gb = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True), mk(C, sc=0.2)
+    go = torch.randn(M, C, generator=g)
+    xin = F.layer_norm(x, (C,), gw, gb, 1e-5) if ln else x
+    ref = F.linear(F.gelu(F.linear(xin, w1, b1)), w2, b2)
+    ref.backward(go)
+    leaves = [x, w1, b1, w2, b2, gw, gb]
+    dl = [t.detach().to(cuda).requires_grad_(True) for t in leaves]
+    out = MLPFn.apply(dl[0], dl[1], dl[2], dl[3], dl[4], dl[5] if ln else None, dl[6] if ln else None, 1e-5)
+    check("out", out, ref, 1e-4)
+    out.backward(go.to(cuda))
+    for n, d, r in zip("x w1 b1 w2 b2 gamma beta".split(), dl, leaves):
+        if r.grad is not None:
+            check(n, d.grad, r.grad)
+
+
+@pytest.mark.parametrize("M,C", [(1024, 256), (77, 128), (300, 512), (64, 1024)])
+def test_layernorm_backward(cuda, M, C):
+    from mastermetastyletransfer_amd.autograd import LayerNormFn
+    g = torch.Generator().manual_seed(C)
+    x = (torch.randn(M, C, generator=g) * 2 + 0.5).requires_grad_(True)
+    gw = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    gb = (0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    go = torch.randn(M, C, generator=g)
+    F.layer_norm(x, (C,), gw, gb, 1e-5).backward(go)
+    xd, wd, bd = (t.detach().to(cuda).requires_grad_(True) for t in (x, gw, gb))
+    LayerNormFn.apply(xd, wd, bd, 1e-5).backward(go.to(cuda))
+    check("dx", xd.grad, x.grad); check("dgamma", wd.grad, gw.grad); check("dbeta", bd.grad, gb.grad)
+
+
+@pytest.mark.parametrize("B,T,C,n_pad", [(2, 1024, 256, 201), (3, 64, 256, 132), (2, 100, 64, 0), (1, 4096, 128, 0)])
+def test_instnorm_backward(cuda, B, T, C, n_pad):
+    """InstanceNorm over T rows + n_pad copies of a parameter row; gradients w.r.t. x and the row (style_transformer.py:520-530)"""
+    from mastermetastyletransfer_amd.autograd import InstNormFn
+    g = torch.Generator().manual_seed(T)
+    x = (torch.randn(B * T, C, generator=g) * 1.5 + 0.3).requires_grad_(True)
+    row = (0.5 * torch.randn(C, generator=g)).requires_grad_(True)
+    go = torch.randn(B * T, C, generator=g)
+    gpad = torch.randn(B, C, generator=g)
+    ext = torch.cat([x.view(B, T, C), row.view(1, 1, C).expand(B, n_pad, C)], dim=1) if n_pad else x.view(B, T, C)
+    y = F.instance_norm(ext.permute(0, 2, 1), eps=1e-5).permute(0, 2, 1)
+    loss = (y[:, :T].reshape(B * T, C) * go).sum()
+    if n_pad:
+        loss = loss + (y[:, T] * gpad).sum() * 1.0       # every pad copy is the same row; upstream gradient = the sum over its copies
+    loss.backward()
+    xd, rd = x.detach().to(cuda).requires_grad_(True), row.detach().to(cuda).requires_grad_(True)
+    yd, pad_out = InstNormFn.apply(xd, rd if n_pad else None, B, T, n_pad, 1e-5)
+    check("y", yd, y[:, :T].reshape(B * T, C), 1e-4)
+    l2 = (yd * go.to(cuda)).sum()
+    if n_pad:
+        check("pad_out", pad_out, y[:, T], 1e-4)
+        l2 = l2 + (pad_out * gpad.to(cuda)).sum()
+    l2.backward()
+    check("dx", xd.grad, x.grad)
+    if n_pad:
+        check("drow", rd.grad, row.grad)
+
+
+def _attn_module(cuda, dim, nh, shift, seed):
+    from mastermetastyletransfer_amd import ShiftedWindowAttention
+    m = ShiftedWindowAttention(dim, nh, [7, 7], list(shift))
+    sd = seeded_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed)
+    m.load_state_dict(sd)
+    return m.to(cuda), sd
+
+
+@pytest.mark.parametrize("H,W,shift", [(7, 7, (0, 0)), (14, 14, (3, 3)), (9, 9, (4, 4)), (9, 12, (4, 4)), (14, 9, (4, 0)), (32, 32, (4, 4))])
+@pytest.mark.parametrize("mode", ["qkv", "qk_v", "q_k_v", "dual"])
+def test_window_attention_backward(cuda, H, W, shift, mode):
+    """train_forward.attention (projections + master_window_attn_bwd + proj) vs autograd through the oracle's attention: gradients of
+    the inputs, of Wq/Wk/Wv/proj (incl. the bias rows of zero-padded slots) and of the relative-position table"""
+    from mastermetastyletransfer_amd import train_forward as TF
+    dim, nh, B = 64, 2, 2
+    m, sd = _attn_module(cuda, dim, nh, shift, 31)
+    xs = [seeded_input(f"wab_{mode}_{n}", (B, H, W, dim), 31).requires_grad_(True) for n in "abcd"]
+    p = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    if mode == "qkv":
+        ins = (xs[0], xs[0], [xs[0]])
+    elif mode == "qk_v":
+        ins = (xs[0], xs[0], [xs[1]])
+    elif mode == "q_k_v":
+        ins = (xs[0], xs[1], [xs[2]])
+    else:
+        ins = (xs[0], xs[0], [xs[1], xs[2]])
+    refs = [O.shifted_window_attention(ins[0], ins[1], v, p, "", (7, 7), shift, nh) for v in ins[2]]
+    gos = [seeded_input(f"wab_go{i}", (B, H, W, dim), 32) for i in range(len(refs))]
+    sum((r * g).sum() for r, g in zip(refs, gos)).backward()
+    tok = {}
+
+    def dev(t):
+        if id(t) not in tok:
+            tok[id(t)] = t.detach().reshape(B * H * W, dim).to(cuda).requires_grad_(True)
+        return tok[id(t)]
+    outs = TF.attention(m, dev(ins[0]), dev(ins[1]), [dev(v) for v in ins[2]], B, H, W)
+    for o, r in zip(outs, refs):
+        check("out", o, r.reshape(B * H * W, dim), 1e-4)
+    sum((o * g.reshape(B * H * W, dim).to(cuda)).sum() for o, g in zip(outs, gos)).backward()
+    for t in xs:
+        if t.grad is not None:
+            check("dx", tok[id(t)].grad, t.grad.reshape(B * H * W, dim))
+    gscale = max(float(v.grad.abs().max()) for k, v in p.items() if v.is_floating_point() and v.grad is not None)
+    for n, prm in m.named_parameters():
+        check(n, prm.grad, p[n].grad, floor=1e-3 * gscale)        # Wk.bias: zero in exact arithmetic (softmax shift invariance)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 9, 9), (2, 32, 32), (1, 14, 12)])
+def test_sigma_mu_attention_backward(cuda, B, H, W):
+    from mastermetastyletransfer_amd import StyleTransformer
+    from mastermetastyletransfer_amd import train_forward as TF
+    dim, nh = 64, 2
+    st = StyleTransformer(dim, dim, nh, nh, [7, 7], [7, 7], [4, 4], [4, 4])
+    sd = seeded_state_dict(O.style_transformer_shapes(dim, nh), 41)
+    st.load_state_dict(sd)
+    att = st.decoder.decoder_MHA_for_sigma_and_mu.to(cuda)
+    pfx = "decoder.decoder_MHA_for_sigma_and_mu."
+    p = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    xs = [seeded_input(f"smb_{n}", (B, H, W, dim), 41).requires_grad_(True) for n in "abcd"]
+    rs, rm = O.sigma_mu_attention(*xs, p, pfx, (7, 7), (4, 4), nh)
+    gs, gm = seeded_input("smb_gs", (B, H, W, dim), 42), seeded_input("smb_gm", (B, H, W, dim), 43)
+    ((rs * gs).sum() + (rm * gm).sum()).backward()
+    d = [t.detach().reshape(B * H * W, dim).to(cuda).requires_grad_(True) for t in xs]
+    s, mu = TF.sigma_mu(att, *d, B, H, W)
+    check("sigma", s, rs.reshape(-1, dim), 1e-4); check("mu", mu, rm.reshape(-1, dim), 1e-4)
+    ((s * gs.reshape(-1, dim).to(cuda)).sum() + (mu * gm.reshape(-1, dim).to(cuda)).sum()).backward()
+    for t, dt in zip(xs, d):
+        check("dx", dt.grad, t.grad.reshape(-1, dim))
+    gscale = max(float(p[pfx + n].grad.abs().max()) for n, _ in att.named_parameters())
+    for n, prm in att.named_parameters():
+        check(n, prm.grad, p[pfx + n].grad, floor=1e-3 * gscale)   # Wk.bias: zero in exact arithmetic (InstanceNorm removes it)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,up,relu,nchw", [(2, 8, 8, 256, 128, False, True, False), (1, 16, 16, 128, 128, True, True, False),
+                                                         (2, 12, 20, 64, 32, True, True, False), (2, 16, 16, 32, 3, False, False, True),
+                                                         (1, 2, 2, 32, 32, True, True, False), (1, 6, 10, 128, 64, False, True, False)])
+def test_conv_reflect_backward(cuda, B, H, W, Cin, Cout, up, relu, nchw):
+    """Upsample? -> ReflectionPad -> Conv3x3 -> ReLU? (decoder.py:24-54): data, weight and bias gradients"""
+    from mastermetastyletransfer_amd.autograd import ConvReflectFn
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).requires_grad_(True)
+    b = (0.1 * torch.randn(Cout, generator=g)).requires_grad_(True)
+    xi = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    ref = F.conv2d(F.pad(xi, (1, 1, 1, 1), mode="reflect"), w, b)
+    if relu:
+        ref = F.relu(ref)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(cuda).requires_grad_(True)
+    wd, bd = w.detach().to(cuda).requires_grad_(True), b.detach().to(cuda).requires_grad_(True)
+    out = ConvReflectFn.apply(xd, wd, bd, up, relu, nchw)
+    check("out", out if nchw else out.permute(0, 3, 1, 2), ref, 1e-4)
+    out.backward((go if nchw else go.permute(0, 2, 3, 1).contiguous()).to(cuda))
+    check("dx", xd.grad.permute(0, 3, 1, 2), x.grad); check("dw", wd.grad, w.grad); check("db", bd.grad, b.grad)
+
+
+@pytest.mark.parametrize("B,H,W,dc,ds", [(2, 64, 64, "euclidian", "euclidian"), (1, 48, 80, "euclidian_squared", "euclidian_squared"),
+                                         (2, 32, 32, "euclidian", "euclidian_squared")])
+def test_perceptual_loss_backward(cuda, B, H, W, dc, ds):
+    """custom_loss with an output image that requires grad: loss values and d(total)/d(output image) vs autograd through the oracle
+    (VGG-19 data gradients, max-pool + ReLU backward, InstanceNorm'd L1/L2 and mean/std terms)"""
+    from mastermetastyletransfer_amd import custom_loss
+    sd = seeded_state_dict(L.vgg19_shapes(), 51)
+    c, s = (seeded_input(f"plb_{n}", (B, 3, H, W), 52 + i, kind="image") for i, n in enumerate("cs"))
+    o = seeded_input("plb_o", (B, 3, H, W), 55, kind="image").requires_grad_(True)
+    total, cl, sl = L.overall_loss(c, s, o, sd, 7.0, dc, ds)
+    total.backward()
+    loss = custom_loss(default_lambda_value=7.0, distance_content=dc, distance_style=ds, vgg_state_dict=sd).to(cuda)
+    od = o.detach().to(cuda).requires_grad_(True)
+    t2, c2, s2 = loss(c.to(cuda), s.to(cuda), od, output_content_and_style_loss=True)
+    assert abs(float(t2) - float(total)) <= 2e-4 * abs(float(total)) and abs(float(c2) - float(cl)) <= 2e-4 * abs(float(cl))
+    t2.backward()
+    check("d_output", od.grad, o.grad)
+
+
+def test_rowscale_and_muladd(cuda):
+    from mastermetastyletransfer_amd.autograd import MulAddFn, RowScaleAddFn
+    g = torch.Generator().manual_seed(3)
+    B, T, C = 3, 50, 64
+    x, r, q, sg, mu = (torch.randn(B * T, C, generator=g).requires_grad_(True) for _ in range(5))
+    sc = torch.tensor([0.0, 1.0 / 0.9, 1.0 / 0.9])
+    go = torch.randn(B * T, C, generator=g)
+    (r + x * sc.repeat_interleave(T)[:, None]).backward(go)
+    (q * sg + mu).backward(go)
+    d = [t.detach().to(cuda).requires_grad_(True) for t in (x, r, q, sg, mu)]
+    o1 = RowScaleAddFn.apply(d[0], d[1], sc.to(cuda), B, T)
+    o2 = MulAddFn.apply(d[2], d[3], d[4])
+    check("o1", o1, r + x * sc.repeat_interleave(T)[:, None], 1e-6); check("o2", o2, q * sg + mu, 1e-6)
+    o1.backward(go.to(cuda)); o2.backward(go.to(cuda))
+    for n, dt, t in zip("x r q sigma mu".split(), d, (x, r, q, sg, mu)):
+        check(n, dt.grad, t.grad, 1e-6)
+
+
+def test_fused_adam_and_reptile(cuda):
+    from mastermetastyletransfer_amd import FusedAdam, reptile_update
+    g = torch.Generator().manual_seed(9)
+    shapes = [(300,), (7, 5), (1024, 256), (3, 32, 3, 3), (1,)]
+    ref = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+    dev = [torch.nn.Parameter(p.detach().to(cuda)) for p in ref]
+    o1, o2 = torch.optim.Adam(ref, lr=3e-3), FusedAdam(dev, lr=3e-3)
+    for step in range(4):
+        for p, d in zip(ref, dev):
+            p.grad = torch.randn(p.shape, generator=g) * 10 ** float(torch.randint(-5, 2, (1,), generator=g))
+            d.grad = p.grad.to(cuda)
+        o1.step(); o2.step()
+    for p, d in zip(ref, dev):
+        assert torch.allclose(d.detach().cpu(), p.detach(), rtol=2e-6, atol=1e-7)
+    theta = [torch.randn(*s, generator=g) for s in shapes]
+    omega = [torch.randn(*s, generator=g) for s in shapes]
+    td = [t.to(cuda) for t in theta]
+    reptile_update(td, [o.to(cuda) for o in omega], 0.3)
+    for t, o, d in zip(theta, omega, td):
+        assert torch.allclose(d.cpu(), t + 0.3 * (o - t), rtol=1e-6, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# reference-pinned golden cases: StyleTransformer (train mode, explicit masks) -> Decoder -> custom_loss -> backward
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def _model(cuda):
+    from mastermetastyletransfer_amd import MasterStyleTransferModel
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7], allow_random_swin_encoder=True)
+    return m
+
+
+def _compare_grads(named_params, ref_grads, prefix_filter=None):
+    gscale = max(float(g.abs().max()) for g in ref_grads.values())
+    worst = 0.0
+    for n, p in named_params:
+        if n not in ref_grads:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0 or not p.requires_grad, n
+            continue
+        assert p.grad is not None, n
+        if n in M.ZERO_GRAD:
+            assert float(p.grad.abs().max()) <= 1e-4 * gscale, n
+            continue
+        e = float((p.grad.cpu() - ref_grads[n]).abs().max()) / max(float(ref_grads[n].abs().max()), 1e-6 * gscale)
+        worst = max(worst, e)
+        assert e <= TOL, f"{n}: relative gradient error {e:.3e}"
+    return worst
+
+
+@pytest.mark.parametrize("i", range(len(M.CASES)))
+def test_golden_train_cases(cuda, i):
+    from mastermetastyletransfer_amd import custom_loss
+    from mastermetastyletransfer_amd import train_forward as TF
+    from tests.test_train_oracle_cpu import GOLD, oracle_case
+    tag, B, H, W, k, dc, ds, lam, only = M.CASES[i]
+    st_sd, dec_sd, vgg_sd, fc, fs, content, style = M.case_inputs(i, B, H, W)
+    (total, cl, sl), ref_grads, ref_out = oracle_case(i)
+    m = _model(cuda)
+    m.style_transformer.load_state_dict(st_sd); m.decoder.load_state_dict(dec_sd)
+    m = m.to(cuda).train()
+    named = [("style_transformer." + n, p) for n, p in m.style_transformer.named_parameters()] + \
+            [("decoder." + n, p) for n, p in m.decoder.named_parameters()]
+    if only:
+        for n, p in named:
+            p.requires_grad = n.startswith(only)
+    loss_fn = custom_loss(default_lambda_value=lam, distance_content=dc, distance_style=ds, vgg_state_dict=vgg_sd).to(cuda)
+    TF.sd_masks.set_masks(M.case_masks(i, B, k))
+    try:
+        decoded = m.decoder(m.style_transformer(fc.to(cuda), fs.to(cuda), k).permute(0, 3, 1, 2))
+        assert TF.sd_masks.remaining() == 0
+    finally:
+        TF.sd_masks.set_masks(None)
+    check("decoded", decoded, ref_out, 1e-3)
+    t2, c2, s2 = loss_fn(content.to(cuda), style.to(cuda), decoded, output_content_and_style_loss=True)
+    for got, want in ((t2, total), (c2, cl), (s2, sl)):
+        assert abs(float(got) - want) <= 5e-4 * abs(want), (float(got), want)
+    assert np.allclose([float(t2), float(c2), float(s2)], GOLD[f"{tag}_loss"], rtol=1e-3)     # the reference's own numbers
+    t2.backward()
+    worst = _compare_grads(named, ref_grads)
+    print(f"{tag}: worst relative gradient error {worst:.2e}")
+
+
+@pytest.mark.parametrize("B,S", [(2, 64), (8, 256)])
+def test_full_train_step(cuda, B, S):
+    """MasterStyleTransferModel in train mode (frozen Swin encoder with its StochasticDepth, k from random.seed(0)), custom_loss,
+    backward, FusedAdam step - against the oracle's autograd step with the same masks (BASELINE config 4 at B=8, 256^2)."""
+    from mastermetastyletransfer_amd import FusedAdam, custom_loss
+    from mastermetastyletransfer_amd import train_forward as TF
+    sds = (seeded_state_dict(O.swin_shapes(), 1), seeded_state_dict(O.style_transformer_shapes(), 2), seeded_state_dict(O.decoder_shapes(), 3))
+    vgg = seeded_state_dict(L.vgg19_shapes(), 4)
+    c = seeded_input("fts_c", (B, 3, S, S), 5, kind="image"); s = seeded_input("fts_s", (B, 3, S, S), 6, kind="image")
+    random.seed(0)
+    k = random.randint(1, 2)                                        # train_only_inner_loop.py:519 with max_layers = 2
+    g = torch.Generator().manual_seed(7)
+    probs = [p for p in O.SWIN_B_SD_PROBS if p > 0]
+    swin_masks = [torch.empty(B).bernoulli_(1 - p, generator=g).div_(1 - p) for _ in range(2) for p in probs for _ in range(2)]
+    masks = O.SDMasks.draw(O.SD_CALLS_PER_LAYER * k, B, 0.1, g)
+    losses, ref_grads = T.train_step_grads(c, s, k, *sds, vgg, masks, 10.0, swin_masks=swin_masks)
+    m = _model(cuda)
+    m.swin_encoder.load_state_dict(sds[0]); m.style_transformer.load_state_dict(sds[1]); m.decoder.load_state_dict(sds[2])
+    m = m.to(cuda).train()
+    for p in m.swin_encoder.parameters():                           # train_only_inner_loop.py:254-257
+        p.requires_grad = False
+    loss_fn = custom_loss(default_lambda_value=10.0, vgg_state_dict=vgg).to(cuda)
+    opt = FusedAdam([{"params": m.style_transformer.parameters()}, {"params": m.decoder.parameters()}], lr=1e-3)
+    TF.sd_masks.set_masks(swin_masks + masks)
+    try:
+        out = m(c.to(cuda), s.to(cuda), k)
+        assert TF.sd_masks.remaining() == 0
+    finally:
+        TF.sd_masks.set_masks(None)
+    check("output", out, losses["output"], 1e-3)
+    total, cl, sl = loss_fn(c.to(cuda), s.to(cuda), out, output_content_and_style_loss=True)
+    assert abs(float(total) - float(losses["total"])) <= 5e-4 * abs(float(losses["total"]))
+    opt.zero_grad(); total.backward()
+    named = [("style_transformer." + n, p) for n, p in m.style_transformer.named_parameters()] + \
+            [("decoder." + n, p) for n, p in m.decoder.named_parameters()]
+    worst = _compare_grads(named, ref_grads)
+    print(f"B={B} S={S} k={k}: loss {float(total):.4f}, worst relative gradient error {worst:.2e}")
+    # Adam: the device optimizer on ITS gradients vs the oracle's Adam on the same (device) gradients
+    before = {n: p.detach().cpu().clone() for n, p in named}
+    dev_grads = {n: p.grad.detach().cpu().clone() for n, p in named}
+    opt.step()
+    T.adam_step(before, dev_grads, {}, 1e-3, 1)
+    for n, p in named:
+        assert torch.allclose(p.detach().cpu(), before[n], rtol=1e-5, atol=2e-7), n
