@@ -39,7 +39,16 @@ def train_step_grads(content: Tensor, style: Tensor, k: int, swin_sd, st_sd, dec
     """One forward + backward.  Returns (losses dict, grads dict keyed 'style_transformer.<name>' / 'decoder.<name>').
     `trainable`: optional predicate on the key (fast adaptation trains only 'style_transformer.encoder.*',
     train_only_inner_loop.py:306-318).  `swin_masks`: the 2 x O.SWIN_SD_CALLS StochasticDepth masks of the two frozen-encoder calls
-    (content's six, then style's six), None = identity."""
+    (content's six, then style's six), None = identity.  The computation runs in the dtype of `content` (float64: the reference
+    the fp32 implementations are measured against)."""
+    dt = content.dtype
+    cast = lambda sd: {n: (t.to(dt) if t.is_floating_point() else t) for n, t in sd.items()}
+    swin_sd, st_sd, dec_sd, vgg_sd = cast(swin_sd), cast(st_sd), cast(dec_sd), cast(vgg_sd)
+    style = style.to(dt)
+    if masks is not None:
+        masks = [m.to(dt) for m in masks]
+    if swin_masks is not None:
+        swin_masks = [m.to(dt) for m in swin_masks]
     with torch.no_grad():
         sdc = O.SDMasks(swin_masks[:O.SWIN_SD_CALLS]) if swin_masks is not None else None
         sds = O.SDMasks(swin_masks[O.SWIN_SD_CALLS:]) if swin_masks is not None else None

@@ -29,7 +29,7 @@ def rel(got, ref):
 
 
 def check(name, got, ref, tol=TOL, floor=0.0):
-    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
     err = float((got - ref).abs().max())
     assert err <= tol * max(float(ref.abs().max()), floor), f"{name}: max|d| {err:.3e} vs max|ref| {float(ref.abs().max()):.3e}"
@@ -225,12 +225,21 @@ def test_perceptual_loss_backward(cuda, B, H, W, dc, ds):
     o = seeded_input("plb_o", (B, 3, H, W), 55, kind="image").requires_grad_(True)
     total, cl, sl = L.overall_loss(c, s, o, sd, 7.0, dc, ds)
     total.backward()
+    o64 = o.detach().double().requires_grad_(True)           # float64 evaluation: the reference for the image gradient
+    L.overall_loss(c.double(), s.double(), o64, {k_: v.double() for k_, v in sd.items()}, 7.0, dc, ds)[0].backward()
     loss = custom_loss(default_lambda_value=7.0, distance_content=dc, distance_style=ds, vgg_state_dict=sd).to(cuda)
     od = o.detach().to(cuda).requires_grad_(True)
     t2, c2, s2 = loss(c.to(cuda), s.to(cuda), od, output_content_and_style_loss=True)
     assert abs(float(t2) - float(total)) <= 2e-4 * abs(float(total)) and abs(float(c2) - float(cl)) <= 2e-4 * abs(float(cl))
     t2.backward()
-    check("d_output", od.grad, o.grad)
+    # Reference = the float64 oracle: with small maps the fp32 CPU oracle itself is up to 1.7e-2 off (InstanceNorm of nearly constant
+    # channels; case 1x48x80, profiles/r02_grad_conditioning.txt).  |x| has a discontinuous derivative: where IN(Fc) - IN(Fcs) is at
+    # rounding level an element's gradient flips by 2/(B*C*HW), so the L1 distances carry isolated differences of ~1e-3 of the
+    # maximum (measured 1.02e-3) and are held to 1e-3 in L2 and 4e-3 on the maximum; the smooth squared distances to 1e-3 on both.
+    got, ref = od.grad.cpu().double(), o64.grad
+    l2 = float((got - ref).norm() / ref.norm())
+    assert l2 <= 1e-3, l2
+    check("d_output", got, ref, 1e-3 if dc == "euclidian_squared" and ds == "euclidian_squared" else 4e-3)
 
 
 def test_rowscale_and_muladd(cuda):
@@ -284,21 +293,30 @@ def _model(cuda):
     return m
 
 
-def _compare_grads(named_params, ref_grads, prefix_filter=None):
-    gscale = max(float(g.abs().max()) for g in ref_grads.values())
-    worst = 0.0
+def _compare_grads(named_params, ref64, ref32):
+    """The gradient of this loss is ill-conditioned in fp32: |.| distances and ReLU/max-pool switches are discontinuous, and
+    InstanceNorm (eps 1e-5) amplifies rounding on nearly constant channels - the fp32 CPU oracle itself sits ~1e-3 (relative to each
+    tensor's max-abs) from its float64 evaluation (profiles/r02_grad_conditioning.txt).  So both fp32 implementations are measured
+    against the float64 oracle: every HIP gradient within max(3e-3, 4x the CPU-fp32 error) and the median over the tensors within
+    max(1e-3, 2x the CPU-fp32 median).  (Each backward kernel alone meets 1e-3 against torch autograd: the tests above.)"""
+    gscale = max(float(g.abs().max()) for g in ref64.values())
+    eh, ec = [], []
     for n, p in named_params:
-        if n not in ref_grads:
+        if n not in ref64:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0 or not p.requires_grad, n
             continue
         assert p.grad is not None, n
         if n in M.ZERO_GRAD:
             assert float(p.grad.abs().max()) <= 1e-4 * gscale, n
             continue
-        e = float((p.grad.cpu() - ref_grads[n]).abs().max()) / max(float(ref_grads[n].abs().max()), 1e-6 * gscale)
-        worst = max(worst, e)
-        assert e <= TOL, f"{n}: relative gradient error {e:.3e}"
-    return worst
+        den = max(float(ref64[n].abs().max()), 1e-6 * gscale)
+        h = float((p.grad.cpu().double() - ref64[n]).abs().max()) / den
+        c = float((ref32[n].double() - ref64[n]).abs().max()) / den
+        assert h <= max(3e-3, 4 * c), f"{n}: HIP gradient error vs float64 {h:.3e} (CPU fp32: {c:.3e})"
+        eh.append(h); ec.append(c)
+    mh, mc = float(np.median(eh)), float(np.median(ec))
+    assert mh <= max(1e-3, 2 * mc), (mh, mc)
+    return max(eh), mh, max(ec), mc
 
 
 @pytest.mark.parametrize("i", range(len(M.CASES)))
@@ -308,7 +326,8 @@ def test_golden_train_cases(cuda, i):
     from tests.test_train_oracle_cpu import GOLD, oracle_case
     tag, B, H, W, k, dc, ds, lam, only = M.CASES[i]
     st_sd, dec_sd, vgg_sd, fc, fs, content, style = M.case_inputs(i, B, H, W)
-    (total, cl, sl), ref_grads, ref_out = oracle_case(i)
+    (total, cl, sl), ref32, ref_out = oracle_case(i)
+    _, ref64, _ = oracle_case(i, torch.float64)
     m = _model(cuda)
     m.style_transformer.load_state_dict(st_sd); m.decoder.load_state_dict(dec_sd)
     m = m.to(cuda).train()
@@ -330,8 +349,8 @@ def test_golden_train_cases(cuda, i):
         assert abs(float(got) - want) <= 5e-4 * abs(want), (float(got), want)
     assert np.allclose([float(t2), float(c2), float(s2)], GOLD[f"{tag}_loss"], rtol=1e-3)     # the reference's own numbers
     t2.backward()
-    worst = _compare_grads(named, ref_grads)
-    print(f"{tag}: worst relative gradient error {worst:.2e}")
+    wh, mh, wc, mc = _compare_grads(named, ref64, ref32)
+    print(f"{tag}: gradient error vs float64 oracle: HIP worst {wh:.2e} median {mh:.2e} | CPU fp32 oracle worst {wc:.2e} median {mc:.2e}")
 
 
 @pytest.mark.parametrize("B,S", [(2, 64), (8, 256)])
@@ -349,7 +368,8 @@ def test_full_train_step(cuda, B, S):
     probs = [p for p in O.SWIN_B_SD_PROBS if p > 0]
     swin_masks = [torch.empty(B).bernoulli_(1 - p, generator=g).div_(1 - p) for _ in range(2) for p in probs for _ in range(2)]
     masks = O.SDMasks.draw(O.SD_CALLS_PER_LAYER * k, B, 0.1, g)
-    losses, ref_grads = T.train_step_grads(c, s, k, *sds, vgg, masks, 10.0, swin_masks=swin_masks)
+    losses, ref32 = T.train_step_grads(c, s, k, *sds, vgg, masks, 10.0, swin_masks=swin_masks)
+    _, ref64 = T.train_step_grads(c.double(), s.double(), k, *sds, vgg, masks, 10.0, swin_masks=swin_masks)
     m = _model(cuda)
     m.swin_encoder.load_state_dict(sds[0]); m.style_transformer.load_state_dict(sds[1]); m.decoder.load_state_dict(sds[2])
     m = m.to(cuda).train()
@@ -369,8 +389,9 @@ def test_full_train_step(cuda, B, S):
     opt.zero_grad(); total.backward()
     named = [("style_transformer." + n, p) for n, p in m.style_transformer.named_parameters()] + \
             [("decoder." + n, p) for n, p in m.decoder.named_parameters()]
-    worst = _compare_grads(named, ref_grads)
-    print(f"B={B} S={S} k={k}: loss {float(total):.4f}, worst relative gradient error {worst:.2e}")
+    wh, mh, wc, mc = _compare_grads(named, ref64, ref32)
+    print(f"B={B} S={S} k={k}: loss {float(total):.4f}; gradient error vs float64 oracle: HIP worst {wh:.2e} median {mh:.2e} | "
+          f"CPU fp32 oracle worst {wc:.2e} median {mc:.2e}")
     # Adam: the device optimizer on ITS gradients vs the oracle's Adam on the same (device) gradients
     before = {n: p.detach().cpu().clone() for n, p in named}
     dev_grads = {n: p.grad.detach().cpu().clone() for n, p in named}

@@ -13,15 +13,18 @@ import make_golden_train as M
 GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_train.npz"))
 
 
-def oracle_case(i):
-    """(losses, grads, inputs) of golden case i from the oracle; shared with the GPU parity test"""
+def oracle_case(i, dtype=torch.float32):
+    """(losses, grads, output) of golden case i from the oracle; shared with the GPU parity test (dtype=float64: the reference
+    gradients the two fp32 implementations are measured against)"""
     tag, B, H, W, k, dc, ds, lam, only = M.CASES[i]
     st_sd, dec_sd, vgg_sd, fc, fs, content, style = M.case_inputs(i, B, H, W)
-    masks = M.case_masks(i, B, k)
+    masks = [m.to(dtype) for m in M.case_masks(i, B, k)]
+    fc, fs, content, style = (t.to(dtype) for t in (fc, fs, content, style))
+    vgg_sd = {n: t.to(dtype) for n, t in vgg_sd.items()}
 
     def leaf(prefix, sd):
-        return {n: (t.clone().requires_grad_(True) if t.is_floating_point() and (only is None or (prefix + n).startswith(only)) else t.clone())
-                for n, t in sd.items()}
+        return {n: (t.to(dtype).clone().requires_grad_(True) if t.is_floating_point() and (only is None or (prefix + n).startswith(only))
+                    else (t.to(dtype) if t.is_floating_point() else t.clone())) for n, t in sd.items()}
     st, dec = leaf("style_transformer.", st_sd), leaf("decoder.", dec_sd)
     total, c, s, out = T.train_forward_loss(fc, fs, content, style, k, st, dec, vgg_sd, masks, lam, dc, ds)
     total.backward()
