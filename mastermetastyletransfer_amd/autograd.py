@@ -50,6 +50,8 @@ def linear_dgrad(g: Tensor, w: Tensor, gelu_pre: Optional[Tensor] = None) -> Ten
     M, N = g.shape
     K = w.shape[1]
     da = torch.empty((M, K), dtype=F, device=g.device)
+    if ops._COUNT_ON:
+        ops._count("linear_bwd", flops=2.0 * M * N * K, bytes=4.0 * (M * N + N * K + M * K * (1 + (gelu_pre is not None))))
     _check(load_library().master_linear_dgrad(_p(g), _p(w), _p(da), _p(gelu_pre), M, N, K, g.stride(0), K, K, F32, _stream()),
            "master_linear_dgrad")
     return da
@@ -63,6 +65,8 @@ def linear_wgrad(g: Tensor, a: Tensor) -> Tensor:
     dw = torch.empty((N, K), dtype=F, device=g.device)
     nws = lib.master_gemm_workspace_floats(N, K)
     ws = _ws(nws, g.device)
+    if ops._COUNT_ON:
+        ops._count("linear_bwd", flops=2.0 * M * N * K, bytes=4.0 * (M * N + M * K + N * K))
     _check(lib.master_linear_wgrad(_p(g), _p(a), _p(dw), M, N, K, g.stride(0), a.stride(0), _p(ws), ws.numel(), F32, _stream()),
            "master_linear_wgrad")
     return dw
@@ -305,6 +309,10 @@ class WindowAttnFn(torch.autograd.Function):
         v1 = bv1[:, ov1:ov1 + C] if dual else None
         kbs = kp.stride(0) if kp.dim() == 2 else 0
         vbs = v0p.stride(0) if v0p.dim() == 2 else 0
+        if ops._COUNT_ON:
+            nv = 2 if dual else 1
+            ops._count("window_attn_bwd", flops=2.0 * B * plan.nW * heads * plan.N * plan.N * 32 * (4 + 3 * nv),
+                       bytes=4.0 * B * T * C * (2 + 2 * nv) * 2)
         with torch.cuda.device(dev):
             _check(load_library().master_window_attn_bwd(
                 _p(q), _p(k), _p(v0), _p(v1), q.stride(0), k.stride(0), v0.stride(0), _p(kp), _p(v0p), _p(v1p), kbs, vbs, _p(bias64),
@@ -363,6 +371,8 @@ def conv_backward(g: Tensor, y_relu: Optional[Tensor], x: Tensor, weight: Tensor
     if need_dw:
         dwp = torch.empty((Cp, 3, 3, Cin), dtype=F, device=dev)
         ws = _ws(lib.master_gemm_workspace_floats(Cp, 9 * Cin), dev)
+        if ops._COUNT_ON:
+            ops._count("conv_wgrad", flops=2.0 * B * H * W * Cout * 9 * Cin, bytes=4.0 * (B * H * W * Cout + x.numel() + Cout * 9 * Cin))
         _check(lib.master_conv3x3_wgrad(_p(gm), _p(x), _p(dwp), B, Hin, Win, Cin, Cp, Cp, up, 0 if reflect else 1, _p(ws), ws.numel(), F32,
                                         _stream()), "master_conv3x3_wgrad")
         dw = dwp[:Cout].permute(0, 3, 1, 2).contiguous()                               # [Cout,3,3,Cin] -> [Cout,Cin,3,3]
@@ -372,6 +382,8 @@ def conv_backward(g: Tensor, y_relu: Optional[Tensor], x: Tensor, weight: Tensor
         if Cp != Cout:
             wf = torch.nn.functional.pad(wf, (0, Cp - Cout))
         wf = wf.contiguous()
+        if ops._COUNT_ON:
+            ops._count("conv_dgrad", flops=2.0 * B * H * W * Cout * 9 * Cin, bytes=4.0 * (B * H * W * (Cout + Cin) + Cout * 9 * Cin))
         if reflect:
             dxp = torch.empty((B, H + 2, W + 2, Cin), dtype=F, device=dev)
             _check(lib.master_conv3x3_dgrad(_p(gm), _p(wf), _p(dxp), None, None, B, H, W, Cp, Cin, 1, F32, _stream()), "master_conv3x3_dgrad")
@@ -527,6 +539,10 @@ class PerceptualLossFn(torch.autograd.Function):
                 Cx = w.shape[1]
                 wf = w.flip(2, 3).permute(1, 2, 3, 0).contiguous()                    # [Cx][3][3][Cg]
                 dx = torch.empty((Bn, H, W, Cx), dtype=F, device=dev)
+                if ops._COUNT_ON:      # algorithmic: the convolution's real channel counts (the 3-channel image is computed padded to 32)
+                    cx_real = ctx.weights[widx[i]].shape[1]
+                    ops._count("conv_dgrad", flops=2.0 * Bn * H * W * Cg * 9 * cx_real,
+                               bytes=4.0 * (Bn * H * W * (Cg + cx_real * (1 + (relu_src is not None) + (add is not None))) + Cg * 9 * cx_real))
                 _check(lib.master_conv3x3_dgrad(_p(g), _p(wf), _p(dx), _p(relu_src), _p(add), Bn, H, W, Cg, Cx, 0, F32, _stream()),
                        "master_conv3x3_dgrad")
                 g = dx

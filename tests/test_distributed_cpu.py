@@ -47,6 +47,58 @@ def _worker(rank, world, port, batch, q):
         dist.destroy_process_group()
 
 
+def _oracle_forward(c, s, k):
+    """a REAL forward per rank: the CPU oracle of the whole path (Swin-B[:2 stages] -> StyleTransformer -> decoder) with seeded
+    weights - on the GPU box the same driver code shards MasterStyleTransferModel.forward"""
+    from oracle import master_oracle as O
+    from oracle.seeded import seeded_state_dict
+    sds = (seeded_state_dict(O.swin_shapes(), 1), seeded_state_dict(O.style_transformer_shapes(), 2), seeded_state_dict(O.decoder_shapes(), 3))
+    with torch.no_grad():
+        return O.full_forward(c, s, k, *sds)
+
+
+def _worker_real(rank, world, port, batch, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.seeded import seeded_input
+        c = seeded_input("dist_c", (batch, 3, 32, 32), 5, kind="image"); s = seeded_input("dist_s", (batch, 3, 32, 32), 6, kind="image")
+        out = ShardedStylizer(_oracle_forward, rank, world)(c, s, 1)
+        # rank ids through the same collective the bench uses to prove every rank is connected
+        ids = torch.empty((world,), dtype=torch.int64)
+        dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int64))
+        lo, hi = shard_range(batch, rank, world)
+        mine = _oracle_forward(c[lo:hi], s[lo:hi], 1)
+        whole = _oracle_forward(c, s, 1) if rank == 0 else None
+        q.put((rank, tuple(out.shape), ids.tolist(), bool(torch.equal(out[lo:hi], mine)),
+               float((out - whole).abs().max()) if whole is not None else 0.0, out.numpy().tobytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("batch", [4, 3])
+def test_world_size_2_gloo_real_forward(batch):
+    """every rank ends with the SAME gathered batch, bit for bit; each shard inside it is bit-identical to that rank's own forward; and
+    the gathered batch equals the single-process forward of the whole batch (per-sample ops: only the BLAS blocking of a different batch size differs: <= 1e-4 on outputs of magnitude 3)"""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_real, args=(r, 2, port, batch, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == [0, 1]
+    for rank, shape, ids, shard_equal, err, _ in res:
+        assert shape == (batch, 3, 32, 32) and ids == [0, 1] and shard_equal and err <= 1e-4, (rank, shape, ids, shard_equal, err)
+    assert res[0][5] == res[1][5], "ranks disagree on the gathered batch"
+
+
 @pytest.mark.parametrize("batch", [8, 5])
 def test_world_size_2_gloo(batch):
     with socket.socket() as sk:

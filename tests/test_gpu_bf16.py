@@ -111,8 +111,14 @@ def test_full_forward_bf16(cuda, B, S):
         ref = O.full_forward(c, s, 1, *sds)
     assert got.dtype == torch.float32 and got.shape == ref.shape
     mx, l2 = rel_err(got, ref)
-    print(f"bf16 full forward B={B} S={S}: max|d|/max|ref| = {mx:.3e}, relative L2 = {l2:.3e}, max|d| = {(got.cpu()-ref).abs().max():.3e}")
-    assert l2 < 5e-2 and mx < 0.25, (mx, l2)
+    # what the bf16 error is in an image: 8-bit grey levels after the harness's clip(x * 255).astype(uint8) (test_model.py:207)
+    q = lambda t: (t.cpu() * 255.0).clamp(0, 255).to(torch.uint8).float()
+    dq = (q(got) - q(ref)).abs()
+    print(f"bf16 full forward B={B} S={S}: max|d|/max|ref| = {mx:.3e}, relative L2 = {l2:.3e}, max|d| = {(got.cpu()-ref).abs().max():.3e}; "
+          f"uint8 image: mean |d| {dq.mean():.2f} levels, max {dq.max():.0f}, {100 * (dq > 2).float().mean():.2f}% of values off by > 2 levels")
+    # bounds = what is measured (rel. L2 1.6-1.8e-2, max 2.5e-2 of max|ref|) plus margin; a broken layer shows up as >= 1e-1
+    assert l2 < 2.5e-2 and mx < 0.05, (mx, l2)
+    assert dq.mean() < 2.5 and dq.max() <= 0.05 * 255 * max(1.0, float(ref.abs().max())), (float(dq.mean()), float(dq.max()))
     # switching back to fp32 restores the parity-mode result (derived-weight caches are keyed by dtype)
     m.set_compute_dtype(torch.float32)
     with torch.no_grad():

@@ -217,10 +217,13 @@ def test_full_forward_vs_oracle(cuda, B, S, k):
     print(f"full forward B={B} S={S} k={k}: max|d| = {err:.2e}, ref max {ref.abs().max():.2f}")
 
 
-def test_full_batch_32_properties(cuda):
-    """BASELINE configs[1] size (bs=32, 256x256): per-sample independence and determinism - sample i of the
-    batch equals the same pair run alone (no cross-sample statistics anywhere on the path), bitwise repeatable."""
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_full_batch_32_properties(cuda, mode):
+    """BASELINE configs[1] at its own size AND dtype (bs=32, 256x256, bf16; and the fp32 parity mode): per-sample independence and
+    determinism - sample i of the batch equals the same pair run alone (no cross-sample statistics anywhere on the path), bitwise
+    repeatable - and samples of the batch against the CPU oracle (fp32: 1e-3 max-abs; bf16: the bench's relative-L2 bound)."""
     m, (swin_sd, st_sd, dec_sd) = full_model(cuda)
+    m.set_compute_dtype(torch.float32 if mode == "fp32" else torch.bfloat16)
     c = seeded_input("c32", (32, 3, 256, 256), 10, kind="image").to(cuda)
     s = seeded_input("s32", (32, 3, 256, 256), 11, kind="image").to(cuda)
     with torch.no_grad():
@@ -230,8 +233,14 @@ def test_full_batch_32_properties(cuda):
         for i in (0, 13, 31):
             one = m(c[i:i + 1], s[i:i + 1], 1)
             assert torch.equal(one, full[i:i + 1]), f"sample {i} depends on its batch"
-        ref = O.full_forward(c[5:6].cpu(), s[5:6].cpu(), 1, swin_sd, st_sd, dec_sd)
-    assert_close(full[5:6], ref, "sample 5 of the bs=32 batch")
+        for i in (5, 31):
+            ref = O.full_forward(c[i:i + 1].cpu(), s[i:i + 1].cpu(), 1, swin_sd, st_sd, dec_sd)
+            if mode == "fp32":
+                assert_close(full[i:i + 1], ref, f"sample {i} of the bs=32 batch")
+            else:
+                l2 = float((full[i:i + 1].cpu() - ref).norm() / ref.norm())
+                mx = float((full[i:i + 1].cpu() - ref).abs().max() / ref.abs().max())
+                assert l2 < 2.5e-2 and mx < 0.05, (i, l2, mx)
 
 
 @pytest.mark.gpu
@@ -345,3 +354,49 @@ def test_harness_chain_end_to_end(cuda):
     assert np.allclose([float(total), float(cl), float(sl)], [float(rt), float(rcl), float(rsl)], rtol=5e-4)
     ref8 = IO.postprocess(ro.numpy())
     assert np.abs(img8.astype(int) - ref8.astype(int)).max() <= 1                       # a 1e-3 fp difference can cross a truncation boundary
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# torchvision pin (Swin-B features[:4] and VGG-19 cfg "E" live in torchvision, which the reference does not vendor or
+# pin): where the GPU box has torchvision, the oracle's restatement AND the HIP path are checked against torchvision's own modules
+# with the same seeded weights.  torchvision is a third-party library, not the reference; nothing is vendored.  Skips where absent
+# (this image has none: the skip is recorded in DESIGN.md as "parity unpinned" for that stage).
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def test_swin_encoder_vs_torchvision(cuda):
+    tv = pytest.importorskip("torchvision")
+    from torchvision.models import swin_b
+    net = swin_b(weights=None).features[:4].eval()
+    sd = seeded_state_dict(O.swin_shapes(), 1)
+    missing = net.load_state_dict(sd, strict=True)
+    img = seeded_input("tv_swin", (2, 3, 128, 128), 7, kind="image")
+    with torch.no_grad():
+        ref = net(img)
+        assert_close(O.swin_encoder(img, sd), ref, "oracle swin_encoder vs torchvision", 2e-5)
+        m, _ = full_model(cuda)
+        m.swin_encoder.load_state_dict(sd)
+        assert_close(m.swin_encoder(img.to(cuda)), ref, "HIP swin encoder vs torchvision", 2e-4)
+
+
+def test_vgg19_vs_torchvision(cuda):
+    tv = pytest.importorskip("torchvision")
+    from torchvision.models import vgg19
+    from oracle import loss_oracle as L
+    from mastermetastyletransfer_amd import VGG19_custom
+    net = vgg19(weights=None).features[:30].eval()
+    sd = seeded_state_dict(L.vgg19_shapes(), 4)
+    net.load_state_dict(sd, strict=True)
+    img = seeded_input("tv_vgg", (2, 3, 64, 64), 8, kind="image")
+    taps_at = (6, 11, 20, 29)
+    with torch.no_grad():
+        refs, x = [], img
+        for i, layer in enumerate(net):
+            x = layer(x)
+            if i in taps_at:
+                refs.append(x.clone())
+        for a, b in zip(L.vgg19_features(img, sd), refs):
+            assert_close(a, b, "oracle VGG-19 vs torchvision", 2e-5)
+        v = VGG19_custom()
+        v.features.load_state_dict(sd)
+        v = v.to(cuda)
+        for a, b in zip(v(img.to(cuda)), refs):
+            assert_close(a.permute(0, 3, 1, 2), b, "HIP VGG-19 vs torchvision", 2e-4)
