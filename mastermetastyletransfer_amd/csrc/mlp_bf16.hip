@@ -89,6 +89,12 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
 #define SW128(i) ((l7 ^ (((row0b + 8 * (i)) >> 1) & 7)) << 4)
     const int sw256_0 = SW256(0), sw256_1 = SW256(1), sw256_2 = SW256(2), sw256_3 = SW256(3);
     const int sw128_0 = SW128(0), sw128_1 = SW128(1);
+    // per-lane byte offsets of the lane's first row, fixed for the whole kernel (one multiply each, here): a stream step then only
+    // derives a wave-uniform base pointer with scalar arithmetic.  (r02: this address setup used to be redone per step in vector
+    // registers - 350 clocks x 32 steps = 10 % of the workgroup's time in the clock probe.)
+    const int vrow_w1 = row0 * (C * 2);
+    const int vrow_w2 = (ROW2 == 128 ? row0b : row0) * (p.HID * 2);
+    const int pstride_w1 = 4 * C * 2, pstride_w2 = (ROW2 == 128 ? 8 : 4) * p.HID * 2;
     const char* d_base = nullptr; int d_pstride = 0, d_vrow = 0; bool d_128 = false, d_valid = false; unsigned char* d_slot = nullptr;
     auto set_dma_step = [&](int t) __attribute__((always_inline)) {
         d_valid = t < T;
@@ -100,11 +106,14 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
             else { is_w1 = false; hc = b; idx = b < nhc - 1 ? o - KB : o; }
         }
         d_slot = lds + (t % RING) * SLOT + wave * DMA_PER_STEP * 1024;
-        if (is_w1) { d_base = (const char*)(p.w1 + (size_t)hc * 128 * C + idx * 128); d_pstride = 4 * C * 2; d_vrow = row0 * (C * 2); d_128 = false; }
-        else {
-            d_base = (const char*)(p.w2 + hc * 128 + (ROW2 == 128 ? idx * JB2 : 0));
-            d_pstride = (ROW2 == 128 ? 8 : 4) * p.HID * 2; d_vrow = (ROW2 == 128 ? row0b : row0) * (p.HID * 2); d_128 = ROW2 == 128;   // byte offset of this lane's first row
-        }
+        // mask arithmetic, not a ternary on two variables: hipcc turns such a select into a private table in scratch memory
+        const int mk = -(int)is_w1;
+        d_pstride = (pstride_w1 & mk) | (pstride_w2 & ~mk);
+        d_vrow = (vrow_w1 & mk) | (vrow_w2 & ~mk);
+        d_128 = !is_w1 && ROW2 == 128;
+        const char* b1p = (const char*)(p.w1 + (size_t)hc * 128 * C + idx * 128);
+        const char* b2p = (const char*)(p.w2 + hc * 128 + (ROW2 == 128 ? idx * JB2 : 0));
+        d_base = (const char*)(((size_t)b1p & (size_t)(long long)mk) | ((size_t)b2p & ~(size_t)(long long)mk));
     };
     auto dma_piece = [&](int i) __attribute__((always_inline)) {
         if (!d_valid) return;
@@ -122,6 +131,15 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
         for (int i = 0; i < DMA_PER_STEP; ++i) dma_piece(i);
     };
 
+    // ---- X fragments (B operand of phase 1): lane (token m, half h) holds x[m][16s + 8h .. +8].  Requested BEFORE the first DMA burst:
+    //      loads return in order, so behind 96 KB of weights they would arrive ~1.5 k clocks later and the LayerNorm with them --------
+    Frag xf[KS1];
+    {
+        const bf16_t* xp = p.x + (size_t)mc * p.ldx + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) xf[s].u = *(const u32x4*)(xp + 16 * s);
+    }
+
     int t_issue = 0;
     for (; t_issue < AHEAD && t_issue < T; ++t_issue) issue(t_issue);
 
@@ -133,12 +151,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
         if (p.ln_g) { lng[tid] = p.ln_g[tid]; lnb[tid] = p.ln_b[tid]; }
     }
 
-    // ---- X fragments (B operand of phase 1): lane (token m, half h) holds x[m][16s + 8h .. +8] ---------
-    Frag xf[KS1];
     {
-        const bf16_t* xp = p.x + (size_t)mc * p.ldx + 8 * h;
-#pragma unroll
-        for (int s = 0; s < KS1; ++s) xf[s].u = *(const u32x4*)(xp + 16 * s);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                     // parameter vectors visible to every wave
         if (p.ln_g) {
@@ -218,7 +231,21 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
     unsigned gu[4];
     auto gelu_pair = [&](int jt, int s, int q) __attribute__((always_inline)) {
         const int e0 = 4 * (2 * s + (q >> 1)) + 2 * (q & 1);
+#if defined(MLP_X_CHEAPGELU)          // probe builds: identity instead of the polynomial (what does the GELU arithmetic cost?)
+        const f32x2 v = f32x2{hprev[jt][e0], hprev[jt][e0 + 1]};
+#elif defined(MLP_X_PLAINGELU)        // probe builds: the same polynomial in un-packed fp32 (18 instructions per pair instead of 9 packed)
+        f32x2 v;
+#pragma unroll
+        for (int z = 0; z < 2; ++z) {
+            const float xx = hprev[jt][e0 + z], t = xx * xx;
+            float R = fmaf(t, 2.278150468e-08f, -1.598605536e-06f);
+            R = fmaf(R, t, 4.795558198e-05f); R = fmaf(R, t, -8.140160353e-04f); R = fmaf(R, t, 8.772390895e-03f);
+            R = fmaf(R, t, -6.457311660e-02f); R = fmaf(R, t, 3.978833556e-01f);
+            v[z] = xx * __builtin_amdgcn_fmed3f(fmaf(xx, R, 0.5f), 0.0f, 1.0f);
+        }
+#else
         const f32x2 v = gelu_poly2(f32x2{hprev[jt][e0], hprev[jt][e0 + 1]});          // common.h; b1 is already in the accumulator
+#endif
         gu[q] = pack_bf16x2(v[0], v[1]);
     };
     auto gelu_swap = [&](int jt, int s) __attribute__((always_inline)) {
@@ -227,6 +254,25 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
         auto sw1 = __builtin_amdgcn_permlane32_swap(gu[1], gu[3], false, false);
         hf[jt][s].u[0] = sw0[0]; hf[jt][s].u[2] = sw0[1];
         hf[jt][s].u[1] = sw1[0]; hf[jt][s].u[3] = sw1[1];
+    };
+    // Fine-grained form (default, r02): the polynomial in un-packed fp32, ONE hidden value after every phase-1 MFMA of the next chunk.
+    // Measured (profiles/r02_mlp_probe_*.txt, clocks per 128-token workgroup, C = 256): GELU arithmetic = 18.7 k of 111 k (identity
+    // instead of the polynomial: 92.3 k); packed bursts 111.3 k, un-packed bursts 110.7 k, un-packed one value per MFMA 107.6 k, the
+    // same dealt out four values at a time for instruction-level parallelism 107.3 k.  11 VALU instructions per 32-clock MFMA are
+    // issue-bound (4 clocks each): only ~1/3 hides.  Hiding the rest means spreading chunk hc's GELU over phase 2 of chunk hc-1 as
+    // well (5 instructions per MFMA), i.e. one more pipeline stage and a second hidden-fragment buffer - not done.
+    float gfine[2];
+    auto gelu_fine = [&](int v) __attribute__((always_inline)) {          // v = 0..63: value index inside the previous hidden chunk
+        const int ks = v >> 3, jtg = ks >> 1, sg = ks & 1, q = (v >> 1) & 3, z = v & 1;
+        const int e0 = 4 * (2 * sg + (q >> 1)) + 2 * (q & 1);
+        const float xx = hprev[jtg][e0 + z], t = xx * xx;
+        float R = fmaf(t, 2.278150468e-08f, -1.598605536e-06f);
+        R = fmaf(R, t, 4.795558198e-05f); R = fmaf(R, t, -8.140160353e-04f); R = fmaf(R, t, 8.772390895e-03f);
+        R = fmaf(R, t, -6.457311660e-02f); R = fmaf(R, t, 3.978833556e-01f);
+        gfine[z] = xx * __builtin_amdgcn_fmed3f(fmaf(xx, R, 0.5f), 0.0f, 1.0f);
+        if (z == 1) gu[q] = pack_bf16x2(gfine[0], gfine[1]);
+        if ((v & 7) == 7) gelu_swap(jtg, sg);
+        asm volatile("" :: "v"(gfine[z]));                                // pin: LLVM otherwise sinks the arithmetic below the MFMAs
     };
     auto gelu_kstep = [&](int jt, int s) __attribute__((always_inline)) {
 #pragma unroll
@@ -269,8 +315,17 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
 #ifndef MLP_X_NODMA1
                 if (jt == 1) { SB(); dma_piece(s); SB(); }      // two VALU instructions: hides behind the MFMA
 #endif
+#ifndef MLP_X_BURSTGELU
+                if (pipe) {
+                    constexpr int VPM = 64 / (KB * 32);          // hidden values per MFMA: 1 (C = 256) or 2 (C = 128)
+                    SB();
+#pragma unroll
+                    for (int u = 0; u < VPM; ++u) gelu_fine(((kb * 8 + s) * 4 + jt) * VPM + u);
+                    SB();
+                }
+#endif
             }
-#ifndef MLP_X_NOGELU
+#ifdef MLP_X_BURSTGELU
             if (pipe) {
                 // 8 k-step slices of GELU(previous chunk) between the KB*8 MFMA groups of this chunk.  Each slice is one burst of
                 // four independent packed-fp32 chains: v_pk_* does not overlap this wave's MFMAs (measured, issue_probe.hip:
@@ -361,6 +416,24 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
     //      the now idle weight ring (own 32-KB region, 16-B chunks swizzled by token&15) and walks it row by row:
     //      residual loads and bf16 stores are whole contiguous rows.
     PROBE_MARK();
+    // residual = x without a LayerNorm (every MLP of the StyleEncoder and the last MLP: style_transformer.py:865-882,:1125): the raw X
+    // fragments are still in registers.  Fragment s holds channels 16s + 8h .. +7 of the lane's token, the accumulators hold
+    // 8g + 4h .. +3: the same half-wave exchange as the GELU path (two v_permlane32_swap per 16 channels) lines them up - no second
+    // read of x from HBM and no load latency in the epilogue.
+    const bool res_in_regs = p.res == p.x && p.ldr == p.ldx && p.ln_g == nullptr;
+    if (res_in_regs) {
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) {
+            auto swa = __builtin_amdgcn_permlane32_swap(xf[s].u[0], xf[s].u[2], false, false);
+            auto swb = __builtin_amdgcn_permlane32_swap(xf[s].u[1], xf[s].u[3], false, false);
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+                const int e0 = 4 * (2 * (s & 1) + gg);
+                oacc[s >> 1][e0 + 0] += __uint_as_float(swa[gg] << 16); oacc[s >> 1][e0 + 1] += __uint_as_float(swa[gg] & 0xffff0000u);
+                oacc[s >> 1][e0 + 2] += __uint_as_float(swb[gg] << 16); oacc[s >> 1][e0 + 3] += __uint_as_float(swb[gg] & 0xffff0000u);
+            }
+        }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                   // every wave is done reading the last weight slot
     {
@@ -382,7 +455,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
         const int m0w = blockIdx.x * 128 + wave * 32;
         const f32x4 bv = *(const f32x4*)(b2s + 4 * q);
         u32x2 rr[32 / RPI];
-        if (p.res) {
+        const bool res_mem = p.res != nullptr && !res_in_regs;
+        if (res_mem) {
 #pragma unroll
             for (int it = 0; it < 32 / RPI; ++it) {
                 const int mm = m0w + it * RPI + rsub;
@@ -395,7 +469,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
             f32x4 v = *(const f32x4*)(stage + row * C + ((q ^ (row & 15)) << 2));
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += bv[e];
-            if (p.res) {
+            if (res_mem) {
                 v[0] += __uint_as_float(rr[it][0] << 16); v[1] += __uint_as_float(rr[it][0] & 0xffff0000u);
                 v[2] += __uint_as_float(rr[it][1] << 16); v[3] += __uint_as_float(rr[it][1] & 0xffff0000u);
             }
