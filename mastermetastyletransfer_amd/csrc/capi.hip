@@ -158,11 +158,7 @@ int master_linear_dgrad(const void* g, const void* w, void* da, const void* gelu
     return gemm_f32_dgrad((const float*)g, (const float*)w, (float*)da, (const float*)gelu_pre, M, N, K, ldg, ldda, ld_pre, s);
 }
 
-size_t master_gemm_workspace_floats(int rows, int cols) {
-    size_t n = gemm_f32_t_workspace(rows, cols);
-    const size_t cap = (size_t)32 << 20;                       // 128 MB: more splits than that buy nothing
-    return n > cap ? cap : n;
-}
+size_t master_gemm_workspace_floats(int rows, int cols) { return gemm_f32_t_workspace(rows, cols); }
 
 int master_linear_wgrad(const void* g, const void* a, void* dw, int M, int N, int K, int ldg, int lda, void* ws, size_t ws_floats, int dtype,
                         master_stream_t stream) {

@@ -203,6 +203,8 @@ int launch(const GemmArgs& p, hipStream_t s) {
 
 template <bool CONV>
 int dispatch(const GemmArgs& p, hipStream_t s) {
+    // fewer than one 128x128 tile per CU (train step: 8 192-token matrices): 64-row tiles double the number of workgroups
+    if (p.N > 64 && (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) < 256) return launch<64, 128, 32, 64, CONV>(p, s);
     if (p.N > 64) return launch<128, 128, 64, 64, CONV>(p, s);
     if (p.N > 32) return launch<128, 64, 64, 32, CONV>(p, s);
     return launch<256, 32, 64, 32, CONV>(p, s);

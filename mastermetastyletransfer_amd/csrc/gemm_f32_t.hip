@@ -10,9 +10,11 @@
 // the pairing of gemm_f32.hip, so a row-major A keeps its ds_read_b128 path.
 //
 // Weight gradients contract over all tokens / pixels of the batch (8 192 ... 524 288) into a small output, so the contraction is split
-// over blockIdx.y: every split writes its partial tile to a workspace slab and splitk_reduce_kernel adds the slabs in a fixed order
+// over blockIdx.y: every split writes its partial tile to a workspace slab and reduce_slabs_kernel (train_misc.hip) adds the slabs in a fixed order
 // (deterministic, no atomics).
 #include "common.h"
+
+int reduce_slabs_launch(const float* part, float* out, size_t n, size_t slab, int splits, hipStream_t s);   // train_misc.hip
 
 namespace {
 
@@ -215,16 +217,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_t_kernel(
     }
 }
 
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n4,
-                                                            size_t slab, int splits) {
-    // n4 = element count / 4; slabs are 16-byte aligned
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        f32x4 s = *(const f32x4*)(part + 4 * i);
-        for (int k = 1; k < splits; ++k) s += *(const f32x4*)(part + (size_t)k * slab + 4 * i);
-        *(f32x4*)(out + 4 * i) = s;
-    }
-}
-
 template <int BM, int BN, int WM, int WN, bool AT, bool GATHER>
 int launch_t(TArgs p, float* final_out, float* ws, size_t ws_floats, int want_splits, hipStream_t s) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
@@ -233,8 +225,8 @@ int launch_t(TArgs p, float* final_out, float* ws, size_t ws_floats, int want_sp
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const int nk = (p.K + BK - 1) / BK;
     int splits = want_splits;
-    if (splits <= 0) {                                       // fill >= 2 waves of workgroups per CU
-        splits = (1024 + tiles - 1) / tiles;
+    if (splits <= 0) {                                       // two workgroups per CU
+        splits = (512 + tiles - 1) / tiles;
         if (splits > nk / 4) splits = nk / 4;                // keep >= 4 chunks per split
     }
     if (splits < 1) splits = 1;
@@ -250,24 +242,29 @@ int launch_t(TArgs p, float* final_out, float* ws, size_t ws_floats, int want_sp
     static LdsLimit lds_limit;
     lds_limit.ensure((const void*)gemm_f32_t_kernel<BM, BN, WM, WN, AT, GATHER>, (int)lds);
     hipLaunchKernelGGL((gemm_f32_t_kernel<BM, BN, WM, WN, AT, GATHER>), dim3(tiles, splits), dim3(NT), lds, s, p);
-    if (splits > 1) {
-        const size_t n4 = slab / 4;
-        int blocks = (int)((n4 + 255) / 256); if (blocks > 1024) blocks = 1024;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, final_out, n4, slab, splits);
-    }
+    if (splits > 1) return reduce_slabs_launch(ws, final_out, (size_t)p.M * p.ldo, slab, splits, s);
     return master_check_launch("gemm_f32_t");
 }
 
 }  // namespace
 
 // number of floats of workspace that lets a weight-gradient GEMM use its preferred split count
-size_t gemm_f32_t_workspace(int M, int N) { return (((size_t)M * N + 3) & ~(size_t)3) * 64; }
+size_t gemm_f32_t_workspace(int M, int N) {
+    const size_t slab = ((size_t)M * N + 3) & ~(size_t)3;
+    size_t n = slab * 512, cap = (size_t)8 << 20;            // up to 512 splits, at most 32 MB - but never fewer than 8 slabs
+    if (n > cap) n = cap;
+    return n < slab * 8 ? slab * 8 : n;
+}
 
 // dX[M,Kc] = G[M,Nc] . W[Nc,Kc] (* gelu'(aux) when aux != NULL)
 int gemm_f32_dgrad(const float* g, const float* w, float* out, const float* aux, int M, int Nc, int Kc, int ldg, int ldo, int ld_aux,
                    hipStream_t s) {
     TArgs p{g, w, out, M, Kc, Nc, ldg, Kc, ldo, 0, 0, aux, ld_aux, 0, 0, 0, 0, 0, 0, 0};
-    if (Kc > 64) return launch_t<128, 128, 64, 64, false, false>(p, out, nullptr, 0, 1, s);
+    if (Kc > 64) {
+        // fewer than one 128x128 tile per CU (the StyleTransformer's 8 192-token matrices): 64-row tiles double the workgroups
+        if ((long long)((M + 127) / 128) * ((Kc + 127) / 128) < 256) return launch_t<64, 128, 32, 64, false, false>(p, out, nullptr, 0, 1, s);
+        return launch_t<128, 128, 64, 64, false, false>(p, out, nullptr, 0, 1, s);
+    }
     return launch_t<128, 64, 64, 32, false, false>(p, out, nullptr, 0, 1, s);
 }
 
