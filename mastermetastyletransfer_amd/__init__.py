@@ -4,9 +4,10 @@ from .graph import GraphedStylizer
 from .imageio import Preprocess, postprocess
 from .loss import VGG19_custom, custom_loss
 from .model import MasterStyleTransferModel
+from .meta import ReptileTrainer, allreduce_gradients, set_fast_adaptation
 from .optim import FusedAdam, reptile_update
 from .modules import (Decoder, ShiftedWindowAttention, ShiftedWindowAttention_for_decoder_last_MHA, StyleDecoder,
                       StyleEncoder, StyleSwinTransformerBlock, StyleTransformer, SwinEncoder)
 
-__all__ = ["FusedAdam", "reptile_update", "MasterStyleTransferModel", "GraphedStylizer", "Preprocess", "postprocess", "custom_loss", "VGG19_custom", "StyleTransformer", "StyleEncoder", "StyleDecoder", "StyleSwinTransformerBlock",
+__all__ = ["FusedAdam", "reptile_update", "ReptileTrainer", "set_fast_adaptation", "allreduce_gradients", "MasterStyleTransferModel", "GraphedStylizer", "Preprocess", "postprocess", "custom_loss", "VGG19_custom", "StyleTransformer", "StyleEncoder", "StyleDecoder", "StyleSwinTransformerBlock",
            "ShiftedWindowAttention", "ShiftedWindowAttention_for_decoder_last_MHA", "Decoder", "SwinEncoder"]

@@ -57,8 +57,22 @@ __device__ __forceinline__ Frag pack_tile(const f32x16& t, int s, float mul) {
     return f;
 }
 
+#ifdef ATTN_CLOCK_PROBE   // diagnostic build only (profiles/probes/attn_block_probe.hip): s_memtime sections of wave 0
+#define PROBE_MARK() do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); probe_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PROBE_ADD(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); probe_sec[i] += t_ - probe_last; probe_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PROBE_MARK() do {} while (0)
+#define PROBE_ADD(i) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+#ifdef ATTN_CLOCK_PROBE
+    const unsigned long long probe_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long probe_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, probe_last = 0;
+    // 0 wait for the gathered tile + barrier | 1 LayerNorm + barrier + next gather issue | 2 QKV MFMAs | 3 S^T + bias + mask |
+    // 4 softmax (exp2, pack, denominators) | 5 P.V | 6 heads meet in LDS (2 barriers) | 7 proj + residual + store
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // = head
     const int r = lane & 31, h = lane >> 5;
@@ -139,8 +153,10 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
         const unsigned char* raw = lds + XRAW + buf * 64 * ROWB;           // this window's un-normalised rows (also the residual)
 
         // ---- 1. LayerNorm: raw rows (LDS, linear) -> normalised bf16 rows (LDS, 16-B chunks swizzled by row&15) ------
+        PROBE_MARK();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                      // raw tile landed; previous window's proj reads of XS done
+        PROBE_ADD(0);
         {
             const int sidx = lrow < p.N ? src[lrow] : -1;
             float v[32];
@@ -177,6 +193,7 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                      // XS complete
         if (win + ng < nwin) gather(win + ng, buf ^ 1);      // next window's rows fly under this window's math
+        PROBE_ADD(1);
 
         // ---- 2. Q^T, K^T [channel][slot] and V [slot][channel] of this wave's head --------------------------------------
         f32x16 qt[2], kt[2], vt[2];
@@ -206,6 +223,7 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
             }
         }
 
+        PROBE_ADD(2);
         // ---- 3. S^T[key][query] = K Q^T from packed accumulator tiles; bias, mask, softmax -------------------------------------
         f32x16 st[2][2];
         {
@@ -256,6 +274,7 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
                     }
             }
         }
+        PROBE_ADD(3);
         float inv[2];
         Frag pf[2][2][2];                                                  // [query tile][key tile][k-step]
 #pragma unroll
@@ -286,6 +305,7 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
             inv[q2] = __builtin_amdgcn_rcpf(rs[0]);
         }
 
+        PROBE_ADD(4);
         // ---- 4. O^T[d][query] = V^T P^T (V tiles as the A operand: X^T B with X = V[key][d]) ------------------------------------
         f32x16 ot[2];
 #pragma unroll
@@ -302,6 +322,7 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
                     ot[q2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.b, pf[q2][k2][s].b, ot[q2], 0, 0, 0);
             }
 
+        PROBE_ADD(5);
         __builtin_amdgcn_s_barrier();                                      // every head is done reading XS (its X fragments)
         // O[slot][head*32 + d] -> LDS (the XS tile is reused), 8-B pieces: d = 8g + 4h + e
 #pragma unroll
@@ -317,6 +338,7 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                      // all heads' O in LDS
+        PROBE_ADD(6);
 
         // ---- 5. proj: out^T[n][slot] for this wave's 32 output channels, + bias + residual -------------------------------------------
         f32x16 pt[2];
@@ -358,7 +380,15 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
                 *(u32x2*)(p.out + off + 8 * g) = o;
             }
         }
+        PROBE_ADD(7);
     }
+#ifdef ATTN_CLOCK_PROBE
+    if (tid == 0 && g_probe) {
+        g_probe[blockIdx.x * 10] = __builtin_amdgcn_s_memtime() - probe_t0;
+        g_probe[blockIdx.x * 10 + 1] = (unsigned long long)((nwin - gi + ng - 1) / ng);
+        for (int i = 0; i < 8; ++i) g_probe[blockIdx.x * 10 + 2 + i] = probe_sec[i];
+    }
+#endif
 }
 
 }  // namespace

@@ -1,0 +1,106 @@
+"""Meta-training on the HIP train step: the Reptile outer loop of the reference's train.py:402-534 and the
+"fast adaptation" stage of train_only_inner_loop.py:306-318, plus the data-parallel gradient all-reduce a multi-GPU train run needs.
+
+Host orchestration only - every tensor operation is a kernel of libmaster_hip.so (train-mode forward/backward through autograd.py,
+FusedAdam, reptile_update) or a collective.
+
+Reptile (train.py:402-534), per outer iteration:   omega <- theta;   for num_inner_updates steps: k = randint(1, max_layers),
+out = decoder(StyleTransformer_omega(enc(content), enc(style), k)), loss = custom_loss(...), Adam step on omega;
+theta += outer_lr * (omega - theta).   The reference file as written has its loss / backward block de-indented out of the inner
+`for` (train.py:469) and the backward/step under an `else` that the default flags never take (:482, :515-517), so with default flags
+no gradient step runs; this module implements the algorithm those lines describe (loss, backward and step inside every inner update).
+The inner optimizer is created once and keeps its moments across outer iterations, like the reference's (train.py:389-398).
+"""
+from __future__ import annotations
+
+import copy
+import random
+from typing import Callable, Iterable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+
+from .optim import FusedAdam, reptile_update
+
+
+def set_fast_adaptation(model) -> List[nn.Parameter]:
+    """train_only_inner_loop.py:306-318: only the StyleEncoder stays trainable (Swin encoder, StyleDecoder and the image decoder are
+    frozen).  Returns the trainable parameters (hand them to the optimizer)."""
+    for p in model.swin_encoder.parameters():
+        p.requires_grad = False
+    for p in model.style_transformer.decoder.parameters():
+        p.requires_grad = False
+    for p in model.style_transformer.encoder.parameters():
+        p.requires_grad = True
+    for p in model.decoder.parameters():
+        p.requires_grad = False
+    return [p for p in model.style_transformer.encoder.parameters()]
+
+
+def allreduce_gradients(params: Iterable[nn.Parameter], average: bool = True) -> None:
+    """Data-parallel training: ONE all-reduce of all gradients as a flat buffer (4.3 M floats = 17 MB for StyleTransformer + decoder,
+    SURVEY 8e; one large collective suits the per-link-bound xGMI ring better than 69 small ones)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    ps = [p for p in params if p.grad is not None]
+    if not ps:
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    dist.all_reduce(flat)
+    if average:
+        flat /= dist.get_world_size()
+    off = 0
+    for p in ps:
+        n = p.grad.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        off += n
+
+
+class ReptileTrainer:
+    """theta = `model` (MasterStyleTransferModel); omega = private copies of its StyleTransformer and image decoder."""
+
+    def __init__(self, model, loss_fn, inner_lr: float = 1e-4, outer_lr: float = 1e-4, num_inner_updates: int = 4, max_layers: int = 4):
+        self.model, self.loss_fn = model, loss_fn
+        self.outer_lr, self.num_inner_updates, self.max_layers = outer_lr, num_inner_updates, max_layers
+        for p in model.swin_encoder.parameters():                     # freeze_encoder (the reference's default)
+            p.requires_grad = False
+        self.omega_st = copy.deepcopy(model.style_transformer).train()
+        self.omega_dec = copy.deepcopy(model.decoder).train()
+        self.optimizer = FusedAdam(list(self.omega_st.parameters()) + list(self.omega_dec.parameters()), lr=inner_lr)     # train.py:398
+        self.on_inner_step: Optional[Callable[[int, Tensor], None]] = None       # hook(inner index, total loss) after backward, before step
+
+    def _omega_forward(self, content: Tensor, style: Tensor, k: int) -> Tensor:
+        from . import train_forward as TF
+        B = content.shape[0]
+        enc = self.model.swin_encoder
+        was = enc.training
+        enc.train(True)                                               # the reference's model is in train mode (StochasticDepth active)
+        with torch.no_grad():
+            x, _, h, w = enc.run(content, style)
+        enc.train(was)
+        fc, fs = x[: B * h * w], x[B * h * w:]
+        fcs = TF.style_transformer(self.omega_st, fc, fs, k, B, h, w, TF.sd_masks)
+        return TF.image_decoder(self.omega_dec, fcs.view(B, h, w, -1))
+
+    def outer_step(self, style_batch: Tensor, content_batches: Sequence[Tensor], layer_counts: Optional[Sequence[int]] = None) -> List[float]:
+        """one outer iteration; content_batches: num_inner_updates batches.  Returns the inner losses."""
+        assert len(content_batches) == self.num_inner_updates
+        self.omega_st.load_state_dict(self.model.style_transformer.state_dict())       # omega <- theta  (train.py:432-433)
+        self.omega_dec.load_state_dict(self.model.decoder.state_dict())
+        losses = []
+        for i, content in enumerate(content_batches):
+            k = layer_counts[i] if layer_counts is not None else random.randint(1, self.max_layers)      # train.py:448
+            out = self._omega_forward(content, style_batch, k)
+            total = self.loss_fn(content, style_batch, out)
+            self.optimizer.zero_grad()
+            total.backward()
+            if self.on_inner_step is not None:
+                self.on_inner_step(i, total)
+            self.optimizer.step()
+            losses.append(float(total.detach()))
+        # theta += outer_lr * (omega - theta): every tensor of both modules in one launch  (train.py:524-534)
+        theta = list(self.model.style_transformer.parameters()) + list(self.model.decoder.parameters())
+        omega = list(self.omega_st.parameters()) + list(self.omega_dec.parameters())
+        reptile_update([p.data for p in theta], [p.data for p in omega], self.outer_lr)
+        return losses

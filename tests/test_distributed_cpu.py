@@ -120,3 +120,44 @@ def test_world_size_2_gloo(batch):
 def test_world_size_1_is_identity():
     x = torch.randn(3, 3, 4, 4)
     assert all_gather_images(x, 3, 0, 1) is x
+
+
+def _worker_grads(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mastermetastyletransfer_amd.meta import allreduce_gradients
+        g = torch.Generator().manual_seed(rank)
+        ps = [torch.nn.Parameter(torch.zeros(s)) for s in ((5, 3), (7,), (2, 2, 2))] + [torch.nn.Parameter(torch.zeros(4))]
+        for p in ps[:3]:
+            p.grad = torch.randn(p.shape, generator=g)
+        allreduce_gradients(ps)                       # the last parameter has no gradient: skipped on every rank
+        q.put((rank, [p.grad.clone() for p in ps[:3]], ps[3].grad is None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world_2():
+    """the data-parallel train step's one collective: a flat all-reduce that averages every gradient over the ranks"""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_grads, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = []
+    for shape in ((5, 3), (7,), (2, 2, 2)):
+        want.append(sum(torch.randn(shape, generator=torch.Generator().manual_seed(r)) for r in range(2)) / 2)
+    # generators advance tensor by tensor: rebuild in the same order
+    gens = [torch.Generator().manual_seed(r) for r in range(2)]
+    want = [sum(torch.randn(shape, generator=gens[r]) for r in range(2)) / 2 for shape in ((5, 3), (7,), (2, 2, 2))]
+    for rank, grads, none_kept in res:
+        assert none_kept
+        for a, b in zip(grads, want):
+            assert torch.allclose(a, b, atol=1e-7)

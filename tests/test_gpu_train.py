@@ -399,3 +399,45 @@ def test_full_train_step(cuda, B, S):
     T.adam_step(before, dev_grads, {}, 1e-3, 1)
     for n, p in named:
         assert torch.allclose(p.detach().cpu(), before[n], rtol=1e-5, atol=2e-7), n
+
+
+def test_reptile_outer_step_and_fast_adaptation(cuda):
+    """meta.ReptileTrainer (train.py:402-534): omega <- theta, inner Adam steps on omega, theta += eta (omega - theta).  The
+    orchestration is replayed on the CPU from the DEVICE gradients of every inner step (gradient parity is covered above): oracle Adam
+    on omega, then the interpolation - theta must match.  Then fast adaptation: only StyleEncoder parameters receive gradients."""
+    from mastermetastyletransfer_amd import ReptileTrainer, custom_loss, set_fast_adaptation
+    from mastermetastyletransfer_amd import train_forward as TF
+    B, S = 2, 64
+    sds = (seeded_state_dict(O.swin_shapes(), 1), seeded_state_dict(O.style_transformer_shapes(), 2), seeded_state_dict(O.decoder_shapes(), 3))
+    m = _model(cuda)
+    m.swin_encoder.load_state_dict(sds[0]); m.style_transformer.load_state_dict(sds[1]); m.decoder.load_state_dict(sds[2])
+    m = m.to(cuda).train()
+    loss_fn = custom_loss(default_lambda_value=10.0, vgg_state_dict=seeded_state_dict(L.vgg19_shapes(), 4)).to(cuda)
+    tr = ReptileTrainer(m, loss_fn, inner_lr=1e-3, outer_lr=0.25, num_inner_updates=2, max_layers=2)
+    names = ["style_transformer." + n for n, _ in m.style_transformer.named_parameters()] + ["decoder." + n for n, _ in m.decoder.named_parameters()]
+    theta0 = {n: p.detach().cpu().clone() for n, p in zip(names, list(m.style_transformer.parameters()) + list(m.decoder.parameters()))}
+    omega_params = list(tr.omega_st.parameters()) + list(tr.omega_dec.parameters())
+    grads_seen = []
+    tr.on_inner_step = lambda i, total: grads_seen.append({n: p.grad.detach().cpu().clone() for n, p in zip(names, omega_params)})
+    style = seeded_input("rep_s", (B, 3, S, S), 6, kind="image").to(cuda)
+    contents = [seeded_input(f"rep_c{i}", (B, 3, S, S), 7 + i, kind="image").to(cuda) for i in range(2)]
+    torch.manual_seed(0)
+    losses = tr.outer_step(style, contents, layer_counts=[1, 2])
+    assert len(grads_seen) == 2 and all(np.isfinite(l) for l in losses)
+    omega = {n: t.clone() for n, t in theta0.items()}
+    state = {}
+    for step, g in enumerate(grads_seen, 1):
+        T.adam_step(omega, g, state, 1e-3, step)
+    for n, p in zip(names, list(m.style_transformer.parameters()) + list(m.decoder.parameters())):
+        want = theta0[n] + 0.25 * (omega[n] - theta0[n])
+        assert torch.allclose(p.detach().cpu(), want, rtol=1e-5, atol=3e-7), n
+    # fast adaptation (train_only_inner_loop.py:306-318)
+    trainable = set_fast_adaptation(m)
+    assert len(trainable) == sum(1 for _ in m.style_transformer.encoder.parameters())
+    out = m(contents[0], style, 1)
+    loss_fn(contents[0], style, out).backward()
+    for n, p in m.named_parameters():
+        if n.startswith("style_transformer.encoder."):
+            assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        else:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
