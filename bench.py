@@ -174,7 +174,7 @@ PMC_KERNELS = {"mlp": ("mlp_bf16_kernel", "mlp_c128_kernel"), "linear": ("linear
 def pmc_traffic(family, args):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes of THIS command line
     (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/pmc_traffic.py); None when no matching profile exists."""
-    path = os.path.join(ROOT, "profiles", "r01_bf16_bs32_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_bf16_bs32_pmc_traffic.json")
     if args.dtype != "bf16" or args.batch != 32 or args.size != 256 or args.layers != 1 or not os.path.exists(path):
         return None, None
     prof = json.load(open(path))
@@ -182,7 +182,7 @@ def pmc_traffic(family, args):
     for name, v in prof.items():
         if any(name.startswith(pfx) for pfx in PMC_KERNELS.get(family, ())):
             tot_b += v["hbm_bytes_per_launch"] * v["launches"]; tot_n += v["launches"]
-    return (round(tot_b / tot_n) if tot_n else None), "profiles/r01_bf16_bs32_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    return (round(tot_b / tot_n) if tot_n else None), "profiles/r02_bf16_bs32_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
 
 
 def extras(model, content, style, k, args, ops):

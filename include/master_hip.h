@@ -16,6 +16,10 @@
  *     Norm statistics, softmax and all epilogues are fp32 in both modes.
  *   - return value: MASTER_OK or a negative master_status; master_last_error_string() describes
  *     the last failure on the calling thread.  Nothing throws, nothing synchronises the device.
+ *   - threads / devices: entry points may be called from several host threads and for several GPUs of one process; a call
+ *     works on the CURRENT HIP device (callers make the operands' device current).  The only state kept between calls is a
+ *     per-(kernel, device) atomic remembering the dynamic-LDS limit already raised there, the mutex-protected timing records of
+ *     master_prof_*, and the thread-local error string.
  */
 #ifndef MASTER_HIP_H
 #define MASTER_HIP_H
