@@ -93,15 +93,22 @@ def main():
     # N > 1: the ranks of one node share the host, and the forward is ~75 launches (1.0 ms of enqueue per step): replay a HIP graph
     # (one launch per step, bit-identical results) so that the ranks do not contend for host time; N = 1 keeps the eager path
     forward = lambda: model(content, style, k)
+    launch_mode = "eager"
     if world > 1 and not args.eager:
-        from mastermetastyletransfer_amd import GraphedStylizer
-        graphed = GraphedStylizer(model, B, S, S, k)
-        graphed.content.copy_(content); graphed.style.copy_(style)
-        forward = lambda: (graphed.graph.replay(), graphed.out.clone())[1]     # private copy: the async gather of step i reads it while step i+1 replays
+        try:
+            from mastermetastyletransfer_amd import GraphedStylizer
+            graphed = GraphedStylizer(model, B, S, S, k)
+            graphed.content.copy_(content); graphed.style.copy_(style)
+            forward = lambda: (graphed.graph.replay(), graphed.out.clone())[1]     # private copy: the async gather of step i reads it while step i+1 replays
+            launch_mode = "hipGraph replay"
+        except Exception as e:                      # a capture problem must not cost the scaling run: fall back to kernel-by-kernel enqueue
+            print(f"[rank {rank}] hipGraph capture failed ({e!r}); running eager", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
     ranks_seen = None
     if world > 1:                                   # prove that RCCL connected every rank: all-gather of the rank ids
+        from mastermetastyletransfer_amd.distributed import all_gather_tensor
         ids = torch.empty((world,), dtype=torch.int64, device=device)
-        dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int64, device=device))
+        all_gather_tensor(ids, torch.tensor([rank], dtype=torch.int64, device=device))
         ranks_seen = sorted(int(i) for i in ids.cpu())
         assert ranks_seen == list(range(world)), ranks_seen
 
@@ -126,9 +133,10 @@ def main():
         dt = time.perf_counter() - t0
     per_rank_ms = None
     if world > 1:
+        from mastermetastyletransfer_amd.distributed import all_gather_tensor
         mine = torch.tensor([dt], device=device, dtype=torch.float64)
         every = torch.empty((world,), device=device, dtype=torch.float64)
-        dist.all_gather_into_tensor(every, mine)
+        all_gather_tensor(every, mine)
         per_rank_ms = [round(float(v) / args.steps * 1e3, 3) for v in every.cpu()]
         dt = float(every.max())
     assert out.shape == (B * world, 3, S, S)
@@ -146,7 +154,7 @@ def main():
     if world > 1:
         result["rccl_ranks_seen"] = ranks_seen
         result["per_rank_ms_per_step"] = per_rank_ms
-        result["forward_launch"] = "eager" if args.eager else "hipGraph replay"
+        result["forward_launch"] = launch_mode
 
     if rank == 0 and world == 1 and not args.no_extras:
         result.update(extras(model, content, style, k, args, ops))

@@ -20,17 +20,41 @@ def init_from_env(prefer_gpu: bool = True) -> Tuple[int, int, torch.device]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     use_gpu = prefer_gpu and torch.cuda.device_count() > 0
+    # MASTER_DIST_REHEARSAL=1: several ranks share ONE GPU over gloo (collectives staged through the host) - only to rehearse the
+    # N > 1 driver code on a one-GPU box; RCCL refuses two ranks on one device.  Never set on a real multi-GPU run.
+    rehearsal = os.environ.get("MASTER_DIST_REHEARSAL") == "1"
+    if use_gpu and rehearsal:
+        local = local % torch.cuda.device_count()
     device = torch.device(f"cuda:{local}") if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        if use_gpu:
+        if use_gpu and not rehearsal:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
     return rank, world, device
+
+
+def _host_staged() -> bool:
+    """gloo cannot all-gather device tensors: in rehearsal mode the collectives run on host copies"""
+    return dist.is_initialized() and dist.get_backend() == "gloo"
+
+
+def all_gather_tensor(out: torch.Tensor, local: torch.Tensor, async_op: bool = False):
+    """dist.all_gather_into_tensor; device tensors over gloo (rehearsal) go through the host, synchronously"""
+    if _host_staged() and local.is_cuda:
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, local.cpu())
+        out.copy_(o)
+
+        class _Done:
+            def wait(self):
+                return True
+        return _Done() if async_op else None
+    return dist.all_gather_into_tensor(out, local, async_op=async_op)
 
 
 def shard_range(batch: int, rank: int, world: int) -> Tuple[int, int]:
@@ -47,14 +71,14 @@ def all_gather_images(local: torch.Tensor, batch: int, rank: int, world: int) ->
     local = local.contiguous()
     if batch % world == 0:
         out = local.new_empty((batch,) + tuple(local.shape[1:]))
-        dist.all_gather_into_tensor(out, local)
+        all_gather_tensor(out, local)
         return out
     # ragged tail: pad every shard to the largest one, gather, then cut the padding out
     cap = -(-batch // world)
     padded = local.new_zeros((cap,) + tuple(local.shape[1:]))
     padded[: local.shape[0]] = local
     out = local.new_empty((world * cap,) + tuple(local.shape[1:]))
-    dist.all_gather_into_tensor(out, padded)
+    all_gather_tensor(out, padded)
     parts = []
     for r in range(world):
         lo, hi = shard_range(batch, r, world)
@@ -81,7 +105,7 @@ class AsyncImageGather:
             self._retire()
         local = local.contiguous()
         out = self.buffers.pop() if self.buffers else local.new_empty((self.batch,) + tuple(local.shape[1:]))
-        work = dist.all_gather_into_tensor(out, local, async_op=True)
+        work = all_gather_tensor(out, local, async_op=True)
         self.pending.append((work, out, local))
         return out                 # valid after wait() (or after `depth` further submits)
 
