@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = the headline metric; train = BASELINE config 4: inner-loop train step bs=8 256x256 (fp32 mode), steps/s")
     ap.add_argument("--eager", action="store_true", help="N > 1: enqueue kernel by kernel instead of replaying a HIP graph")
+    ap.add_argument("--loss-dtype", choices=["fp32", "bf16"], default="fp32", help="--mode train: compute dtype of the frozen VGG-19 loss network")
     args = ap.parse_args()
     if args.mode == "train":
         return train_main(args)
@@ -290,6 +291,9 @@ def extras(model, content, style, k, args, ops):
                             "config5_bs16_512": {"images_per_s": round(16 / t5, 1), "ms_per_step": round(t5 * 1e3, 3), "steps": 4}}
         try:
             out["train_step"] = train_bench(content.device, steps=5, warmup=2)
+            alt = train_bench(content.device, steps=5, warmup=2, roofline=False, loss_dtype="bf16")
+            out["train_step"]["with_bf16_loss_network"] = {"value": alt["value"], "unit": "steps/s", "ms_per_step": alt["ms_per_step"],
+                                                           "note": "frozen VGG-19 in bf16 (activations and data gradients); model, weight gradients and Adam fp32"}
         except Exception as e:                      # the headline line must survive a failure of this extra leg
             out["train_step"] = {"error": repr(e)}
     # ---- CPU baseline: the oracle (a port of the reference) on the host cores, bounded sample -------
@@ -321,7 +325,7 @@ def extras(model, content, style, k, args, ops):
 FWD_GFLOP = {"swin_per_image": 7.552, "st_layer": 9.079, "decoder": 7.965, "vgg": 47.34}      # per image @256^2, BASELINE.md section 3
 
 
-def train_bench(device, steps=10, warmup=3, B=8, S=256, max_layers=4, roofline=True):
+def train_bench(device, steps=10, warmup=3, B=8, S=256, max_layers=4, roofline=True, loss_dtype="fp32"):
     """K train steps: random k, train-mode forward (StochasticDepth masks drawn on the device), custom_loss, backward, FusedAdam.
     Returns the result dict (steps/s, algorithmic TFLOP/s, per-family kernel times of one step, roofline of the dominant family)."""
     import random
@@ -335,6 +339,7 @@ def train_bench(device, steps=10, warmup=3, B=8, S=256, max_layers=4, roofline=T
         if isinstance(m_, torch.nn.Conv2d):
             torch.nn.init.kaiming_normal_(m_.weight, nonlinearity="relu"); torch.nn.init.normal_(m_.bias, std=0.05)
     loss_fn = custom_loss(default_lambda_value=10.0, vgg_state_dict=vgg.state_dict()).to(device)
+    loss_fn.set_compute_dtype(torch.float32 if loss_dtype == "fp32" else torch.bfloat16)     # the frozen loss network only; the model stays fp32
     opt = FusedAdam([{"params": model.style_transformer.parameters()}, {"params": model.decoder.parameters()}], lr=1e-4)
     content, style = synthetic_batch(B, S, device, seed=11)
     random.seed(0)
@@ -360,7 +365,8 @@ def train_bench(device, steps=10, warmup=3, B=8, S=256, max_layers=4, roofline=T
              + B * FWD_GFLOP["vgg"] + 2 * B * (k * FWD_GFLOP["st_layer"] + FWD_GFLOP["decoder"]) for k in kt)
     res = {"metric": "train steps/sec, inner-loop step (train-mode forward + VGG-19 perceptual loss + backward + Adam), bs=8 256x256",
            "value": round(steps / dt, 3), "unit": "steps/s", "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps, "warmup": warmup,
-           "dtype": "fp32", "images_per_s": round(B * steps / dt, 1), "transformer_layer_counts": kt,
+           "dtype": "fp32" if loss_dtype == "fp32" else "fp32 model + bf16 frozen VGG-19 loss network", "images_per_s": round(B * steps / dt, 1),
+           "transformer_layer_counts": kt,
            "alg_tflop_per_step": round(gf / steps / 1e3, 3), "alg_tflops": round(gf / dt / 1e3, 2),
            "frac_of_fp32_mfma_peak": round(gf / dt / 1e3 / PEAK_TFLOPS["fp32"], 4), "final_loss": float(last)}
     if roofline:
@@ -395,7 +401,7 @@ def train_main(args):
         raise SystemExit("--mode train is BASELINE config 4: one GPU")
     device = torch.device("cuda:0")
     torch.cuda.set_device(device)
-    res = train_bench(device, steps=args.steps, warmup=args.warmup, roofline=not args.no_extras)
+    res = train_bench(device, steps=args.steps, warmup=args.warmup, roofline=not args.no_extras, loss_dtype=args.loss_dtype)
     res.update({"n_gpus": 1, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
                 "config": {"workload": "train_only_inner_loop.py:519-575 step on synthetic 256x256 batches of 8 content + 8 style images: "
                                        "k = random.randint(1, 4) with random.seed(0), Swin encoder frozen, StochasticDepth p = 0.1, "

@@ -426,35 +426,30 @@ EPS_IN = 1e-5
 
 
 class PerceptualLossFn(torch.autograd.Function):
-    """(content_loss, style_loss) = f(content, style, output; frozen VGG-19 weights).  Only `output` receives a gradient.
+    """(content_loss, style_loss) = f(content, style, output; frozen VGG-19 `vgg` = loss.VGG19_custom).  Only `output` receives a gradient.
 
-    forward: the three feature extractions as one batch of 3B (conv outputs saved for the backward), per-(image, channel) statistics,
+    forward: the three feature extractions as one batch of 3B (conv outputs kept for the backward), per-(image, channel) statistics,
     IN-distance (content) and mean/std distance (style) at relu2_1/3_1/4_1/5_1.
     backward: per tap the loss gradient w.r.t. the output image's feature map (master_loss_tap_bwd), then the VGG chain in reverse on
     the B output images only: conv data gradients with the ReLU mask of the layer below and the next tap's gradient in the GEMM
-    epilogue, max-pool backward fused with the ReLU mask; ends in the image gradient [B,3,H,W]."""
+    epilogue, max-pool backward fused with the ReLU mask; ends in the fp32 image gradient [B,3,H,W].
+    The loss network runs in vgg.compute_dtype: fp32 (parity mode) or bf16 (bf16 MFMA, fp32 accumulation; the network is frozen, so
+    there is no bf16 weight gradient anywhere) - statistics, loss terms and the image gradient are fp32 in both."""
 
     @staticmethod
-    def forward(ctx, content, style, output, squared_c: bool, squared_s: bool, *wb):
-        weights, biases = wb[0::2], wb[1::2]
+    def forward(ctx, content, style, output, vgg, squared_c: bool, squared_s: bool):
         B = output.shape[0]
         dev = output.device
-        x = ops.image_to_nhwc(torch.cat([content, style, output.detach()], dim=0).float(), _CPAD, F)
+        dt = vgg.compute_dtype
+        x = ops.image_to_nhwc(torch.cat([content, style, output.detach()], dim=0).float(), _CPAD, dt)
         acts = {}                         # conv index -> ReLU output [3B,H,W,C]
         taps = []
         h = x
-        ci = 0
-        packed = []
         for i in range(30):
             if i in VGG19_CONVS:
-                w = weights[ci].detach().permute(0, 2, 3, 1)
-                if w.shape[3] % 32:
-                    w = torch.nn.functional.pad(w, (0, _CPAD - w.shape[3]))
-                w = w.contiguous().float()
-                packed.append(w)
-                h = ops.conv3x3_zero(h, w, biases[ci].detach().float().contiguous(), relu=True)
+                w, b = vgg._weights(i)
+                h = ops.conv3x3_zero(h, w, b, relu=True)
                 acts[i] = h
-                ci += 1
             elif i in VGG19_POOLS:
                 h = ops.maxpool2x2(h)
             elif i in VGG19_TAPS:
@@ -473,10 +468,8 @@ class PerceptualLossFn(torch.autograd.Function):
                 style_loss = style_loss + torch.mean(torch.square(dm)) + torch.mean(torch.square(ds))
             else:
                 style_loss = style_loss + torch.mean(torch.abs(dm)) + torch.mean(torch.abs(ds))
-        ctx.B, ctx.flags = B, (squared_c, squared_s)
-        ctx.x0 = x
+        ctx.B, ctx.flags, ctx.vgg = B, (squared_c, squared_s), vgg
         ctx.acts, ctx.taps, ctx.stats = acts, taps, stats
-        ctx.weights = [w.detach() for w in weights]
         return content_loss, style_loss
 
     @staticmethod
@@ -484,8 +477,10 @@ class PerceptualLossFn(torch.autograd.Function):
         B = ctx.B
         squared_c, squared_s = ctx.flags
         lib = load_library()
-        acts, taps, stats = ctx.acts, ctx.taps, ctx.stats
+        acts, taps, stats, vgg = ctx.acts, ctx.taps, ctx.stats, ctx.vgg
         dev = taps[0].device
+        dt = taps[0].dtype
+        DT = ops._dt(taps[0])
         gc = float(g_content) if g_content is not None else 0.0           # scalars: one host read each (the step ends in a sync anyway)
         gs = float(g_style) if g_style is not None else 0.0
         with torch.cuda.device(dev):
@@ -505,59 +500,48 @@ class PerceptualLossFn(torch.autograd.Function):
                 so = std[2 * B:]
                 coefA = (gs * dmu / float(HW)).contiguous()
                 coefB = torch.where(so > 0, gs * dsg / (float(HW - 1) * so), torch.zeros_like(so)).contiguous()   # torch: std' = 0 at std = 0
-                dx = torch.empty((B, H, W, C), dtype=F, device=dev)
+                dx = torch.empty((B, H, W, C), dtype=dt, device=dev)
                 ws = _ws(lib.master_loss_tap_workspace_floats(B, HW, C), dev)
                 wc = gc / float(B * C * HW)
                 _check(lib.master_loss_tap_bwd(_p(f), _p(mean), _p(var), _p(coefA), _p(coefB), _p(ws), _p(dx), B, HW, C, EPS_IN, wc,
-                                               int(squared_c), int(t == 3), F32, _stream()), "master_loss_tap_bwd")
+                                               int(squared_c), int(t == 3), DT, _stream()), "master_loss_tap_bwd")
                 tap_grads.append(dx)
             # ---- VGG-19 backward on the output images --------------------------------------------------------------------------------
             # layer list: conv0 conv2 pool4 conv5[tap0] conv7 pool9 conv10[tap1] conv12 conv14 conv16 pool18 conv19[tap2] conv21 conv23
             #             conv25 pool27 conv28[tap3].  g = gradient of conv i's ReLU output, already masked by that ReLU.
             sl = slice(2 * B, 3 * B)
             out_of = lambda i: acts[i][sl]
-            widx = {c: n for n, c in enumerate(VGG19_CONVS)}
             tap_of = {5: 0, 10: 1, 19: 2}                # conv whose ReLU output is tap t (joined in the epilogue of the conv above)
             g = tap_grads[3]                             # relu5_1 = ReLU(conv28): masked inside master_loss_tap_bwd (relu_gate)
             order = list(VGG19_CONVS)
             for pos in range(len(order) - 1, -1, -1):
                 i = order[pos]
                 below = order[pos - 1] if pos > 0 else None
-                x_in = None
                 pooled = (i - 1) in VGG19_POOLS
-                if below is None:
-                    relu_src, add = None, None
-                elif pooled:
-                    relu_src, add = None, None           # the pool's backward applies the ReLU mask of `below`
+                if below is None or pooled:
+                    relu_src, add = None, None           # (a pool's backward applies the ReLU mask of `below`)
                 else:
                     relu_src = out_of(below)
                     add = tap_grads[tap_of[below]] if below in tap_of else None
-                w = ctx.weights[widx[i]]
-                if w.shape[1] % 32:                       # first conv: Cin 3 -> 32 (zero weights), like the forward
-                    w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, _CPAD - w.shape[1]))
+                wf = vgg._flipped(i)                                                   # [Cx][3][3][Cg], cached (the network is frozen)
                 Bn, H, W, Cg = g.shape
-                Cx = w.shape[1]
-                wf = w.flip(2, 3).permute(1, 2, 3, 0).contiguous()                    # [Cx][3][3][Cg]
-                dx = torch.empty((Bn, H, W, Cx), dtype=F, device=dev)
+                Cx = wf.shape[0]
+                dx = torch.empty((Bn, H, W, Cx), dtype=dt, device=dev)
                 if ops._COUNT_ON:      # algorithmic: the convolution's real channel counts (the 3-channel image is computed padded to 32)
-                    cx_real = ctx.weights[widx[i]].shape[1]
+                    cx_real = vgg.features[i].weight.shape[1]
                     ops._count("conv_dgrad", flops=2.0 * Bn * H * W * Cg * 9 * cx_real,
-                               bytes=4.0 * (Bn * H * W * (Cg + cx_real * (1 + (relu_src is not None) + (add is not None))) + Cg * 9 * cx_real))
-                _check(lib.master_conv3x3_dgrad(_p(g), _p(wf), _p(dx), _p(relu_src), _p(add), Bn, H, W, Cg, Cx, 0, F32, _stream()),
+                               bytes=g.element_size() * (Bn * H * W * (Cg + cx_real * (1 + (relu_src is not None) + (add is not None))) + Cg * 9 * cx_real))
+                _check(lib.master_conv3x3_dgrad(_p(g), _p(wf), _p(dx), _p(relu_src), _p(add), Bn, H, W, Cg, Cx, 0, DT, _stream()),
                        "master_conv3x3_dgrad")
                 g = dx
                 if pooled:
                     y = out_of(below)                     # the pool's input = ReLU output of the conv below
                     Np, Hp, Wp, Cpp = y.shape
                     dpool = torch.empty_like(y)
-                    if not y.is_contiguous():
-                        y = y.contiguous()
-                    _check(lib.master_maxpool2x2_bwd(_p(g), _p(y), _p(dpool), Np, Hp, Wp, Cpp, F32, _stream()), "master_maxpool2x2_bwd")
+                    _check(lib.master_maxpool2x2_bwd(_p(g), _p(y), _p(dpool), Np, Hp, Wp, Cpp, DT, _stream()), "master_maxpool2x2_bwd")
                     g = dpool
-                    if below in tap_of:                   # not the case for VGG-19 (taps feed convolutions directly); kept for safety
-                        g = g + tap_grads[tap_of[below]] * (y > 0)
             Bn, H, W, Cp = g.shape
             dimg = torch.empty((Bn, 3, H, W), dtype=F, device=dev)
-            _check(lib.master_nhwc_to_image(_p(g), _p(dimg), Bn, H * W, Cp, F32, _stream()), "master_nhwc_to_image")
-        ctx.acts = ctx.taps = ctx.stats = ctx.x0 = None
-        return (None, None, dimg, None, None) + (None,) * (2 * len(ctx.weights))
+            _check(lib.master_nhwc_to_image(_p(g), _p(dimg), Bn, H * W, Cp, DT, _stream()), "master_nhwc_to_image")
+        ctx.acts = ctx.taps = ctx.stats = ctx.vgg = None
+        return None, None, dimg, None, None, None

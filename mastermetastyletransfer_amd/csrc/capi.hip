@@ -22,8 +22,9 @@ int colsum_slabs(int, int);
 int colsum_launch(const float*, float*, float*, int, int, int, hipStream_t);
 int relu_mask_launch(const float*, const float*, float*, int, int, int, int, int, hipStream_t);
 int fold_reflect_launch(const float*, float*, int, int, int, int, int, hipStream_t);
-int maxpool2_bwd_launch(const float*, const float*, float*, int, int, int, int, hipStream_t);
-int nhwc_to_image_launch(const float*, float*, int, int, int, hipStream_t);
+template <typename T> int maxpool2_bwd_launch(const void*, const void*, void*, int, int, int, int, hipStream_t);
+template <typename T> int nhwc_to_image_launch(const void*, float*, int, int, int, hipStream_t);
+int gemm_bf16_conv3x3_dgrad(const bf16_t*, const bf16_t*, bf16_t*, const bf16_t*, const bf16_t*, int, int, int, int, int, hipStream_t);
 int rowscale_add_launch(const float*, const float*, const float*, float*, int, int, int, hipStream_t);
 int mul_add_launch(const float*, const float*, const float*, float*, size_t, hipStream_t);
 int mul_add_bwd_launch(const float*, const float*, const float*, float*, float*, size_t, hipStream_t);
@@ -31,8 +32,8 @@ int adam_chunk();
 int adam_launch(const void*, int, long long, float, float, float, float, float, int, hipStream_t);
 int lerp_launch(const void*, int, long long, float, hipStream_t);
 int loss_tap_slices(int);
-int loss_tap_bwd_launch(const float*, const float*, const float*, const float*, const float*, float*, float*, int, int, int, float, float,
-                        int, int, hipStream_t);
+template <typename T> int loss_tap_bwd_launch(const void*, const float*, const float*, const float*, const float*, float*, void*, int, int, int,
+                                              float, float, int, int, hipStream_t);
 int layernorm_bwd_blocks(int);
 int layernorm_bwd_launch(const float*, const float*, const float*, float*, float*, float*, int, int, float, hipStream_t);
 int instnorm_bwd_launch(const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, float, hipStream_t);
@@ -234,8 +235,14 @@ int master_window_attn_bwd(const void* q, const void* k, const void* v0, const v
 
 int master_conv3x3_dgrad(const void* g, const void* wf, void* out, const void* relu_src, const void* add, int B, int H, int W, int Cg, int Cx,
                          int full, int dtype, master_stream_t stream) {
-    F32_ONLY("conv3x3_dgrad");
     REQUIRE(g && wf && out, "conv3x3_dgrad: null operand");
+    if (dtype == MASTER_BF16) {          // the frozen loss network in bf16: zero-padded form only
+        REQUIRE(full == 0 && Cg % 32 == 0 && Cx % 4 == 0 && al16(g) && al16(wf), "conv3x3_dgrad(bf16): zero-padded form, Cg %% 32 == 0");
+        hipStream_t sb = (hipStream_t)stream;
+        ProfScope psb(MASTER_K_CONV_DGRAD, sb);
+        return gemm_bf16_conv3x3_dgrad((const bf16_t*)g, (const bf16_t*)wf, (bf16_t*)out, (const bf16_t*)relu_src, (const bf16_t*)add, B, H, W, Cg, Cx, sb);
+    }
+    F32_ONLY("conv3x3_dgrad");
     REQUIRE(B > 0 && H > 0 && W > 0 && Cg > 0 && Cg % 32 == 0 && Cx > 0 && (full == 0 || full == 1), "conv3x3_dgrad: bad dims (Cg=%d)", Cg);
     REQUIRE(al16(g) && al16(wf), "conv3x3_dgrad: g/wf must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
@@ -275,19 +282,17 @@ int master_fold_reflect(const void* dxp, void* out, int B, int H, int W, int C, 
 }
 
 int master_maxpool2x2_bwd(const void* g, const void* y, void* dx, int N, int H, int W, int C, int dtype, master_stream_t stream) {
-    F32_ONLY("maxpool2x2_bwd");
     REQUIRE(g && y && dx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0, "maxpool2x2_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_TRAIN_MISC, s);
-    return maxpool2_bwd_launch((const float*)g, (const float*)y, (float*)dx, N, H, W, C, s);
+    return dtype == MASTER_F32 ? maxpool2_bwd_launch<float>(g, y, dx, N, H, W, C, s) : maxpool2_bwd_launch<bf16_t>(g, y, dx, N, H, W, C, s);
 }
 
 int master_nhwc_to_image(const void* g, float* out, int N, int HW, int Cp, int dtype, master_stream_t stream) {
-    F32_ONLY("nhwc_to_image");
     REQUIRE(g && out && N > 0 && HW > 0 && Cp >= 3, "nhwc_to_image: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_TRAIN_MISC, s);
-    return nhwc_to_image_launch((const float*)g, out, N, HW, Cp, s);
+    return dtype == MASTER_F32 ? nhwc_to_image_launch<float>(g, out, N, HW, Cp, s) : nhwc_to_image_launch<bf16_t>(g, out, N, HW, Cp, s);
 }
 
 int master_rowscale_add(const void* x, const void* res, const float* scale, void* out, int B, int T, int C, int dtype, master_stream_t stream) {
@@ -318,12 +323,12 @@ int master_mul_add_bwd(const void* g, const void* q, const void* sigma, void* dq
 size_t master_loss_tap_workspace_floats(int B, int HW, int C) { return (size_t)B * (size_t)(loss_tap_slices(HW) + 1) * 2 * (size_t)C; }
 int master_loss_tap_bwd(const void* x, const float* mean, const float* var, const float* coefA, const float* coefB, float* ws, void* dx, int B,
                         int HW, int C, float eps, float wc, int squared, int relu_gate, int dtype, master_stream_t stream) {
-    F32_ONLY("loss_tap_bwd");
     REQUIRE(x && mean && var && coefA && coefB && ws && dx && B > 0 && HW > 0, "loss_tap_bwd: null operand");
     REQUIRE(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0, "loss_tap_bwd: C/4 must divide 256 (C=%d)", C);
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_TRAIN_MISC, s);
-    return loss_tap_bwd_launch((const float*)x, mean, var, coefA, coefB, ws, (float*)dx, B, HW, C, eps, wc, squared, relu_gate, s);
+    return dtype == MASTER_F32 ? loss_tap_bwd_launch<float>(x, mean, var, coefA, coefB, ws, dx, B, HW, C, eps, wc, squared, relu_gate, s)
+                               : loss_tap_bwd_launch<bf16_t>(x, mean, var, coefA, coefB, ws, dx, B, HW, C, eps, wc, squared, relu_gate, s);
 }
 
 int master_adam_chunk(void) { return adam_chunk(); }

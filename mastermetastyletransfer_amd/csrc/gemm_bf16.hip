@@ -27,6 +27,7 @@ struct GemmArgsB {
     int Hin, Win, Cin, Hout, Wout, up, out_nchw;
     int zero_pad;      // conv gather: out-of-image taps read 0 (nn.Conv2d padding=1) instead of the mirror pixel (padding_mode='reflect')
     int Kw;            // real length (and stride) of a weight row; K - Kw trailing columns are zero padding
+    int mask_relu;     // r1 is a ReLU output that gates the result: out = r1 > 0 ? acc + r2 : 0  (data gradient chains of the loss network)
 };
 
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
@@ -193,7 +194,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_bf16_kernel(G
         if (m >= p.M || n >= p.N) continue;
         f32x4 v = *(const f32x4*)(Os + ml * LDO + nl);
         if (vec_ok) {
-            if (p.r1) {
+            if (p.r1 && !p.mask_relu) {
                 const u32x2 u = *(const u32x2*)(p.r1 + (size_t)m * p.ldr + n);
                 v[0] *= __uint_as_float(u[0] << 16); v[1] *= __uint_as_float(u[0] & 0xffff0000u);
                 v[2] *= __uint_as_float(u[1] << 16); v[3] *= __uint_as_float(u[1] & 0xffff0000u);
@@ -203,13 +204,21 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_bf16_kernel(G
                 v[0] += __uint_as_float(u[0] << 16); v[1] += __uint_as_float(u[0] & 0xffff0000u);
                 v[2] += __uint_as_float(u[1] << 16); v[3] += __uint_as_float(u[1] & 0xffff0000u);
             }
+            if (p.mask_relu) {
+                const u32x2 u = *(const u32x2*)(p.r1 + (size_t)m * p.ldr + n);
+                if (!(__uint_as_float(u[0] << 16) > 0.f)) v[0] = 0.f;
+                if (!(__uint_as_float(u[0] & 0xffff0000u) > 0.f)) v[1] = 0.f;
+                if (!(__uint_as_float(u[1] << 16) > 0.f)) v[2] = 0.f;
+                if (!(__uint_as_float(u[1] & 0xffff0000u) > 0.f)) v[3] = 0.f;
+            }
             u32x2 o; o[0] = pack2(v[0], v[1]); o[1] = pack2(v[2], v[3]);
             *(u32x2*)(out + (size_t)m * p.ldo + n) = o;
         } else {
             for (int e = 0; e < 4 && n + e < p.N; ++e) {
                 float x = v[e];
-                if (p.r1) x *= bf16_to_f32(p.r1[(size_t)m * p.ldr + n + e]);
+                if (p.r1 && !p.mask_relu) x *= bf16_to_f32(p.r1[(size_t)m * p.ldr + n + e]);
                 if (p.r2) x += bf16_to_f32(p.r2[(size_t)m * p.ldr + n + e]);
+                if (p.mask_relu && !(bf16_to_f32(p.r1[(size_t)m * p.ldr + n + e]) > 0.f)) x = 0.f;
                 out[(size_t)m * p.ldo + n + e] = f32_to_bf16(x);
             }
         }
@@ -240,7 +249,7 @@ int dispatch(const GemmArgsB& p, hipStream_t s) {
 int gemm_bf16_linear(const bf16_t* a, const bf16_t* w, const float* bias, const bf16_t* r1, const bf16_t* r2,
                      bf16_t* out, int M, int N, int K, int lda, int ldo, int ldr, int act, hipStream_t s) {
     if (K % BK != 0) { master_set_error("linear(bf16): K must be a multiple of 64 (K=%d)", K); return MASTER_ERR_INVALID; }
-    GemmArgsB p{a, w, bias, r1, r2, out, M, N, K, lda, ldo, ldr, act, 0, 0, 0, 1, 1, 0, 0, 0, K};
+    GemmArgsB p{a, w, bias, r1, r2, out, M, N, K, lda, ldo, ldr, act, 0, 0, 0, 1, 1, 0, 0, 0, K, 0};
     return dispatch<false>(p, s);
 }
 
@@ -250,6 +259,16 @@ int gemm_bf16_conv3x3(const bf16_t* x, const bf16_t* w, const float* bias, void*
     const int Hout = Hin << up, Wout = Win << up;
     const int Kpad = (9 * Cin + BK - 1) / BK * BK;
     GemmArgsB p{x, w, bias, nullptr, nullptr, out, B * Hout * Wout, Cout, Kpad, 0, Cout, 0,
-                relu ? MASTER_ACT_RELU : MASTER_ACT_NONE, Hin, Win, Cin, Hout, Wout, up, out_nchw, zero_pad, 9 * Cin};
+                relu ? MASTER_ACT_RELU : MASTER_ACT_NONE, Hin, Win, Cin, Hout, Wout, up, out_nchw, zero_pad, 9 * Cin, 0};
+    return dispatch<true>(p, s);
+}
+
+// Data gradient of a zero-padded 3x3 convolution in bf16 (the frozen loss network when it runs in bf16): the forward kernel on the
+// output gradient g [B,H,W,Cg] with flipped, transposed weights wf [Cx][3][3][Cg]; out = relu_src > 0 ? acc + add : 0 (both optional).
+int gemm_bf16_conv3x3_dgrad(const bf16_t* g, const bf16_t* wf, bf16_t* out, const bf16_t* relu_src, const bf16_t* add, int B, int H, int W,
+                            int Cg, int Cx, hipStream_t s) {
+    const int Kpad = (9 * Cg + BK - 1) / BK * BK;
+    GemmArgsB p{g, wf, nullptr, relu_src, add, out, B * H * W, Cx, Kpad, 0, Cx, Cx, MASTER_ACT_NONE, H, W, Cg, H, W, 0, 0, 1, 9 * Cg,
+                relu_src != nullptr};
     return dispatch<true>(p, s);
 }

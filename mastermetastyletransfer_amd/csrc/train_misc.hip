@@ -8,6 +8,24 @@ int reduce_slabs_launch(const float* part, float* out, size_t n, size_t slab, in
 
 namespace {
 
+// element access for the kernels that also serve a bf16 loss network (fp32 math either way)
+template <typename T> struct El;
+template <> struct El<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+    static __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
+    static __device__ __forceinline__ void st4(float* p, f32x4 v) { *(f32x4*)p = v; }
+};
+template <> struct El<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+    static __device__ __forceinline__ f32x4 ld4(const bf16_t* p) {
+        const uint2 u = *(const uint2*)p;
+        return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+    }
+    static __device__ __forceinline__ void st4(bf16_t* p, f32x4 v) { uint2 u; u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]); *(uint2*)p = u; }
+};
+
 // ---- slab reduce: out[i] = sum_k part[k*slab + i].  A workgroup owns 64 outputs; its 4 waves take every 4th slab (loads of one
 //      wave are 64 consecutive floats), 8 independent partial sums per thread keep the loads in flight; the four wave partials are
 //      added in a fixed order through LDS.  (r02: one thread per output walking 512 slabs serially took 41 us per bias gradient.) -------
@@ -102,7 +120,8 @@ __global__ __launch_bounds__(256) void fold_reflect_kernel(const float* __restri
 
 // ---- MaxPool2d(2,2) backward fused with the ReLU backward of the layer below: y is that layer's ReLU output [N,H,W,C]; the gradient of
 //      a pooled value goes to the first maximum of its 2x2 block (scan order, like torch) and only where y > 0. ---------------------------
-__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ dx, int H,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__ g, const T* __restrict__ y, T* __restrict__ dx, int H,
                                                            int W, int C, size_t total) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;             // (pooled pixel, channel)
     if (i >= total) return;
@@ -111,20 +130,21 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
     const int ox = (int)(t % W2); t /= W2; const int oy = (int)(t % H2); const size_t n = t / H2;
     const size_t base = ((n * H + 2 * oy) * (size_t)W + 2 * ox) * C + c;
     const size_t o[4] = {base, base + C, base + (size_t)W * C, base + (size_t)W * C + C};
-    float best = y[o[0]]; int arg = 0;
+    float best = El<T>::ld(y + o[0]); int arg = 0;
 #pragma unroll
-    for (int k = 1; k < 4; ++k) { const float v = y[o[k]]; if (v > best) { best = v; arg = k; } }
-    const float gv = best > 0.f ? g[i] : 0.f;
+    for (int k = 1; k < 4; ++k) { const float v = El<T>::ld(y + o[k]); if (v > best) { best = v; arg = k; } }
+    const float gv = best > 0.f ? El<T>::ld(g + i) : 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) dx[o[k]] = k == arg ? gv : 0.f;
+    for (int k = 0; k < 4; ++k) El<T>::st(dx + o[k], k == arg ? gv : 0.f);
 }
 
 // NHWC [N,H,W,Cp] -> NCHW [N,3,H,W] (the gradient of the image that image_to_nhwc padded to Cp channels)
-__global__ __launch_bounds__(256) void nhwc_to_image_kernel(const float* __restrict__ g, float* __restrict__ out, int HW, int Cp, size_t total) {
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_image_kernel(const T* __restrict__ g, float* __restrict__ out, int HW, int Cp, size_t total) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;             // (n, c, pixel)
     if (i >= total) return;
     const size_t q = i % HW, nc = i / HW, n = nc / 3; const int c = (int)(nc - n * 3);
-    out[i] = g[(n * HW + q) * Cp + c];
+    out[i] = El<T>::ld(g + (n * HW + q) * Cp + c);
 }
 
 // ---- StochasticDepth row mode:  out[m,:] = res[m,:] + scale[m / T] * x[m,:]   (res optional) ------------------------------------------
@@ -206,10 +226,10 @@ __global__ __launch_bounds__(256) void lerp_kernel(const TensorRec* __restrict__
 // Pass 1 (MODE 0) writes per-slice partial sums of gy and gy*yj; pass 2 (MODE 1) adds them up per channel and writes the gradient,
 // gated by x_j > 0 when relu_gate (the tap is a ReLU output and nothing else consumes it: relu5_1).
 constexpr int SLICE_ROWS = 256;
-template <int MODE>
-__global__ __launch_bounds__(256) void loss_tap_bwd_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ var,
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void loss_tap_bwd_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ var,
                                                            const float* __restrict__ coefA, const float* __restrict__ coefB, float* __restrict__ partial,
-                                                           const float* __restrict__ sums, float* __restrict__ dx, int B, int HW, int C, float eps, float wc, int squared,
+                                                           const float* __restrict__ sums, T* __restrict__ dx, int B, int HW, int C, float eps, float wc, int squared,
                                                            int relu_gate, int nslice) {
     extern __shared__ float red[];                              // MODE 0: [2][RPB][C]
     const int TPR = C / 4, RPB = 256 / TPR;
@@ -229,8 +249,8 @@ __global__ __launch_bounds__(256) void loss_tap_bwd_kernel(const float* __restri
     }
     if (tr < RPB)
         for (int r = r0 + tr; r < r1; r += RPB) {
-            const f32x4 va = *(const f32x4*)(x + ((size_t)i * HW + r) * C + tc * 4);
-            const f32x4 vb = *(const f32x4*)(x + ((size_t)j * HW + r) * C + tc * 4);
+            const f32x4 va = El<T>::ld4(x + ((size_t)i * HW + r) * C + tc * 4);
+            const f32x4 vb = El<T>::ld4(x + ((size_t)j * HW + r) * C + tc * 4);
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -243,7 +263,7 @@ __global__ __launch_bounds__(256) void loss_tap_bwd_kernel(const float* __restri
                     o[e] = gx;
                 }
             }
-            if (MODE == 1) *(f32x4*)(dx + ((size_t)i * HW + r) * C + tc * 4) = o;
+            if (MODE == 1) El<T>::st4(dx + ((size_t)i * HW + r) * C + tc * 4, o);
         }
     if (MODE == 0) {
 #pragma unroll
@@ -302,16 +322,20 @@ int fold_reflect_launch(const float* dxp, float* out, int B, int H, int W, int C
     hipLaunchKernelGGL(fold_reflect_kernel, dim3(blocks_for(total)), dim3(256), 0, s, dxp, out, H, W, C, up, total);
     return master_check_launch("fold_reflect");
 }
-int maxpool2_bwd_launch(const float* g, const float* y, float* dx, int N, int H, int W, int C, hipStream_t s) {
+template <typename T> int maxpool2_bwd_launch(const void* g, const void* y, void* dx, int N, int H, int W, int C, hipStream_t s) {
     const size_t total = (size_t)N * (H / 2) * (W / 2) * C;
-    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, s, g, y, dx, H, W, C, total);
+    hipLaunchKernelGGL((maxpool2_bwd_kernel<T>), dim3(blocks_for(total)), dim3(256), 0, s, (const T*)g, (const T*)y, (T*)dx, H, W, C, total);
     return master_check_launch("maxpool2_bwd");
 }
-int nhwc_to_image_launch(const float* g, float* out, int N, int HW, int Cp, hipStream_t s) {
+template int maxpool2_bwd_launch<float>(const void*, const void*, void*, int, int, int, int, hipStream_t);
+template int maxpool2_bwd_launch<bf16_t>(const void*, const void*, void*, int, int, int, int, hipStream_t);
+template <typename T> int nhwc_to_image_launch(const void* g, float* out, int N, int HW, int Cp, hipStream_t s) {
     const size_t total = (size_t)N * 3 * HW;
-    hipLaunchKernelGGL(nhwc_to_image_kernel, dim3(blocks_for(total)), dim3(256), 0, s, g, out, HW, Cp, total);
+    hipLaunchKernelGGL((nhwc_to_image_kernel<T>), dim3(blocks_for(total)), dim3(256), 0, s, (const T*)g, out, HW, Cp, total);
     return master_check_launch("nhwc_to_image");
 }
+template int nhwc_to_image_launch<float>(const void*, float*, int, int, int, hipStream_t);
+template int nhwc_to_image_launch<bf16_t>(const void*, float*, int, int, int, hipStream_t);
 int rowscale_add_launch(const float* x, const float* res, const float* scale, float* out, int B, int T, int C, hipStream_t s) {
     const size_t total4 = (size_t)B * T * (C / 4);
     hipLaunchKernelGGL(rowscale_add_kernel, dim3(blocks_for(total4, 2048)), dim3(256), 0, s, x, res, scale, out, T, C / 4, total4);
@@ -338,15 +362,19 @@ int lerp_launch(const void* table, int ntensors, long long nblocks, float eta, h
 }
 int loss_tap_slices(int HW) { return (HW + SLICE_ROWS - 1) / SLICE_ROWS; }
 // partial: B * (slices + 1) * 2 * C floats of workspace (slice partials, then their sums); dx: [B, HW, C]
-int loss_tap_bwd_launch(const float* x, const float* mean, const float* var, const float* coefA, const float* coefB, float* partial, float* dx,
+template <typename T>
+int loss_tap_bwd_launch(const void* xv, const float* mean, const float* var, const float* coefA, const float* coefB, float* partial, void* dxv,
                         int B, int HW, int C, float eps, float wc, int squared, int relu_gate, hipStream_t s) {
+    const T* x = (const T*)xv; T* dx = (T*)dxv;
     const int ns = loss_tap_slices(HW);
     float* sums = partial + (size_t)B * ns * 2 * C;
     const size_t lds = (size_t)2 * (256 / (C / 4)) * C * sizeof(float);
-    hipLaunchKernelGGL((loss_tap_bwd_kernel<0>), dim3(ns, B), dim3(256), lds, s, x, mean, var, coefA, coefB, partial, (const float*)nullptr, dx, B, HW,
+    hipLaunchKernelGGL((loss_tap_bwd_kernel<T, 0>), dim3(ns, B), dim3(256), lds, s, x, mean, var, coefA, coefB, partial, (const float*)nullptr, dx, B, HW,
                        C, eps, wc, squared, relu_gate, ns);
     hipLaunchKernelGGL(loss_tap_finalize_kernel, dim3((B * 2 * C + 255) / 256), dim3(256), 0, s, (const float*)partial, sums, HW, C, ns, B * 2 * C);
-    hipLaunchKernelGGL((loss_tap_bwd_kernel<1>), dim3(ns, B), dim3(256), 0, s, x, mean, var, coefA, coefB, partial, (const float*)sums, dx, B, HW, C,
+    hipLaunchKernelGGL((loss_tap_bwd_kernel<T, 1>), dim3(ns, B), dim3(256), 0, s, x, mean, var, coefA, coefB, partial, (const float*)sums, dx, B, HW, C,
                        eps, wc, squared, relu_gate, ns);
     return master_check_launch("loss_tap_bwd");
 }
+template int loss_tap_bwd_launch<float>(const void*, const float*, const float*, const float*, const float*, float*, void*, int, int, int, float, float, int, int, hipStream_t);
+template int loss_tap_bwd_launch<bf16_t>(const void*, const float*, const float*, const float*, const float*, float*, void*, int, int, int, float, float, int, int, hipStream_t);

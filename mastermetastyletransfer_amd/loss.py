@@ -6,7 +6,9 @@ zero-padded implicit-GEMM convolutions - then
     total   = content + lambda * style                                 (loss.py:246)
 Same class name, constructor keywords, forward signature and return tuples as the reference.  When the output image carries a
 gradient (train step, train_only_inner_loop.py:529-575) the loss is one autograd Function (autograd.PerceptualLossFn) whose backward
-runs the loss-tap gradient, the VGG-19 data-gradient chain and the max-pool / ReLU backward on the HIP kernels (fp32 mode).
+runs the loss-tap gradient, the VGG-19 data-gradient chain and the max-pool / ReLU backward on the HIP kernels - in the loss
+network's compute dtype: fp32 (parity), or bf16 via set_compute_dtype(torch.bfloat16) (the network is frozen: only activations and
+data gradients are bf16; statistics, loss values and the image gradient stay fp32).
 """
 from __future__ import annotations
 
@@ -55,6 +57,23 @@ class VGG19_custom(nn.Module):
                 hit = (key, ops.convert(w.contiguous().float(), self.compute_dtype), conv.bias.detach().float().contiguous())
             self._packed[i] = hit
         return hit[1], hit[2]
+
+    def _flipped(self, i: int):
+        """weights of conv i for its DATA gradient: [Cin (3 -> 32)][3][3][Cout] with the taps flipped, in the compute dtype; cached
+        (the network is frozen, loss.py:173-175)"""
+        conv = self.features[i]
+        key = (conv.weight.data_ptr(), conv.weight._version, self.compute_dtype, str(conv.weight.device))
+        cache = self.__dict__.setdefault("_flip_cache", {})
+        hit = cache.get(i)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                w = conv.weight.detach().float()
+                if w.shape[1] % 32:
+                    w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, _CPAD - w.shape[1]))
+                wf = w.flip(2, 3).permute(1, 2, 3, 0).contiguous()
+                hit = (key, ops.convert(wf, self.compute_dtype))
+            cache[i] = hit
+        return hit[1]
 
     def forward(self, x: Tensor):
         """x: fp32 NCHW image batch -> list of four NHWC feature maps in the compute dtype"""
@@ -122,16 +141,10 @@ class custom_loss(nn.Module):
             loss_weight = self.lambda_value
         B = content_image.shape[0]
         if output_image.requires_grad and torch.is_grad_enabled():
-            if self.feature_extractor_model.compute_dtype != torch.float32:
-                raise NotImplementedError("the loss backward runs in the fp32 mode: custom_loss.set_compute_dtype(torch.float32)")
-            from .autograd import PerceptualLossFn, VGG19_CONVS as _ORDER
-            wb = []
-            for i in _ORDER:
-                conv = self.feature_extractor_model.features[i]
-                wb += [conv.weight, conv.bias]
-            content_loss, style_loss = PerceptualLossFn.apply(content_image, style_image, output_image,
+            from .autograd import PerceptualLossFn
+            content_loss, style_loss = PerceptualLossFn.apply(content_image, style_image, output_image, self.feature_extractor_model,
                                                               self.distance_content == "euclidian_squared",
-                                                              self.distance_style == "euclidian_squared", *wb)
+                                                              self.distance_style == "euclidian_squared")
             total_loss = content_loss + loss_weight * style_loss
             if output_similarity_loss:
                 similarity_loss = torch.zeros((), dtype=torch.float32, device=content_image.device)
