@@ -111,7 +111,10 @@ def _mlp_fwd(owner: _HipModule, name: str, mlp: nn.Sequential, x: Tensor, residu
     g = owner._b(name + ".ln_w", norm.weight) if norm is not None else None
     b = owner._b(name + ".ln_b", norm.bias) if norm is not None else None
     if ops.mlp_fused_supported(x, w1.shape[0]):
-        return ops.mlp(x, w1, b1, w2, b2, res=residual, ln_gamma=g, ln_beta=b, eps=norm.eps if norm is not None else EPS)
+        try:
+            return ops.mlp(x, w1, b1, w2, b2, res=residual, ln_gamma=g, ln_beta=b, eps=norm.eps if norm is not None else EPS)
+        except NotImplementedError:
+            pass          # MASTER_ERR_UNSUPPORTED (e.g. a hidden width whose bias vectors do not fit next to the weight ring): unfused path
     if norm is not None:
         x = ops.layernorm(x, g, b, norm.eps)
     h = ops.linear(x, w1, b1, act=ops.ACT_GELU)
@@ -655,9 +658,12 @@ class PatchMerging(_HipModule):
 
     def run(self, x2d: Tensor, B, H, W) -> Tensor:
         C = x2d.shape[1]
+        x = x2d.view(B, H, W, C)
         if H % 2 or W % 2:
-            raise NotImplementedError("odd feature maps need torchvision's pad-to-even; image sides must be multiples of 8")
-        return ops.patch_merge_linear(x2d.view(B, H, W, C), self._b("nw", self.norm.weight), self._b("nb", self.norm.bias),
+            # torchvision PatchMerging pads the map with zeros to even sides before the 2x2 gather (image sides that are multiples of 4
+            # but not of 8); the padded copy is plumbing, the gather + LayerNorm + Linear run on it unchanged
+            x = torch.nn.functional.pad(x, (0, 0, 0, W % 2, 0, H % 2)).contiguous()
+        return ops.patch_merge_linear(x, self._b("nw", self.norm.weight), self._b("nb", self.norm.bias),
                                       self._w("red", self.reduction.weight), self.norm.eps)
 
 
@@ -693,8 +699,8 @@ class SwinEncoder(nn.Sequential):
         """fp32 NCHW image batch(es) -> (token matrix [B*H/8*W/8, 2E] in the compute dtype, B, H/8, W/8).  Several
         batches (content, style) are embedded into consecutive slices of one buffer and encoded as one batch."""
         _, _, H, W = imgs[0].shape
-        if H % 8 or W % 8:
-            raise ValueError("image sides must be multiples of 8 (patch 4 + one 2x2 merge)")
+        if H % 4 or W % 4:
+            raise ValueError("image sides must be multiples of 4 (the 4x4 patch embedding has stride 4 and no padding)")
         conv, ln = self[0][0], self[0][2]
         B = sum(int(i.shape[0]) for i in imgs)
         x = torch.empty((B, H // 4, W // 4, conv.weight.shape[0]), dtype=self.compute_dtype, device=imgs[0].device)
@@ -721,7 +727,7 @@ class SwinEncoder(nn.Sequential):
         for blk in self[1]:
             x = blk.run(x, B, h, w, masks.get(id(blk)))
         x = self[2].run(x, B, h, w)
-        h, w = h // 2, w // 2
+        h, w = (h + 1) // 2, (w + 1) // 2
         for blk in self[3]:
             x = blk.run(x, B, h, w, masks.get(id(blk)))
         return x, B, h, w

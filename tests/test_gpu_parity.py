@@ -203,6 +203,19 @@ def test_swin_encoder_vs_oracle(cuda, B, S):
         assert_close(m.swin_encoder(img.to(cuda)), O.swin_encoder(img, swin_sd), f"swin encoder {S}", 2e-4)
 
 
+def test_full_forward_odd_feature_map(cuda):
+    """image sides that are multiples of 4 but not of 8 (260 x 132 -> 65 x 33 tokens): torchvision's PatchMerging pads the map to even
+    sides with zeros; the output is 8 * ceil(side / 8) like the reference's"""
+    m, (swin_sd, st_sd, dec_sd) = full_model(cuda)
+    c = seeded_input("c_odd", (1, 3, 260, 132), 8, kind="image")
+    s = seeded_input("s_odd", (1, 3, 260, 132), 9, kind="image")
+    with torch.no_grad():
+        got = m(c.to(cuda), s.to(cuda), 1)
+        ref = O.full_forward(c, s, 1, swin_sd, st_sd, dec_sd)
+    assert got.shape == ref.shape == (1, 3, 264, 136)
+    assert_close(got, ref, "full forward 260x132")
+
+
 @pytest.mark.parametrize("B,S,k", [(1, 256, 1), (2, 256, 1), (1, 256, 3), (1, 512, 1), (1, 64, 1), (1, 200, 1)])
 def test_full_forward_vs_oracle(cuda, B, S, k):
     """BASELINE configs[0] and [4] shapes: same content/style pair, same weights, <= 1e-3 max-abs."""
