@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / parity / cpu_baseline legs")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = the headline metric; train = BASELINE config 4: inner-loop train step bs=8 256x256 (fp32 mode), steps/s")
-    ap.add_argument("--eager", action="store_true", help="N > 1: enqueue kernel by kernel instead of replaying a HIP graph")
+    ap.add_argument("--eager", action="store_true", help="enqueue kernel by kernel instead of replaying a HIP graph of the forward")
     ap.add_argument("--loss-dtype", choices=["fp32", "bf16"], default="fp32", help="--mode train: compute dtype of the frozen VGG-19 loss network")
     args = ap.parse_args()
     if args.mode == "train":
@@ -91,16 +91,20 @@ def main():
     # fence() drains every outstanding collective, so the timed region contains all K gathers in full
     gather = AsyncImageGather(B * world, rank, world, depth=2)
 
-    # N > 1: the ranks of one node share the host, and the forward is ~75 launches (1.0 ms of enqueue per step): replay a HIP graph
-    # (one launch per step, bit-identical results) so that the ranks do not contend for host time; N = 1 keeps the eager path
+    # The forward is ~75 launches (1.0 ms of host enqueue per step against ~2.1 ms of device time): the timed loop replays a HIP graph of
+    # it (GraphedStylizer: one launch per step, same kernels in the same order, bit-identical results - tests/test_gpu_parity.py), so the
+    # number does not depend on host speed and the ranks of a node do not contend for host time.  --eager enqueues kernel by kernel.
     forward = lambda: model(content, style, k)
     launch_mode = "eager"
-    if world > 1 and not args.eager:
+    if not args.eager:
         try:
             from mastermetastyletransfer_amd import GraphedStylizer
             graphed = GraphedStylizer(model, B, S, S, k)
             graphed.content.copy_(content); graphed.style.copy_(style)
-            forward = lambda: (graphed.graph.replay(), graphed.out.clone())[1]     # private copy: the async gather of step i reads it while step i+1 replays
+            if world > 1:
+                forward = lambda: (graphed.graph.replay(), graphed.out.clone())[1]     # private copy: the async gather of step i reads it while step i+1 replays
+            else:
+                forward = lambda: (graphed.graph.replay(), graphed.out)[1]
             launch_mode = "hipGraph replay"
         except Exception as e:                      # a capture problem must not cost the scaling run: fall back to kernel-by-kernel enqueue
             print(f"[rank {rank}] hipGraph capture failed ({e!r}); running eager", file=sys.stderr, flush=True)
@@ -152,10 +156,10 @@ def main():
                                f"outputs all-gathered over RCCL when n_gpus>1",
                    "global_batch": B * world, "image_size": S, "transformer_layer_count": k, "parallelism": f"dp{world}"},
     }
+    result["forward_launch"] = launch_mode
     if world > 1:
         result["rccl_ranks_seen"] = ranks_seen
         result["per_rank_ms_per_step"] = per_rank_ms
-        result["forward_launch"] = launch_mode
 
     if rank == 0 and world == 1 and not args.no_extras:
         result.update(extras(model, content, style, k, args, ops))

@@ -293,24 +293,30 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
 
     auto phase1_step = [&](const unsigned char* slot, int kb, bool pipe) __attribute__((always_inline)) {
         const unsigned base = lds_off(slot) + r * 256;
-        u32x4 a[2][4];
+#ifdef MLP_PREFETCH2            // fragments requested TWO k-steps ahead (three register buffers): LDS latency under load > one k-step
+        constexpr int NBUF = 3;
+#else
+        constexpr int NBUF = 2;
+#endif
+        u32x4 a[NBUF][4];
         auto rd = [&](int buf, int s) {
             const unsigned ad = base + ((32 * s) ^ x256);
             LDS_READ128(a[buf][0], ad, 0); LDS_READ128(a[buf][1], ad, 8192);
             LDS_READ128(a[buf][2], ad, 16384); LDS_READ128(a[buf][3], ad, 24576);
         };
         rd(0, 0);
+        if (NBUF == 3) rd(1, 1);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-#ifdef MLP_X_NORD1
-            if (s == 0) { rd(1, 1); LGKM_WAIT(0); }
-#else
-            if (s + 1 < 8) { rd((s + 1) & 1, s + 1); LGKM_WAIT(4); } else { LGKM_WAIT(0); }
-#endif
+            if (NBUF == 3) {
+                if (s + 2 < 8) { rd((s + 2) % 3, s + 2); LGKM_WAIT(8); } else if (s + 1 < 8) { LGKM_WAIT(4); } else { LGKM_WAIT(0); }
+            } else {
+                if (s + 1 < 8) { rd((s + 1) & 1, s + 1); LGKM_WAIT(4); } else { LGKM_WAIT(0); }
+            }
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) {
-                Frag f; f.u = a[s & 1][jt];
+                Frag f; f.u = a[s % NBUF][jt];
                 hacc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, xf[kb * 8 + s].b, hacc[jt], 0, 0, 0);
 #ifndef MLP_X_NODMA1
                 if (jt == 1) { SB(); dma_piece(s); SB(); }      // two VALU instructions: hides behind the MFMA
