@@ -509,3 +509,38 @@ def test_train_step_with_bf16_loss_network(cuda):
     worst = min(cosines)
     print(f"bf16 loss network, B={B} {S}x{S}: cosine of the whole parameter gradient {whole:.4f}; worst tensor {worst[0]:.4f} ({worst[1]})")
     assert whole >= 0.999 and worst[0] >= 0.99, (whole, worst)
+
+
+def test_training_reduces_the_loss_and_checkpoints_roundtrip(cuda, tmp_path):
+    """functional check of the whole loop the reference's trainer runs (train_only_inner_loop.py:519-575, :370-385): 12 Adam steps on one
+    fixed batch with device-drawn StochasticDepth masks lower the loss; checkpoints written the reference's way
+    (state_dict of style_transformer / decoder) reload into a fresh model that reproduces the eval output bit for bit"""
+    from mastermetastyletransfer_amd import FusedAdam, custom_loss
+    B, S = 2, 96                                                   # 96 = 12 x 8: a 12 x 12 map -> padded windows + shift
+    sds = (seeded_state_dict(O.swin_shapes(), 1), seeded_state_dict(O.style_transformer_shapes(), 2), seeded_state_dict(O.decoder_shapes(), 3))
+    m = _model(cuda)
+    m.swin_encoder.load_state_dict(sds[0]); m.style_transformer.load_state_dict(sds[1]); m.decoder.load_state_dict(sds[2])
+    m = m.to(cuda).train()
+    for p in m.swin_encoder.parameters():
+        p.requires_grad = False
+    loss_fn = custom_loss(default_lambda_value=10.0, vgg_state_dict=seeded_state_dict(L.vgg19_shapes(), 4)).to(cuda)
+    opt = FusedAdam([{"params": m.style_transformer.parameters()}, {"params": m.decoder.parameters()}], lr=2e-4)
+    c = seeded_input("fit_c", (B, 3, S, S), 5, kind="image").to(cuda); s = seeded_input("fit_s", (B, 3, S, S), 6, kind="image").to(cuda)
+    torch.manual_seed(0)
+    losses = []
+    for it in range(12):
+        total = loss_fn(c, s, m(c, s, 1 + it % 2))
+        opt.zero_grad(); total.backward(); opt.step()
+        losses.append(float(total.detach()))
+    assert all(np.isfinite(losses)), losses
+    assert min(losses[-3:]) < 0.9 * losses[0], losses
+    torch.save(m.style_transformer.state_dict(), tmp_path / "st.pt"); torch.save(m.decoder.state_dict(), tmp_path / "dec.pt")
+    m.eval()
+    with torch.no_grad():
+        want = m(c, s, 2)
+    m2 = _model(cuda)
+    m2.swin_encoder.load_state_dict(sds[0])
+    m2.style_transformer.load_state_dict(torch.load(tmp_path / "st.pt")); m2.decoder.load_state_dict(torch.load(tmp_path / "dec.pt"))
+    m2 = m2.to(cuda).eval()
+    with torch.no_grad():
+        assert torch.equal(m2(c, s, 2), want)
