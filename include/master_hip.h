@@ -229,6 +229,22 @@ int master_linear_wgrad(const void* g, const void* a, void* dw, int M, int N, in
 size_t master_colsum_workspace_floats(int M, int N);
 int master_colsum(const void* x, void* out, void* ws, int M, int N, int ld, int dtype, master_stream_t stream);
 
+/* out[n] = sum_m x[m][n] * y[m][n]: the weight gradient of a per-channel affine (affine InstanceNorm).  Same workspace as master_colsum. */
+int master_colsum_prod(const void* x, const void* y, void* out, void* ws, int M, int N, int ld, int dtype, master_stream_t stream);
+
+/* Non-default StyleDecoder branches of the reference (both dtypes in the forward):
+ * master_channel_affine_fwd: out[m,c] = x[m,c] * gamma[c] + beta[c] (beta optional) - the affine half of
+ *   nn.InstanceNorm2d(dim, affine=True) (style_transformer.py:983-984) after master_instnorm_fwd; its data gradient is the same call
+ *   with beta = NULL on the upstream gradient.
+ * master_softmax_rows_fwd / _bwd: out[m,:] = softmax(scale * x[m,:]) over the first N columns of rows of stride ld (columns [N, ld)
+ *   are row padding and are written as zeros; N % 4 == 0, ld % 4 == 0) and its backward - the global single-head
+ *   attention of decoder_use_regular_MHA_instead_of_Swin_at_the_end (style_transformer.py:1100-1106); Q.K^T and P.V run on
+ *   master_linear_fwd. */
+int master_channel_affine_fwd(const void* x, const float* gamma, const float* beta, void* out, int M, int C, int dtype,
+                              master_stream_t stream);
+int master_softmax_rows_fwd(const void* x, void* out, int M, int N, int ld, float scale, int dtype, master_stream_t stream);
+int master_softmax_rows_bwd(const void* p, const void* g, void* dx, int M, int N, int ld, float scale, int dtype, master_stream_t stream);
+
 /* out[i] = sum_{k < splits} part[k * slab + i], i < n  (fixed order).  Used to add up per-window / per-workgroup partial gradients. */
 int master_reduce_slabs(const float* part, float* out, size_t n, size_t slab, int splits, master_stream_t stream);
 

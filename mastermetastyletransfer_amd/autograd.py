@@ -214,6 +214,53 @@ class InstNormFn(torch.autograd.Function):
         return dx, dpr, None, None, None, None
 
 
+class ChannelAffineFn(torch.autograd.Function):
+    """x * gamma[c] + beta[c] - the affine of nn.InstanceNorm2d(dim, affine=True) (style_transformer.py:983-984)"""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, gamma: Tensor, beta: Tensor):
+        x = _f32c(x)
+        ctx.save_for_backward(x, gamma)
+        return ops.channel_affine(x, gamma.detach().float().contiguous(), beta.detach().float().contiguous())
+
+    @staticmethod
+    @ops._on_device
+    def backward(ctx, g: Tensor):
+        x, gamma = ctx.saved_tensors
+        g = _f32c(g)
+        lib = load_library()
+        M, C = x.shape
+        dx = ops.channel_affine(g, gamma.detach().float().contiguous(), None) if ctx.needs_input_grad[0] else None
+        dgamma = None
+        if ctx.needs_input_grad[1]:
+            dgamma = torch.empty((C,), dtype=F, device=x.device)
+            ws = _ws(lib.master_colsum_workspace_floats(M, C), x.device)
+            _check(lib.master_colsum_prod(_p(g), _p(x), _p(dgamma), _p(ws), M, C, C, F32, _stream()), "master_colsum_prod")
+        dbeta = colsum(g) if ctx.needs_input_grad[2] else None
+        return dx, dgamma, dbeta
+
+
+class SoftmaxRowsFn(torch.autograd.Function):
+    """softmax(scale * x) over rows (the regular-MHA decoder end, style_transformer.py:1100-1106)"""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, scale: float, n_valid: int):
+        p = ops.softmax_rows(_f32c(x), scale, n_valid)
+        ctx.save_for_backward(p)
+        ctx.scale, ctx.n_valid = scale, n_valid
+        return p
+
+    @staticmethod
+    @ops._on_device
+    def backward(ctx, g: Tensor):
+        (p,) = ctx.saved_tensors
+        g = _f32c(g)
+        dx = torch.empty_like(p)
+        _check(load_library().master_softmax_rows_bwd(_p(p), _p(g), _p(dx), p.shape[0], ctx.n_valid, p.shape[1], float(ctx.scale), F32,
+                                                      _stream()), "master_softmax_rows_bwd")
+        return dx, None, None
+
+
 class RowScaleAddFn(torch.autograd.Function):
     """res + scale[b] * x  -  residual add with torchvision StochasticDepth(p, "row") on the branch (style_transformer.py:390-397)"""
 

@@ -19,7 +19,10 @@ int gemm_f32_wgrad(const float*, const float*, float*, int, int, int, int, int, 
 int gemm_f32_conv3x3_wgrad(const float*, const float*, float*, int, int, int, int, int, int, int, int, float*, size_t, hipStream_t);
 int reduce_slabs_launch(const float*, float*, size_t, size_t, int, hipStream_t);
 int colsum_slabs(int, int);
-int colsum_launch(const float*, float*, float*, int, int, int, hipStream_t);
+int colsum_launch(const float*, const float*, float*, float*, int, int, int, hipStream_t);
+template <typename T> int channel_affine_launch(const void*, const float*, const float*, void*, int, int, hipStream_t);
+template <typename T> int softmax_rows_launch(const void*, void*, int, int, int, float, hipStream_t);
+int softmax_rows_bwd_launch(const float*, const float*, float*, int, int, int, float, hipStream_t);
 int relu_mask_launch(const float*, const float*, float*, int, int, int, int, int, hipStream_t);
 int fold_reflect_launch(const float*, float*, int, int, int, int, int, hipStream_t);
 template <typename T> int maxpool2_bwd_launch(const void*, const void*, void*, int, int, int, int, hipStream_t);
@@ -179,7 +182,38 @@ int master_colsum(const void* x, void* out, void* ws, int M, int N, int ld, int 
     REQUIRE(ws || colsum_slabs(M, N) == 1, "colsum: workspace required");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_TRAIN_MISC, s);
-    return colsum_launch((const float*)x, (float*)out, (float*)ws, M, N, ld, s);
+    return colsum_launch((const float*)x, nullptr, (float*)out, (float*)ws, M, N, ld, s);
+}
+
+int master_colsum_prod(const void* x, const void* y, void* out, void* ws, int M, int N, int ld, int dtype, master_stream_t stream) {
+    F32_ONLY("colsum_prod");
+    REQUIRE(x && y && out && M > 0 && N > 0 && N % 4 == 0 && ld >= N && ld % 4 == 0 && al16(x) && al16(y), "colsum_prod: bad arguments");
+    REQUIRE(ws || colsum_slabs(M, N) == 1, "colsum_prod: workspace required");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_TRAIN_MISC, s);
+    return colsum_launch((const float*)x, (const float*)y, (float*)out, (float*)ws, M, N, ld, s);
+}
+
+int master_channel_affine_fwd(const void* x, const float* gamma, const float* beta, void* out, int M, int C, int dtype, master_stream_t stream) {
+    REQUIRE(x && gamma && out && M > 0 && C > 0 && C % 4 == 0 && al16(x) && al16(out), "channel_affine: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_INSTNORM, s);
+    return dtype == MASTER_F32 ? channel_affine_launch<float>(x, gamma, beta, out, M, C, s) : channel_affine_launch<bf16_t>(x, gamma, beta, out, M, C, s);
+}
+
+int master_softmax_rows_fwd(const void* x, void* out, int M, int N, int ld, float scale, int dtype, master_stream_t stream) {
+    REQUIRE(x && out && M > 0 && N > 0 && N % 4 == 0 && ld >= N && ld % 4 == 0 && al16(x) && al16(out), "softmax_rows: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_ATTN, s);
+    return dtype == MASTER_F32 ? softmax_rows_launch<float>(x, out, M, N, ld, scale, s) : softmax_rows_launch<bf16_t>(x, out, M, N, ld, scale, s);
+}
+
+int master_softmax_rows_bwd(const void* p, const void* g, void* dx, int M, int N, int ld, float scale, int dtype, master_stream_t stream) {
+    F32_ONLY("softmax_rows_bwd");
+    REQUIRE(p && g && dx && M > 0 && N > 0 && N % 4 == 0 && ld >= N && ld % 4 == 0 && al16(p) && al16(g) && al16(dx), "softmax_rows_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_ATTN_BWD, s);
+    return softmax_rows_bwd_launch((const float*)p, (const float*)g, (float*)dx, M, N, ld, scale, s);
 }
 
 int master_reduce_slabs(const float* part, float* out, size_t n, size_t slab, int splits, master_stream_t stream) {

@@ -49,8 +49,8 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 
 // ---- column sums: part[slab][n] = sum over the slab's rows of x[m][n]   (bias gradients; N % 4 == 0).  tpr = min(N/4, 64) threads
 //      cover a row chunk of 16-byte vectors, the other 256/tpr thread rows walk the slab's rows. ---------------------------------------
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ part, int M, int N, int ld, int rows_per_slab,
-                                                     int tpr) {
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ part, int M, int N,
+                                                     int ld, int rows_per_slab, int tpr) {
     __shared__ f32x4 red[256];
     const int lanes = 256 / tpr;
     const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr;
@@ -58,7 +58,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     const int r0 = blockIdx.y * rows_per_slab, r1 = min(r0 + rows_per_slab, M);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (n < N && ty < lanes)
-        for (int r = r0 + ty; r < r1; r += lanes) acc += *(const f32x4*)(x + (size_t)r * ld + n);
+        for (int r = r0 + ty; r < r1; r += lanes) {
+            const f32x4 v = *(const f32x4*)(x + (size_t)r * ld + n);
+            acc += y ? v * *(const f32x4*)(y + (size_t)r * ld + n) : v;          // y: column sums of the product x*y (affine-norm weight gradient)
+        }
     red[threadIdx.x] = acc;
     __syncthreads();
     if (ty == 0 && n < N) {
@@ -289,6 +292,64 @@ __global__ __launch_bounds__(256) void loss_tap_finalize_kernel(const float* __r
     sums[t] = s / (float)HW;
 }
 
+// ---- per-channel affine of an affine InstanceNorm2d (style_transformer.py:983-984): out[m,c] = x[m,c] * gamma[c] + beta[c] (beta optional) -----
+template <typename T>
+__global__ __launch_bounds__(256) void channel_affine_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             T* __restrict__ out, int C4, size_t total4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        f32x4 v = El<T>::ld4(x + 4 * i) * *(const f32x4*)(gamma + c);
+        if (beta) v += *(const f32x4*)(beta + c);
+        El<T>::st4(out + 4 * i, v);
+    }
+}
+
+// ---- row softmax of the regular-MHA decoder end (style_transformer.py:1104-1106): out[m,:] = softmax(scale * x[m,:]); one wave per row ----------
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__ x, T* __restrict__ out, int M, int N, int ld, float scale_log2e) {
+    const int lane = threadIdx.x & 63;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+        const T* xr = x + (size_t)row * ld; T* orow = out + (size_t)row * ld;
+        float mx = -3.0e38f;
+        for (int c = lane * 4; c < N; c += 256) { const f32x4 v = El<T>::ld4(xr + c); mx = fmaxf(mx, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]))); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float sum = 0.f;
+        for (int c = lane * 4; c < N; c += 256) {
+            const f32x4 v = El<T>::ld4(xr + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum += exp2f((v[e] - mx) * scale_log2e);
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        for (int c = lane * 4; c < ld; c += 256) {                 // columns [N, ld) are padding of the row: written as zeros
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            if (c < N) {
+                const f32x4 v = El<T>::ld4(xr + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = exp2f((v[e] - mx) * scale_log2e) * inv;
+            }
+            El<T>::st4(orow + c, o);
+        }
+    }
+}
+// dx[m,:] = scale * p[m,:] * (g[m,:] - sum_j g[m,j] p[m,j])      (p = the softmax output)
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ p, const float* __restrict__ g, float* __restrict__ dx, int M,
+                                                               int N, int ld, float scale) {
+    const int lane = threadIdx.x & 63;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+        const float* pr = p + (size_t)row * ld; const float* gr = g + (size_t)row * ld;
+        float dot = 0.f;
+        for (int c = lane * 4; c < N; c += 256) { const f32x4 a = *(const f32x4*)(pr + c), b = *(const f32x4*)(gr + c); dot += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+        dot = wave_sum(dot);
+        for (int c = lane * 4; c < ld; c += 256) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            if (c < N) { const f32x4 a = *(const f32x4*)(pr + c), b = *(const f32x4*)(gr + c); o = a * (b - dot) * scale; }
+            *(f32x4*)(dx + (size_t)row * ld + c) = o;
+        }
+    }
+}
+
 inline unsigned blocks_for(size_t n, unsigned cap = 0x7fffffffu) { size_t b = (n + 255) / 256; return (unsigned)(b > cap ? cap : (b ? b : 1)); }
 
 }  // namespace
@@ -306,9 +367,9 @@ int colsum_slabs(int M, int N) {                      // row slabs such that the
     return slabs < 1 ? 1 : slabs;
 }
 // ws: colsum_slabs(M, N) * N floats
-int colsum_launch(const float* x, float* out, float* ws, int M, int N, int ld, hipStream_t s) {
+int colsum_launch(const float* x, const float* y, float* out, float* ws, int M, int N, int ld, hipStream_t s) {
     const int slabs = colsum_slabs(M, N), rps = (M + slabs - 1) / slabs, tpr = colsum_tpr(N);
-    hipLaunchKernelGGL(colsum_kernel, dim3((N / 4 + tpr - 1) / tpr, slabs), dim3(256), 0, s, x, slabs == 1 ? out : ws, M, N, ld, rps, tpr);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N / 4 + tpr - 1) / tpr, slabs), dim3(256), 0, s, x, y, slabs == 1 ? out : ws, M, N, ld, rps, tpr);
     if (slabs > 1) return reduce_slabs_launch(ws, out, (size_t)N, (size_t)N, slabs, s);
     return master_check_launch("colsum");
 }
@@ -378,3 +439,22 @@ int loss_tap_bwd_launch(const void* xv, const float* mean, const float* var, con
 }
 template int loss_tap_bwd_launch<float>(const void*, const float*, const float*, const float*, const float*, float*, void*, int, int, int, float, float, int, int, hipStream_t);
 template int loss_tap_bwd_launch<bf16_t>(const void*, const float*, const float*, const float*, const float*, float*, void*, int, int, int, float, float, int, int, hipStream_t);
+template <typename T> int channel_affine_launch(const void* x, const float* gamma, const float* beta, void* out, int M, int C, hipStream_t s) {
+    const size_t total4 = (size_t)M * (C / 4);
+    hipLaunchKernelGGL((channel_affine_kernel<T>), dim3(blocks_for(total4, 2048)), dim3(256), 0, s, (const T*)x, gamma, beta, (T*)out, C / 4, total4);
+    return master_check_launch("channel_affine");
+}
+template int channel_affine_launch<float>(const void*, const float*, const float*, void*, int, int, hipStream_t);
+template int channel_affine_launch<bf16_t>(const void*, const float*, const float*, void*, int, int, hipStream_t);
+template <typename T> int softmax_rows_launch(const void* x, void* out, int M, int N, int ld, float scale, hipStream_t s) {
+    int blocks = (M + 3) / 4; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL((softmax_rows_kernel<T>), dim3(blocks), dim3(256), 0, s, (const T*)x, (T*)out, M, N, ld, scale * 1.4426950408889634f);
+    return master_check_launch("softmax_rows");
+}
+template int softmax_rows_launch<float>(const void*, void*, int, int, int, float, hipStream_t);
+template int softmax_rows_launch<bf16_t>(const void*, void*, int, int, int, float, hipStream_t);
+int softmax_rows_bwd_launch(const float* p, const float* g, float* dx, int M, int N, int ld, float scale, hipStream_t s) {
+    int blocks = (M + 3) / 4; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(blocks), dim3(256), 0, s, p, g, dx, M, N, ld, scale);
+    return master_check_launch("softmax_rows_bwd");
+}

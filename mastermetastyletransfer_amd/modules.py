@@ -321,10 +321,13 @@ class ShiftedWindowAttention_for_decoder_last_MHA(_WindowAttentionBase):
             raise ValueError("window_size and shift_size must be of length 2")
         _check_arch(dropout, attention_dropout, qkv_bias, proj_bias, nn.GELU, dim, num_heads)
         if use_q_proj:
-            raise NotImplementedError("use_q_proj=True is not implemented on the HIP path (the reference never enables it)")
-        for n in (instance_norm_q, instance_norm_k):
-            if n is not None and getattr(n, "affine", False):
-                raise NotImplementedError("affine InstanceNorm is not implemented on the HIP path (reference default False)")
+            raise NotImplementedError("use_q_proj=True is not implemented on the HIP path (StyleDecoder hard-codes False, style_transformer.py:1022)")
+        # the reference registers the norm modules it is handed as children (:645-646): with affine=True their weight/bias appear in the
+        # state dict under this module too (shared with StyleDecoder.instance_norm_Query / _Key)
+        if instance_norm_q is not None and getattr(instance_norm_q, "affine", False):
+            self.instance_norm_q = instance_norm_q
+        if instance_norm_k is not None and getattr(instance_norm_k, "affine", False):
+            self.instance_norm_k = instance_norm_k
         self.window_size, self.shift_size, self.num_heads = list(window_size), list(shift_size), num_heads
         self.use_q_proj = use_q_proj
         self.use_Key_instance_norm_after_linear_transformation = use_Key_instance_norm_after_linear_transformation
@@ -339,17 +342,22 @@ class ShiftedWindowAttention_for_decoder_last_MHA(_WindowAttentionBase):
         """token-matrix form.  Returns (sigma, mu), or Query*sigma+mu when fuse_query is given
         (style_transformer.py:1123 folded into the second proj's epilogue)."""
         T = H * W
+        nq, nk = getattr(self, "instance_norm_q", None), getattr(self, "instance_norm_k", None)      # affine norms, or None
+        aff = lambda t, n, tag: t if n is None else ops.channel_affine(t, self._b(tag + ".w", n.weight), self._b(tag + ".b", n.bias))
         q, _ = ops.instnorm(xq, B, T, repeat=q_norm_repeat)                         # :468 (repeat=2: also the caller's :1056)
+        q = aff(q, nq, "inq")
         if not self.use_Key_instance_norm_after_linear_transformation:
             xk, _ = ops.instnorm(xk, B, T)                                          # :470-472
+            xk = aff(xk, nk, "ink")
         k = ops.linear(xk, self._w("k", self.Wk.weight), self._b("k", self.Wk.bias))
         k_pad = self._row("k", self.Wk.bias)
         if self.use_Key_instance_norm_after_linear_transformation:
             # :520-530  statistics over the zero-padded pH x pW map: its padded slots hold Wk.bias
             plan = window_plan(H, W, self.window_size, self.shift_size, xq.device)
             k, k_pad_b = ops.instnorm(k, B, T, pad_row=k_pad, n_pad=plan.n_pad)
+            k = aff(k, nk, "ink")
             if k_pad_b is not None:
-                k_pad = k_pad_b
+                k_pad = k_pad_b if nk is None else aff(k_pad_b.contiguous(), nk, "ink")
         vs = ops.linear(xs, self._w("vs", self.Wv_scale.weight), self._b("vs", self.Wv_scale.bias))
         vsh = ops.linear(xsh, self._w("vsh", self.Wv_shift.weight), self._b("vsh", self.Wv_shift.bias))
         o_s, o_sh = self._core(q, k, [vs, vsh], k_pad, [self._row("vs", self.Wv_scale.bias), self._row("vsh", self.Wv_shift.bias)], B, H, W)
@@ -441,37 +449,101 @@ class StyleDecoder(_HipModule):
                  decoder_use_Key_instance_norm_after_linear_transformation: bool = True,
                  decoder_exclude_MLP_after_Fcs_self_MHA: bool = False):
         super().__init__()
-        if decoder_use_regular_MHA_instead_of_Swin_at_the_end:
-            raise NotImplementedError("decoder_use_regular_MHA_instead_of_Swin_at_the_end=True (global O(N^2) attention, "
-                                      "reference style_transformer.py:1063-1119) is not implemented on the HIP path")
-        if decoder_use_instance_norm_with_affine:
-            raise NotImplementedError("affine InstanceNorm is not implemented on the HIP path (reference default False)")
         self.decoder_dim, self.decoder_num_heads, self.decoder_mlp_ratio = decoder_dim, decoder_num_heads, decoder_mlp_ratio
-        self.decoder_use_instance_norm_with_affine = False
-        self.decoder_use_regular_MHA_instead_of_Swin_at_the_end = False
+        self.decoder_use_instance_norm_with_affine = decoder_use_instance_norm_with_affine
+        self.decoder_use_regular_MHA_instead_of_Swin_at_the_end = decoder_use_regular_MHA_instead_of_Swin_at_the_end
         self.decoder_use_Key_instance_norm_after_linear_transformation = decoder_use_Key_instance_norm_after_linear_transformation
+        self.decoder_stochastic_depth_prob = decoder_stochastic_depth_prob
         self.MHA_self_attn = StyleSwinTransformerBlock(
             dim=decoder_dim, num_heads=decoder_num_heads, window_size=decoder_window_size, shift_size=decoder_shift_size,
             dropout=decoder_dropout, attention_dropout=decoder_attention_dropout, qkv_bias=decoder_qkv_bias,
             proj_bias=decoder_proj_bias, mlp_ratio=decoder_mlp_ratio, stochastic_depth_prob=decoder_stochastic_depth_prob,
             norm_layer=decoder_norm_layer, MLP_activation_layer=decoder_MLP_activation_layer,
             exclude_MLP_after=decoder_exclude_MLP_after_Fcs_self_MHA)
-        self.instance_norm = nn.InstanceNorm2d(decoder_dim, affine=False)          # parameter-free, kept for parity of the tree
+        if decoder_use_instance_norm_with_affine:                                  # :983-984
+            self.instance_norm_Query = nn.InstanceNorm2d(decoder_dim, affine=True)
+            self.instance_norm_Key = nn.InstanceNorm2d(decoder_dim, affine=True)
+            nq, nk = self.instance_norm_Query, self.instance_norm_Key
+        else:
+            self.instance_norm = nn.InstanceNorm2d(decoder_dim, affine=False)      # parameter-free, kept for parity of the tree
+            nq = nk = self.instance_norm
         self.last_MLP = _make_mlp(decoder_dim, int(decoder_dim * decoder_mlp_ratio), decoder_dropout)
-        self.decoder_MHA_for_sigma_and_mu = ShiftedWindowAttention_for_decoder_last_MHA(
-            dim=decoder_dim, num_heads=decoder_num_heads, window_size=decoder_window_size, shift_size=decoder_shift_size,
-            instance_norm_q=self.instance_norm, instance_norm_k=self.instance_norm, dropout=decoder_dropout,
-            attention_dropout=decoder_attention_dropout, qkv_bias=decoder_qkv_bias, proj_bias=decoder_proj_bias,
-            use_q_proj=False,
-            use_Key_instance_norm_after_linear_transformation=decoder_use_Key_instance_norm_after_linear_transformation)
+        if not decoder_use_regular_MHA_instead_of_Swin_at_the_end:
+            self.decoder_MHA_for_sigma_and_mu = ShiftedWindowAttention_for_decoder_last_MHA(
+                dim=decoder_dim, num_heads=decoder_num_heads, window_size=decoder_window_size, shift_size=decoder_shift_size,
+                instance_norm_q=nq, instance_norm_k=nk, dropout=decoder_dropout,
+                attention_dropout=decoder_attention_dropout, qkv_bias=decoder_qkv_bias, proj_bias=decoder_proj_bias,
+                use_q_proj=False,
+                use_Key_instance_norm_after_linear_transformation=decoder_use_Key_instance_norm_after_linear_transformation)
+        else:                                                                      # :1034-1041  global single-head attention at the end
+            self.linear_transformation_Key = nn.Linear(decoder_dim, decoder_dim)
+            self.linear_transformation_Scale = nn.Linear(decoder_dim, decoder_dim)
+            self.linear_transformation_Shift = nn.Linear(decoder_dim, decoder_dim)
+            self.proj_sigma = nn.Linear(decoder_dim, decoder_dim)
+            self.proj_mu = nn.Linear(decoder_dim, decoder_dim)
+
+    REGULAR_MHA_AFFINE_ERROR = ("expected input's size at dim=0 to match num_features ({dim}), but got: {B}.  (the reference hands "
+                                "InstanceNorm2d(affine=True) a 3-D [B, C, H*W] tensor in the regular-MHA branch, style_transformer.py:1073-1090)")
+
+    def _image_norm(self, x: Tensor, B: int, H: int, W: int) -> Tensor:
+        """The regular-MHA branch hands nn.InstanceNorm2d a 3-D [B, C, H*W] tensor (style_transformer.py:1073-1090): torch treats it as
+        one un-batched sample with B channels, i.e. every image is normalised over ALL its channels and tokens jointly (biased
+        variance, eps 1e-5).  Per-channel statistics (master_channel_stats_fwd) are combined on the host side of the device ([B,C]
+        arithmetic), the normalisation itself is one per-channel affine launch per image."""
+        C = x.shape[1]
+        T = H * W
+        mean, var = ops.channel_stats(x.view(B, H, W, C))
+        mu = mean.mean(dim=1)
+        v = (var + (mean - mu[:, None]) ** 2).mean(dim=1)
+        rstd = torch.rsqrt(v + EPS)
+        g = rstd[:, None].expand(B, C).contiguous()
+        b = (-mu * rstd)[:, None].expand(B, C).contiguous()
+        return torch.cat([ops.channel_affine(x[i * T:(i + 1) * T], g[i], b[i]) for i in range(B)], dim=0)
+
+    def _regular_mha(self, query: Tensor, key: Tensor, scale: Tensor, shift: Tensor, B: int, H: int, W: int) -> Tensor:
+        """:1060-1119  sigma, mu = proj(softmax(IN(Query) K^T / sqrt(C)) . V) with ONE head over all H*W tokens of the image; returns
+        Query * sigma + mu.  Q.K^T and P.V run on master_linear_fwd per image (K rows / V^T columns zero-padded to a multiple of 64
+        tokens), the softmax on master_softmax_rows_fwd."""
+        T, C = H * W, query.shape[1]
+        if self.decoder_use_instance_norm_with_affine:
+            raise ValueError(self.REGULAR_MHA_AFFINE_ERROR.format(dim=C, B=B)) if B != C else NotImplementedError(
+                "regular MHA with affine InstanceNorm and batch == dim is not implemented")
+        if T % 4:
+            raise NotImplementedError("the regular-MHA decoder end needs H*W % 4 == 0 tokens per image")
+        lin = lambda t, m, n: ops.linear(t, self._w(n, m.weight), self._b(n, m.bias))
+        q_in = self._image_norm(query, B, H, W)
+        if self.decoder_use_Key_instance_norm_after_linear_transformation:
+            k = self._image_norm(lin(key, self.linear_transformation_Key, "ltk"), B, H, W)
+        else:
+            k = lin(self._image_norm(key, B, H, W), self.linear_transformation_Key, "ltk")
+        vs, vsh = lin(scale, self.linear_transformation_Scale, "lts"), lin(shift, self.linear_transformation_Shift, "ltsh")
+        Tp = -(-T // 64) * 64
+        kp = torch.zeros((B, Tp, C), dtype=k.dtype, device=k.device); kp[:, :T] = k.view(B, T, C)
+        vT = torch.zeros((2, B, C, Tp), dtype=k.dtype, device=k.device)
+        vT[0, :, :, :T] = vs.view(B, T, C).transpose(1, 2); vT[1, :, :, :T] = vsh.view(B, T, C).transpose(1, 2)
+        att = torch.empty((2, B * T, C), dtype=k.dtype, device=k.device)
+        for i in range(B):
+            s = ops.linear(q_in[i * T:(i + 1) * T], kp[i])                                     # [T, Tp] logits (padding columns: 0, ignored)
+            p = ops.softmax_rows(s, C ** -0.5, n_valid=T)
+            ops.linear(p, vT[0, i], out=att[0, i * T:(i + 1) * T]); ops.linear(p, vT[1, i], out=att[1, i * T:(i + 1) * T])
+        mu = lin(att[1], self.proj_mu, "pmu")
+        return ops.linear(att[0], self._w("psg", self.proj_sigma.weight), self._b("psg", self.proj_sigma.bias), r1=query, r2=mu)
 
     def run(self, fcs: Tensor, key: Tensor, scale: Tensor, shift: Tensor, B, H, W) -> Tensor:
         T = H * W
         query = self.MHA_self_attn.run(fcs, fcs, [fcs], [fcs], B, H, W)[0]                     # :1047
-        k_in, _ = ops.instnorm(key, B, T)                                                      # :1057
-        # Query is instance-normalised here (:1056) and once more inside the sigma/mu attention (:468): one launch
-        query = self.decoder_MHA_for_sigma_and_mu.sigma_mu(query, k_in, scale, shift, B, H, W, fuse_query=query,
-                                                           q_norm_repeat=2)                    # :1056,:1059,:1123
+        if self.decoder_use_regular_MHA_instead_of_Swin_at_the_end:
+            query = self._regular_mha(query, key, scale, shift, B, H, W)                       # :1060-1123
+        elif self.decoder_use_instance_norm_with_affine:
+            nq, nk = self.instance_norm_Query, self.instance_norm_Key
+            q_in = ops.channel_affine(ops.instnorm(query, B, T)[0], self._b("inq.w", nq.weight), self._b("inq.b", nq.bias))   # :1056
+            k_in = ops.channel_affine(ops.instnorm(key, B, T)[0], self._b("ink.w", nk.weight), self._b("ink.b", nk.bias))     # :1057
+            query = self.decoder_MHA_for_sigma_and_mu.sigma_mu(q_in, k_in, scale, shift, B, H, W, fuse_query=query)           # :1059,:1123
+        else:
+            k_in, _ = ops.instnorm(key, B, T)                                                  # :1057
+            # Query is instance-normalised here (:1056) and once more inside the sigma/mu attention (:468): one launch
+            query = self.decoder_MHA_for_sigma_and_mu.sigma_mu(query, k_in, scale, shift, B, H, W, fuse_query=query,
+                                                               q_norm_repeat=2)                # :1056,:1059,:1123
         return _mlp_fwd(self, "last_mlp", self.last_MLP, query, query)                         # :1125
 
     def forward(self, Fcs: Tensor, Key: Tensor, Scale: Tensor, Shift: Tensor) -> Tensor:

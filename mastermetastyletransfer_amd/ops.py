@@ -29,7 +29,7 @@ EXPORTS = (
     "master_colsum_workspace_floats", "master_reduce_slabs", "master_layernorm_bwd", "master_layernorm_bwd_workspace_floats",
     "master_instnorm_bwd", "master_window_attn_bwd", "master_conv3x3_dgrad", "master_conv3x3_wgrad", "master_relu_mask",
     "master_fold_reflect", "master_maxpool2x2_bwd", "master_nhwc_to_image", "master_rowscale_add", "master_mul_add_fwd",
-    "master_mul_add_bwd", "master_loss_tap_bwd", "master_loss_tap_workspace_floats", "master_adam_chunk", "master_adam_step", "master_lerp",
+    "master_mul_add_bwd", "master_colsum_prod", "master_channel_affine_fwd", "master_softmax_rows_fwd", "master_softmax_rows_bwd", "master_loss_tap_bwd", "master_loss_tap_workspace_floats", "master_adam_chunk", "master_adam_step", "master_lerp",
 )
 
 _lib = None
@@ -109,6 +109,10 @@ def load_library() -> ctypes.CDLL:
     lib.master_colsum_workspace_floats.argtypes = [ci, ci]; lib.master_colsum_workspace_floats.restype = cz
     lib.master_colsum.argtypes = [vp] * 3 + [ci] * 4 + [vp]
     lib.master_reduce_slabs.argtypes = [vp, vp, cz, cz, ci, vp]
+    lib.master_colsum_prod.argtypes = [vp] * 4 + [ci] * 4 + [vp]
+    lib.master_channel_affine_fwd.argtypes = [vp] * 4 + [ci] * 3 + [vp]
+    lib.master_softmax_rows_fwd.argtypes = [vp] * 2 + [ci] * 3 + [cf, ci, vp]
+    lib.master_softmax_rows_bwd.argtypes = [vp] * 3 + [ci] * 3 + [cf, ci, vp]
     lib.master_layernorm_bwd_workspace_floats.argtypes = [ci, ci]; lib.master_layernorm_bwd_workspace_floats.restype = cz
     lib.master_layernorm_bwd.argtypes = [vp] * 6 + [ci, ci, cf, ci, vp]
     lib.master_instnorm_bwd.argtypes = [vp] * 6 + [ci] * 4 + [cf, ci, vp]
@@ -366,6 +370,29 @@ def instnorm(x: torch.Tensor, B: int, T: int, pad_row: Optional[torch.Tensor] = 
     _check(load_library().master_instnorm_fwd(_p(x), _p(out), _p(pad_row), _p(pad_out), B, T, C, n_pad, eps, repeat, _dt(x),
                                                _stream()), "master_instnorm_fwd")
     return out, pad_out
+
+
+@_on_device
+def channel_affine(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor]) -> torch.Tensor:
+    """x[m,c] * gamma[c] + beta[c]: the affine half of nn.InstanceNorm2d(dim, affine=True); gamma/beta fp32 [C]"""
+    _dev(x)
+    M, C = x.shape
+    assert x.is_contiguous() and gamma.dtype == torch.float32
+    out = torch.empty_like(x)
+    _check(load_library().master_channel_affine_fwd(_p(x), _p(gamma), _p(beta), _p(out), M, C, _dt(x), _stream()), "master_channel_affine_fwd")
+    return out
+
+
+@_on_device
+def softmax_rows(x: torch.Tensor, scale: float = 1.0, n_valid: Optional[int] = None) -> torch.Tensor:
+    """softmax(scale * x) over the first n_valid columns of every row of a [M, ld] matrix; the other columns (row padding) become 0"""
+    _dev(x)
+    M, ld = x.shape
+    assert x.is_contiguous()
+    out = torch.empty_like(x)
+    _check(load_library().master_softmax_rows_fwd(_p(x), _p(out), M, ld if n_valid is None else n_valid, ld, float(scale), _dt(x), _stream()),
+           "master_softmax_rows_fwd")
+    return out
 
 
 @_on_device

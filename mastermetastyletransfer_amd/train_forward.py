@@ -18,7 +18,8 @@ import torch
 from torch import Tensor, nn
 
 from . import ops
-from .autograd import (ConvReflectFn, InstNormFn, LayerNormFn, LinearFn, MLPFn, MulAddFn, RowScaleAddFn, WindowAttnFn)
+from .autograd import (ChannelAffineFn, ConvReflectFn, InstNormFn, LayerNormFn, LinearFn, MLPFn, MulAddFn, RowScaleAddFn, SoftmaxRowsFn,
+                       WindowAttnFn)
 from .window_plan import window_plan
 
 HEAD_DIM = 32
@@ -189,15 +190,18 @@ def sigma_mu(att, xq: Tensor, xk: Tensor, xs: Tensor, xsh: Tensor, B, H, W):
     T = H * W
     C = xq.shape[1]
     plan = window_plan(H, W, att.window_size, att.shift_size, xq.device)
-    q, _ = InstNormFn.apply(xq, None, B, T, 0, 1e-5)                                                # :468
+    nq, nk = getattr(att, "instance_norm_q", None), getattr(att, "instance_norm_k", None)           # affine norms, or None
+    aff = lambda t, n: t if n is None else ChannelAffineFn.apply(t, n.weight, n.bias)
+    q = aff(InstNormFn.apply(xq, None, B, T, 0, 1e-5)[0], nq)                                       # :468
     if not att.use_Key_instance_norm_after_linear_transformation:
-        xk, _ = InstNormFn.apply(xk, None, B, T, 0, 1e-5)                                           # :470-472
+        xk = aff(InstNormFn.apply(xk, None, B, T, 0, 1e-5)[0], nk)                                  # :470-472
     k = LinearFn.apply(xk, att.Wk.weight, att.Wk.bias)
     k_pad = att.Wk.bias
     if att.use_Key_instance_norm_after_linear_transformation:
         k, k_pad_b = InstNormFn.apply(k, att.Wk.bias, B, T, plan.n_pad, 1e-5)                       # :520-530 (padded map statistics)
+        k = aff(k, nk)
         if k_pad_b is not None:
-            k_pad = k_pad_b
+            k_pad = k_pad_b if nk is None else k_pad_b * nk.weight + nk.bias                        # [B,C]: the normalised pad row through the affine
     vs = LinearFn.apply(xs, att.Wv_scale.weight, att.Wv_scale.bias)
     vsh = LinearFn.apply(xsh, att.Wv_shift.weight, att.Wv_shift.bias)
     o_s, o_sh = WindowAttnFn.apply(q, k, vs, vsh, k_pad, att.Wv_scale.bias, att.Wv_shift.bias, _bias64(att), (0, 0, 0, 0), plan, B, T,
@@ -205,15 +209,55 @@ def sigma_mu(att, xq: Tensor, xk: Tensor, xs: Tensor, xsh: Tensor, B, H, W):
     return LinearFn.apply(o_s, att.proj.weight, att.proj.bias), LinearFn.apply(o_sh, att.proj.weight, att.proj.bias)   # :575-576,:594-595
 
 
+def _image_norm(x: Tensor, B: int, T: int) -> Tensor:
+    """the regular-MHA branch's InstanceNorm2d on a 3-D tensor = per-image normalisation over all channels and tokens (modules.py
+    StyleDecoder._image_norm).  Train form: [B] statistics by torch reductions of the [B*T, C] matrix (autograd differentiates them)."""
+    xb = x.view(B, -1)
+    mean = xb.mean(dim=1, keepdim=True)
+    var = ((xb - mean) ** 2).mean(dim=1, keepdim=True)
+    return ((xb - mean) * torch.rsqrt(var + 1e-5)).view_as(x)
+
+
+def regular_mha(dec, query: Tensor, key: Tensor, scale: Tensor, shift: Tensor, B, H, W):
+    """:1060-1119 (decoder_use_regular_MHA_instead_of_Swin_at_the_end): returns (sigma, mu)"""
+    T, C = H * W, query.shape[1]
+    if dec.decoder_use_instance_norm_with_affine:
+        raise ValueError(dec.REGULAR_MHA_AFFINE_ERROR.format(dim=C, B=B))
+    if T % 4:
+        raise NotImplementedError("the regular-MHA decoder end needs H*W % 4 == 0 tokens per image")
+    lin = lambda t, m: LinearFn.apply(t, m.weight, m.bias)
+    q_in = _image_norm(query, B, T)
+    if dec.decoder_use_Key_instance_norm_after_linear_transformation:
+        k = _image_norm(lin(key, dec.linear_transformation_Key), B, T)
+    else:
+        k = lin(_image_norm(key, B, T), dec.linear_transformation_Key)
+    vs, vsh = lin(scale, dec.linear_transformation_Scale), lin(shift, dec.linear_transformation_Shift)
+    Tp = -(-T // 32) * 32
+    pad = lambda t: torch.nn.functional.pad(t, (0, 0, 0, Tp - T))                                   # [T,C] -> [Tp,C] zero rows
+    outs_s, outs_sh = [], []
+    for i in range(B):
+        sl = slice(i * T, (i + 1) * T)
+        p = SoftmaxRowsFn.apply(LinearFn.apply(q_in[sl], pad(k[sl]), None), C ** -0.5, T)           # [T, Tp], padding columns zero
+        outs_s.append(LinearFn.apply(p, pad(vs[sl]).t().contiguous(), None))
+        outs_sh.append(LinearFn.apply(p, pad(vsh[sl]).t().contiguous(), None))
+    return lin(torch.cat(outs_s), dec.proj_sigma), lin(torch.cat(outs_sh), dec.proj_mu)
+
+
 def style_decoder(dec, fcs: Tensor, key: Tensor, scale: Tensor, shift: Tensor, B, H, W, sd: StochasticDepthMasks) -> Tensor:
-    """StyleDecoder.forward (:1045-1128), Swin sigma/mu branch"""
+    """StyleDecoder.forward (:1045-1128)"""
     T = H * W
     query = block(dec.MHA_self_attn, fcs, fcs, [fcs], [fcs], B, H, W, sd)[0]                          # :1047
-    q_in, _ = InstNormFn.apply(query, None, B, T, 0, 1e-5)                                            # :1056
-    k_in, _ = InstNormFn.apply(key, None, B, T, 0, 1e-5)                                              # :1057
-    sigma, mu = sigma_mu(dec.decoder_MHA_for_sigma_and_mu, q_in, k_in, scale, shift, B, H, W)         # :1059
+    if dec.decoder_use_regular_MHA_instead_of_Swin_at_the_end:
+        sigma, mu = regular_mha(dec, query, key, scale, shift, B, H, W)
+    else:
+        q_in, _ = InstNormFn.apply(query, None, B, T, 0, 1e-5)                                        # :1056
+        k_in, _ = InstNormFn.apply(key, None, B, T, 0, 1e-5)                                          # :1057
+        if dec.decoder_use_instance_norm_with_affine:
+            q_in = ChannelAffineFn.apply(q_in, dec.instance_norm_Query.weight, dec.instance_norm_Query.bias)
+            k_in = ChannelAffineFn.apply(k_in, dec.instance_norm_Key.weight, dec.instance_norm_Key.bias)
+        sigma, mu = sigma_mu(dec.decoder_MHA_for_sigma_and_mu, q_in, k_in, scale, shift, B, H, W)     # :1059
     query = MulAddFn.apply(query, sigma, mu)                                                          # :1123
-    p = dec.MHA_self_attn.stochastic_depth_prob       # StyleDecoder.stochastic_depth uses the same decoder_stochastic_depth_prob (:989)
+    p = dec.decoder_stochastic_depth_prob                                                             # (:989)
     return _residual(_mlp(dec.last_MLP, query), query, p, dec.training, sd, B, T)                     # :1125
 
 

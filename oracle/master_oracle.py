@@ -153,21 +153,35 @@ def instance_norm_nhwc(x: Tensor) -> Tensor:
     return y.permute(0, 2, 1).reshape(B, H, W, C)
 
 
+def instance_norm_nhwc_affine(x: Tensor, p: Dict[str, Tensor], key: Optional[str]) -> Tensor:
+    """instance_norm_nhwc, then the per-channel affine of nn.InstanceNorm2d(dim, affine=True) when `key` names its parameters
+    (decoder_use_instance_norm_with_affine, style_transformer.py:983-984)"""
+    y = instance_norm_nhwc(x)
+    return y if key is None else y * p[key + "weight"] + p[key + "bias"]
+
+
 def sigma_mu_attention(xq: Tensor, xk: Tensor, xs: Tensor, xsh: Tensor, p: Dict[str, Tensor],
-                       prefix: str, ws: Sequence[int], shift: Sequence[int], nh: int):
-    """reference shifted_window_attention_for_decoder_last_MHA, default flags
-    (use_q_proj=False, Key instance-norm after the linear map): style_transformer.py:414-611."""
+                       prefix: str, ws: Sequence[int], shift: Sequence[int], nh: int, in_q: Optional[str] = None, in_k: Optional[str] = None,
+                       key_in_after_linear: bool = True):
+    """reference shifted_window_attention_for_decoder_last_MHA (use_q_proj=False): style_transformer.py:414-611.
+    in_q / in_k: state-dict prefixes of affine InstanceNorm parameters (None: affine=False, the default);
+    key_in_after_linear: use_Key_instance_norm_after_linear_transformation (default True)."""
     B, H, W, C = xq.shape
     src, region, pH, pW = window_plan(H, W, tuple(ws), tuple(shift))
-    q = _to_windows(instance_norm_nhwc(xq), src)                     # :468 (second IN of Query), no Wq
+    q = _to_windows(instance_norm_nhwc_affine(xq, p, in_q), src)     # :468 (second IN of Query), no Wq
+    if not key_in_after_linear:
+        xk = instance_norm_nhwc_affine(xk, p, in_k)                  # :470-472
     k = F.linear(_to_windows(xk, src), p[prefix + "Wk.weight"], p[prefix + "Wk.bias"])
     vs = F.linear(_to_windows(xs, src), p[prefix + "Wv_scale.weight"], p[prefix + "Wv_scale.bias"])
     vsh = F.linear(_to_windows(xsh, src), p[prefix + "Wv_shift.weight"], p[prefix + "Wv_shift.bias"])
     # :520-530  Key un-windowed, InstanceNorm2d over the whole padded pH x pW map (bias-only rows
     # of the padding take part in the statistics), re-windowed.  Statistics do not depend on order.
     nW, N = src.shape
-    k = F.instance_norm(k.reshape(B, nW * N, C).permute(0, 2, 1), eps=EPS).permute(0, 2, 1)
-    k = k.reshape(B * nW, N, C)
+    if key_in_after_linear:
+        k = F.instance_norm(k.reshape(B, nW * N, C).permute(0, 2, 1), eps=EPS).permute(0, 2, 1)
+        if in_k is not None:
+            k = k * p[in_k + "weight"] + p[in_k + "bias"]
+        k = k.reshape(B * nW, N, C)
     bias = relative_position_bias(p[prefix + "relative_position_bias_table"],
                                   p[prefix + "relative_position_index"], ws)
     a = _attn_probs(_heads(q, nh), _heads(k, nh), bias, region, nh)
@@ -254,10 +268,39 @@ def style_decoder(fcs: Tensor, key: Tensor, scale: Tensor, shift_t: Tensor, p: D
     q = fcs + _sd(sd, shifted_window_attention(n1, n1, n1, p, b + "attn.", ws, sh, nh))  # :390
     if not cfg.get("decoder_exclude_MLP_after_Fcs_self_MHA", False):
         q = q + _sd(sd, mlp(F.layer_norm(q, (C,), p[b + "norm2.weight"], p[b + "norm2.bias"], EPS), p, b + "mlp."))  # :392
-    q_in = instance_norm_nhwc(q)                                                         # :1056
-    key_in = instance_norm_nhwc(key)                                                     # :1057
-    sigma, mu = sigma_mu_attention(q_in, key_in, scale, shift_t, p,
-                                   "decoder.decoder_MHA_for_sigma_and_mu.", ws, sh, nh)  # :1059
+    affine = cfg.get("decoder_use_instance_norm_with_affine", False)
+    in_q = "decoder.instance_norm_Query." if affine else None
+    in_k = "decoder.instance_norm_Key." if affine else None
+    after = cfg.get("decoder_use_Key_instance_norm_after_linear_transformation", True)
+    if not cfg.get("decoder_use_regular_MHA_instead_of_Swin_at_the_end", False):
+        q_in = instance_norm_nhwc_affine(q, p, in_q)                                     # :1056
+        key_in = instance_norm_nhwc_affine(key, p, in_k)                                 # :1057
+        sigma, mu = sigma_mu_attention(q_in, key_in, scale, shift_t, p, "decoder.decoder_MHA_for_sigma_and_mu.", ws, sh, nh,
+                                       in_q, in_k, after)                                # :1059
+    else:
+        # :1060-1119  one global single-head attention over all tokens of the image (no windows, no bias, no mask)
+        # The reference hands nn.InstanceNorm2d a 3-D tensor [B, C, H*W] here (:1073-1090); torch treats that as ONE un-batched
+        # sample with B "channels", so every image is normalised over ALL its channels and tokens jointly (biased variance, eps 1e-5)
+        # - reproduced as is.  (With affine=True the [dim] weight would meet B channels: the reference raises unless B == dim.)
+        if affine:
+            raise ValueError("decoder_use_regular_MHA_instead_of_Swin_at_the_end with affine InstanceNorm fails in the reference "
+                             "(InstanceNorm2d weight [dim] against B channels)")
+        B, H, W, _ = q.shape
+        lin = lambda t, n: F.linear(t, p[f"decoder.{n}.weight"], p[f"decoder.{n}.bias"])
+
+        def image_norm(t):
+            mean = t.mean(dim=(1, 2, 3), keepdim=True)
+            var = ((t - mean) ** 2).mean(dim=(1, 2, 3), keepdim=True)
+            return (t - mean) / torch.sqrt(var + EPS)
+        q_in = image_norm(q)
+        if after:
+            k2 = image_norm(lin(key, "linear_transformation_Key"))
+        else:
+            k2 = lin(image_norm(key), "linear_transformation_Key")
+        v_s, v_sh = lin(scale, "linear_transformation_Scale"), lin(shift_t, "linear_transformation_Shift")
+        a = F.softmax((q_in.reshape(B, H * W, C) * C ** -0.5) @ k2.reshape(B, H * W, C).transpose(-2, -1), dim=-1)
+        sigma = lin(a @ v_s.reshape(B, H * W, C), "proj_sigma").view(B, H, W, C)
+        mu = lin(a @ v_sh.reshape(B, H * W, C), "proj_mu").view(B, H, W, C)
     q = q * sigma + mu                                                                   # :1123 (un-normalised Query)
     return q + _sd(sd, mlp(q, p, "decoder.last_MLP."))                                   # :1125
 
@@ -370,7 +413,7 @@ def full_forward(content: Tensor, style: Tensor, k: int, swin_sd, st_sd, dec_sd,
 # --------------------------------------------------------------------------------------
 # state-dict shapes (used by tests to build seeded weights without the reference)
 # --------------------------------------------------------------------------------------
-def style_transformer_shapes(dim=256, heads=8, ws=(7, 7), mlp_ratio=4.0) -> Dict[str, Tuple[int, ...]]:
+def style_transformer_shapes(dim=256, heads=8, ws=(7, 7), mlp_ratio=4.0, affine_in=False, regular_mha=False) -> Dict[str, Tuple[int, ...]]:
     hid = int(dim * mlp_ratio)
     T = (2 * ws[0] - 1) * (2 * ws[1] - 1)
     N = ws[0] * ws[1]
@@ -395,7 +438,17 @@ def style_transformer_shapes(dim=256, heads=8, ws=(7, 7), mlp_ratio=4.0) -> Dict
     attn("decoder.MHA_self_attn.attn.", ("Wq", "Wk", "Wv", "proj"))
     mlp_("decoder.MHA_self_attn.mlp.")
     mlp_("decoder.last_MLP.")
-    attn("decoder.decoder_MHA_for_sigma_and_mu.", ("Wk", "Wv_scale", "Wv_shift", "proj"))
+    if affine_in:
+        for n in ("instance_norm_Query", "instance_norm_Key"):
+            s[f"decoder.{n}.weight"] = (dim,); s[f"decoder.{n}.bias"] = (dim,)
+    if regular_mha:
+        for n in ("linear_transformation_Key", "linear_transformation_Scale", "linear_transformation_Shift", "proj_sigma", "proj_mu"):
+            s[f"decoder.{n}.weight"] = (dim, dim); s[f"decoder.{n}.bias"] = (dim,)
+    else:
+        attn("decoder.decoder_MHA_for_sigma_and_mu.", ("Wk", "Wv_scale", "Wv_shift", "proj"))
+        if affine_in:        # the attention module registers the two norm modules it is handed as its own children (:645-646)
+            for n, src in (("instance_norm_q", "instance_norm_Query"), ("instance_norm_k", "instance_norm_Key")):
+                s[f"decoder.decoder_MHA_for_sigma_and_mu.{n}.weight"] = (dim,); s[f"decoder.decoder_MHA_for_sigma_and_mu.{n}.bias"] = (dim,)
     return s
 
 

@@ -103,8 +103,15 @@ def test_error_behaviour_mirrors_reference(lib):
         warnings.simplefilter("ignore")
         with pytest.raises(ValueError, match="path of the pretrained weights"):
             MasterStyleTransferModel(style_transformer_load_pretrained_weights=True, allow_random_swin_encoder=True)
-        with pytest.raises(NotImplementedError):
-            MasterStyleTransferModel(style_decoder_use_regular_MHA_instead_of_Swin_at_the_end=True, allow_random_swin_encoder=True)
+        with pytest.raises(NotImplementedError):      # the reference's F.dropout(training=True default) in eval mode cannot be mirrored
+            MasterStyleTransferModel(style_decoder_dropout=0.1, allow_random_swin_encoder=True)
+        # every other architectural flag of the reference constructs (and has the reference's state-dict keys)
+        alt = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7], allow_random_swin_encoder=True,
+                                       style_decoder_use_regular_MHA_instead_of_Swin_at_the_end=True)
+        assert set(alt.style_transformer.state_dict()) == set(O.style_transformer_shapes(regular_mha=True))
+        alt = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7], allow_random_swin_encoder=True,
+                                       style_decoder_use_instance_norm_with_affine=True)
+        assert set(alt.style_transformer.state_dict()) == set(O.style_transformer_shapes(affine_in=True))
         m = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7], allow_random_swin_encoder=True).eval()
     from mastermetastyletransfer_amd.ops import MasterHipError
     with pytest.raises(MasterHipError, match="no CPU fallback"):

@@ -413,3 +413,44 @@ def test_vgg19_vs_torchvision(cuda):
         v = v.to(cuda)
         for a, b in zip(v(img.to(cuda)), refs):
             assert_close(a.permute(0, 3, 1, 2), b, "HIP VGG-19 vs torchvision", 2e-4)
+
+
+@pytest.mark.parametrize("i", range(5))
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_non_default_decoder_branches(cuda, i, mode):
+    """decoder_use_instance_norm_with_affine, decoder_use_regular_MHA_instead_of_Swin_at_the_end and
+    decoder_use_Key_instance_norm_after_linear_transformation=False on the HIP path against the reference's own outputs
+    (tests/golden/golden_branches.npz): fp32 <= 1e-3 of max|ref| ... bf16 relative L2"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_branches as MB
+    from mastermetastyletransfer_amd import StyleTransformer
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_branches.npz"))
+    tag, affine, regular, after = MB.CASES[i]
+    sd, fc, fs, cfg = MB.case(i)
+    m = StyleTransformer(MB.DIM, MB.DIM, MB.NH, MB.NH, [7, 7], [7, 7], [4, 4], [4, 4], decoder_use_instance_norm_with_affine=affine,
+                         decoder_use_regular_MHA_instead_of_Swin_at_the_end=regular,
+                         decoder_use_Key_instance_norm_after_linear_transformation=after)
+    m.load_state_dict(sd)
+    m = m.to(cuda).eval()
+    for mod in m.modules():
+        if hasattr(mod, "compute_dtype"):
+            mod.compute_dtype = torch.float32 if mode == "fp32" else torch.bfloat16
+    for k in (1, 2):
+        with torch.no_grad():
+            got = m(fc.to(cuda), fs.to(cuda), k).float().cpu()
+        ref = torch.from_numpy(gold[f"{tag}_k{k}"])
+        if mode == "fp32":
+            assert_close(got, ref, f"{tag} k={k}", 1e-4)
+        else:
+            l2 = float((got - ref).norm() / ref.norm())
+            assert l2 < 3e-2, (tag, k, l2)
+
+
+def test_regular_mha_with_affine_norm_raises_like_the_reference(cuda):
+    from mastermetastyletransfer_amd import StyleTransformer
+    m = StyleTransformer(64, 64, 2, 2, [7, 7], [7, 7], [4, 4], [4, 4], decoder_use_instance_norm_with_affine=True,
+                         decoder_use_regular_MHA_instead_of_Swin_at_the_end=True).to(cuda).eval()
+    with pytest.raises(ValueError, match="to match num_features"):
+        with torch.no_grad():
+            m(torch.zeros(2, 8, 8, 64, device=cuda), torch.zeros(2, 8, 8, 64, device=cuda), 1)

@@ -544,3 +544,36 @@ def test_training_reduces_the_loss_and_checkpoints_roundtrip(cuda, tmp_path):
     m2 = m2.to(cuda).eval()
     with torch.no_grad():
         assert torch.equal(m2(c, s, 2), want)
+
+
+@pytest.mark.parametrize("i", [0, 1, 4])
+def test_non_default_decoder_branches_backward(cuda, i):
+    """train-mode gradients through the affine-InstanceNorm and regular-MHA decoder branches vs autograd through the oracle (fp32,
+    StochasticDepth off): every parameter gradient within 1e-3 of its max-abs (a smooth loss: sum of squares of the output)"""
+    import make_golden_branches as MB
+    from mastermetastyletransfer_amd import StyleTransformer
+    tag, affine, regular, after = MB.CASES[i]
+    sd, fc, fs, cfg = MB.case(i)
+    p = {k_: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k_, v in sd.items()}
+    if affine and not regular:          # shared parameters: one tensor under both names, like the reference module tree
+        for n, src in (("instance_norm_q", "instance_norm_Query"), ("instance_norm_k", "instance_norm_Key")):
+            for wb in ("weight", "bias"):
+                p[f"decoder.decoder_MHA_for_sigma_and_mu.{n}.{wb}"] = p[f"decoder.{src}.{wb}"]
+    out = O.style_transformer(fc, fs, 2, p, cfg)
+    (out * out).sum().backward()
+    m = StyleTransformer(MB.DIM, MB.DIM, MB.NH, MB.NH, [7, 7], [7, 7], [4, 4], [4, 4], encoder_stochastic_depth_prob=0.0,
+                         decoder_stochastic_depth_prob=0.0, decoder_use_instance_norm_with_affine=affine,
+                         decoder_use_regular_MHA_instead_of_Swin_at_the_end=regular,
+                         decoder_use_Key_instance_norm_after_linear_transformation=after)
+    m.load_state_dict(sd)
+    m = m.to(cuda).train()
+    got = m(fc.to(cuda), fs.to(cuda), 2)
+    check("out", got, out, 1e-4)
+    (got * got).sum().backward()
+    gscale = max(float(v.grad.abs().max()) for v in p.values() if v.is_floating_point() and v.grad is not None)
+    seen = set()
+    for n, prm in m.named_parameters():
+        if n.endswith("Wk.bias") or id(prm) in seen:
+            continue
+        seen.add(id(prm))
+        check(n, prm.grad, p[n].grad, floor=1e-3 * gscale)

@@ -80,3 +80,18 @@ def test_swin_encoder_shapes_and_determinism():
     y = O.swin_encoder(img, sd)
     assert y.shape == (1, 8, 8, 256) and torch.isfinite(y).all()
     assert torch.equal(y, O.swin_encoder(img, sd))
+
+
+@torch.no_grad()
+def test_non_default_decoder_branches():
+    """affine InstanceNorm, regular-MHA decoder end, Key InstanceNorm before the linear map: oracle vs the reference's outputs
+    (tests/golden/golden_branches.npz, written by make_golden_branches.py)"""
+    import os, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden_branches as MB
+    gold = np.load(os.path.join(here, "golden", "golden_branches.npz"))
+    for i, (tag, *_ ) in enumerate(MB.CASES):
+        sd, fc, fs, cfg = MB.case(i)
+        for k in (1, 2):
+            close(O.style_transformer(fc, fs, k, sd, cfg), gold[f"{tag}_k{k}"], f"{tag}_k{k}")
