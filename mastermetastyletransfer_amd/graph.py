@@ -36,7 +36,9 @@ class GraphedStylizer:
         torch.cuda.current_stream(p.device).wait_stream(side)
         torch.cuda.synchronize(p.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        # thread_local: only this thread's calls are checked during capture (a process-group watchdog thread of a multi-rank run may
+        # query events concurrently)
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out = model(self.content, self.style, self.k)
 
     def __call__(self, content_image: Tensor, style_image: Tensor, copy: bool = False) -> Tensor:
