@@ -204,6 +204,7 @@ int launch(const GemmArgs& p, hipStream_t s) {
 template <bool CONV>
 int dispatch(const GemmArgs& p, hipStream_t s) {
     // fewer than one 128x128 tile per CU (train step: 8 192-token matrices): 64-row tiles double the number of workgroups
+    // (forcing 64-row tiles on the larger inference shapes was measured 5-10 % slower: profiles/r02_ops_fp32_gemm_{base,tile64}.txt)
     if (p.N > 64 && (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) < 256) return launch<64, 128, 32, 64, CONV>(p, s);
     if (p.N > 64) return launch<128, 128, 64, 64, CONV>(p, s);
     if (p.N > 32) return launch<128, 64, 64, 32, CONV>(p, s);
