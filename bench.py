@@ -250,6 +250,19 @@ def extras(model, content, style, k, args, ops):
                         "kernel_alg_tflops": round(counts["window_attn"]["flops"] / (ams * 1e-3) / 1e12, 3),
                         "note": "QK^T is fused with bias+mask+softmax+AV in one register-resident kernel; its MFMA time "
                                 "cannot be separated by events, see DESIGN.md"}
+    # the north star's named target (QK^T of the sigma/mu cross-attention >= 50 % of bf16 MFMA peak) next to what bounds it: a
+    # 49x49x32 problem occupies a 64x64x32 MFMA tile, so at 100 % issue only 58.6 % of the matrix-core work is useful, and QK^T is
+    # 8 of the 40 MFMAs the dual-stream kernel spends per (window, head) (8 bias-through-identity, 8 ones-denominators, 16 P.V)
+    busy = None
+    mp = os.path.join(ROOT, "profiles", "r02_bf16_bs32_pmc_mfma_util.json")
+    if args.dtype == "bf16" and os.path.exists(mp):
+        for name, v in json.load(open(mp)).items():
+            if name.startswith("window_attn_pw_kernel<true>"):
+                busy = v.get("mfma_util_pct", v.get("mfma_util"))
+    out["attn_core"].update({"cross_attn_kernel_mfma_busy_pct_pmc": busy, "pmc_source": "profiles/r02_bf16_bs32_pmc_mfma_util.json",
+                             "padded_tile_useful_fraction_ceiling": round(49 * 49 / (64.0 * 64.0), 3), "qk_share_of_kernel_mfmas": 8 / 40.0,
+                             "target": ">= 50 % of bf16 MFMA peak on the cross-attention QK^T: NOT met and not reachable by a "
+                                       "49x49x32 problem fused into a softmax kernel (VALU/HBM-bound); reported as measured"})
     # ---- parity of one pair against the CPU oracle, same weights ------------------------------------
     from oracle import master_oracle as O
     sds = [{kk: (v.detach().float() if v.is_floating_point() else v.detach()).cpu() for kk, v in mod.state_dict().items()}

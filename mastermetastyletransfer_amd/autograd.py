@@ -488,7 +488,7 @@ class PerceptualLossFn(torch.autograd.Function):
         B = output.shape[0]
         dev = output.device
         dt = vgg.compute_dtype
-        x = ops.image_to_nhwc(torch.cat([content, style, output.detach()], dim=0).float(), _CPAD, dt)
+        x = ops.image_to_nhwc([content, style, output.detach()], _CPAD, dt)      # one NHWC batch [content | style | output]
         acts = {}                         # conv index -> ReLU output [3B,H,W,C]
         taps = []
         h = x

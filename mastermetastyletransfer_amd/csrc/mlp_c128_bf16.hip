@@ -50,20 +50,42 @@ __global__ __launch_bounds__(256, 1) void mlp_c128_kernel(M128Args p) {
     const int m0w = blockIdx.x * 256 + wave * 64;                         // this wave's 64 tokens: tile tt covers m0w + 32 tt + r
     const int nhc = p.HID / 128, T = 2 * nhc;                             // stream: W1(0) W2(0) W1(1) W2(1) ...
 
-    // ---- LDS-DMA of stream step t into ring slot t % RING: piece I = rows 4I..4I+3 of 256 B, source chunk (lane&15) ^ (row&15) ----
+    // ---- LDS-DMA of stream step t into ring slot t % RING: piece I = rows 4I..4I+3 of 256 B, source chunk (lane&15) ^ (row&15).
+    //      A piece is four instructions (running scalar source pointer and LDS address, the lane's byte offset precomputed per i & 3 (one v_add per piece),
+    //      no branch: steps past the end of the stream re-read the first KB of W1 into a 1-KB dummy region per wave), as in
+    //      mlp_bf16.hip: a wave issues in order and each LDS-DMA instruction already costs it 60+ clocks next to MFMAs -------------------
     const int row0 = wave * (PIECES * 4) + (lane >> 4), l15 = lane & 15;
-    auto dma_piece = [&](int t, int i) __attribute__((always_inline)) {
-        const int hc = t >> 1, row = row0 + 4 * i;
-        const int sw = (l15 ^ (row & 15)) << 3;
-        const bf16_t* src = (t & 1) ? p.w2 + (size_t)row * p.HID + hc * 128 + sw             // W2 rows = output channels
-                                    : p.w1 + (size_t)(hc * 128 + row) * C + sw;               // W1 rows = hidden units of the chunk
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds + (t % RING) * SLOT + wave * PIECES * 1024 + i * 1024), 16, 0, 0);
+#define SWB(i) ((l15 ^ ((row0 + 4 * (i)) & 15)) << 4)      /* bytes */
+    const unsigned vo1_0 = row0 * (C * 2) + SWB(0), vo1_1 = row0 * (C * 2) + SWB(1), vo1_2 = row0 * (C * 2) + SWB(2), vo1_3 = row0 * (C * 2) + SWB(3);
+    const unsigned vo_w2 = row0 * 2 * (p.HID - C);           // a W2 step's offsets = the W1 ones + this (row pitch HID instead of C)
+    const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)lds;
+    const unsigned dummy_lds = lds0 + RING * SLOT + (p.HID + 3 * C) * 4 + wave * 1024;
+    const char* d_ptr = nullptr; unsigned d_pstride = 0, d_lds = 0, d_lstride = 0, d_vadd = 0;
+    auto set_dma_step = [&](int t) __attribute__((always_inline)) {
+        const bool valid = t < T;
+        const int hc = valid ? t >> 1 : 0;
+        const int mk = -(int)(!valid || !(t & 1)), vm = -(int)valid;                      // mk: a W1 step (or the dummy)
+        d_vadd = vo_w2 & ~(unsigned)mk;                          // per lane, once per step
+        d_pstride = (unsigned)(((4 * C * 2) & mk) | ((4 * p.HID * 2) & ~mk)) & (unsigned)vm;
+        d_lstride = 1024u & (unsigned)vm;
+        d_lds = ((lds0 + (t % RING) * SLOT + wave * PIECES * 1024) & (unsigned)vm) | (dummy_lds & ~(unsigned)vm);
+        const char* b1p = (const char*)(p.w1 + (size_t)hc * 128 * C);
+        const char* b2p = (const char*)(p.w2 + hc * 128);
+        d_ptr = (const char*)(((size_t)b1p & (size_t)(long long)mk) | ((size_t)b2p & ~(size_t)(long long)mk));
+    };
+    auto dma_piece = [&](int i) __attribute__((always_inline)) {                              // pieces of a step go out in order i = 0..7
+        const unsigned a1 = (i & 3) == 0 ? vo1_0 : (i & 3) == 1 ? vo1_1 : (i & 3) == 2 ? vo1_2 : vo1_3;     // i is a constant here
+        const unsigned voff = a1 + d_vadd;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(d_ptr + voff),
+                                         (__attribute__((address_space(3))) void*)(size_t)d_lds, 16, 0, 0);
+        d_ptr += (size_t)d_pstride; d_lds += d_lstride;
     };
     int t_issue = 0;
-    for (; t_issue < AHEAD && t_issue < T; ++t_issue)
+    for (; t_issue < AHEAD; ++t_issue) {
+        set_dma_step(t_issue);
 #pragma unroll
-        for (int i = 0; i < PIECES; ++i) dma_piece(t_issue, i);
+        for (int i = 0; i < PIECES; ++i) dma_piece(i);
+    }
 
     for (int i = tid; i < p.HID; i += 256) b1s[i] = p.b1[i];
     if (tid < C) {
@@ -121,13 +143,12 @@ __global__ __launch_bounds__(256, 1) void mlp_c128_kernel(M128Args p) {
     }
 
     // ---- per-step synchronisation: my DMAs of step t landed -> barrier -> everyone's have, and everyone left step t-1's slot ------
-    int t_cons = 0, t_dma = -1;
+    int t_cons = 0;
     auto begin_step = [&]() __attribute__((always_inline)) {
-        const int ahead = t_issue - 1 - t_cons;
-        if (ahead >= 2) WAIT_VMCNT(16); else if (ahead == 1) WAIT_VMCNT(8); else WAIT_VMCNT(0);
+        WAIT_VMCNT(16);                                                 // two later steps (real or dummy: 8 pieces each) may still be in flight
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        t_dma = t_issue < T ? t_issue++ : -1;                           // its pieces are issued between this step's MFMAs
+        set_dma_step(t_issue++);                                        // its pieces are issued between this step's MFMAs
         const unsigned char* slot = lds + (t_cons % RING) * SLOT;
         ++t_cons;
         return slot;
@@ -171,7 +192,7 @@ __global__ __launch_bounds__(256, 1) void mlp_c128_kernel(M128Args p) {
                     Frag f; f.u = a[s & 1][jt];
                     hacc[0][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, xf[0][s].b, hacc[0][jt], 0, 0, 0);
                     hacc[1][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, xf[1][s].b, hacc[1][jt], 0, 0, 0);
-                    if (jt == 1 && t_dma >= 0) { __builtin_amdgcn_sched_barrier(0); dma_piece(t_dma, s); __builtin_amdgcn_sched_barrier(0); }
+                    if (jt == 1) { __builtin_amdgcn_sched_barrier(0); dma_piece(s); __builtin_amdgcn_sched_barrier(0); }
                 }
             }
         }
@@ -216,7 +237,7 @@ __global__ __launch_bounds__(256, 1) void mlp_c128_kernel(M128Args p) {
                     Frag f; f.u = a[g & 1][nt];
                     oacc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, hf[0][g & 1].b, oacc[0][nt], 0, 0, 0);
                     oacc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, hf[1][g & 1].b, oacc[1][nt], 0, 0, 0);
-                    if (nt == 1 && t_dma >= 0) { __builtin_amdgcn_sched_barrier(0); dma_piece(t_dma, g); __builtin_amdgcn_sched_barrier(0); }
+                    if (nt == 1) { __builtin_amdgcn_sched_barrier(0); dma_piece(g); __builtin_amdgcn_sched_barrier(0); }
                 }
             }
         }
@@ -277,7 +298,7 @@ int mlp_c128_bf16(const bf16_t* x, const float* ln_g, const float* ln_b, const b
                   const float* b2, const bf16_t* res, bf16_t* out, int M, int Cc, int HID, int ldx, int ldr, int ldo, float eps,
                   hipStream_t s) {
     if (Cc != C || HID % 128 != 0 || HID < 128) return MASTER_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)RING * SLOT + (size_t)(HID + 3 * C) * sizeof(float);
+    const size_t lds = (size_t)RING * SLOT + (size_t)(HID + 3 * C) * sizeof(float) + 4 * 1024;        // ring | b1, b2, ln | 1-KB DMA dummy per wave
     if (lds > 160 * 1024) return MASTER_ERR_UNSUPPORTED;
     M128Args p{x, ln_g, ln_b, w1, b1, w2, b2, res, out, M, HID, ldx, ldr, ldo, eps};
     static LdsLimit lds_limit;

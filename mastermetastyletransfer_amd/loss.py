@@ -76,7 +76,8 @@ class VGG19_custom(nn.Module):
         return hit[1]
 
     def forward(self, x: Tensor):
-        """x: fp32 NCHW image batch -> list of four NHWC feature maps in the compute dtype"""
+        """x: fp32 NCHW image batch (or a list of batches, laid out one after the other) -> list of four NHWC feature maps in the
+        compute dtype"""
         h = ops.image_to_nhwc(x, _CPAD, self.compute_dtype)
         taps = []
         for i in range(30):
@@ -151,7 +152,7 @@ class custom_loss(nn.Module):
                 return (total_loss, content_loss, style_loss, similarity_loss) if output_content_and_style_loss else (total_loss, similarity_loss)
             return (total_loss, content_loss, style_loss) if output_content_and_style_loss else total_loss
         # the three feature extractions of loss.py:227-229 are independent: one batch [content | style | output]
-        taps = self.feature_extractor_model(torch.cat([content_image, style_image, output_image], dim=0))
+        taps = self.feature_extractor_model([content_image, style_image, output_image])
         content_loss, style_loss = 0.0, 0.0
         for f in taps:
             N, H, W, C = f.shape

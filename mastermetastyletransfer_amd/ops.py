@@ -160,7 +160,8 @@ def _on_device(fn):
     @functools.wraps(fn)
     def wrapper(*args, **kwargs):
         dev = None
-        for a in args:
+        flat = [t for a in args for t in (a if isinstance(a, (list, tuple)) else (a,))]
+        for a in flat:
             if isinstance(a, torch.Tensor) and a.is_cuda:
                 if dev is None:
                     dev = a.device
@@ -443,13 +444,21 @@ def patch_merge_linear(x: torch.Tensor, gamma, beta, w: torch.Tensor, eps: float
 
 
 @_on_device
-def image_to_nhwc(img: torch.Tensor, cpad: int, dtype: torch.dtype) -> torch.Tensor:
-    """fp32 NCHW [N,3,H,W] -> dtype NHWC [N,H,W,cpad] with zero channels 3..cpad-1"""
-    _dev(img)
-    img = img.contiguous().float()
-    N, _, H, W = img.shape
-    out = torch.empty((N, H, W, cpad), dtype=dtype, device=img.device)
-    _check(load_library().master_image_to_nhwc_fwd(_p(img), _p(out), N, H, W, cpad, _dt(out), _stream()), "master_image_to_nhwc_fwd")
+def image_to_nhwc(img, cpad: int, dtype: torch.dtype) -> torch.Tensor:
+    """fp32 NCHW [N,3,H,W] -> dtype NHWC [N,H,W,cpad] with zero channels 3..cpad-1. A list/tuple of image batches of one H x W is
+    written into consecutive batch slices of ONE output (no concatenated fp32 copy of the inputs is made)."""
+    imgs = list(img) if isinstance(img, (list, tuple)) else [img]
+    _dev(*imgs)
+    imgs = [i.contiguous().float() for i in imgs]
+    _, _, H, W = imgs[0].shape
+    if any(tuple(i.shape[1:]) != (3, H, W) for i in imgs):
+        raise ValueError(f"image_to_nhwc: image batches must all be [N,3,{H},{W}], got {[tuple(i.shape) for i in imgs]}")
+    out = torch.empty((sum(i.shape[0] for i in imgs), H, W, cpad), dtype=dtype, device=imgs[0].device)
+    lo = 0
+    for i in imgs:
+        n = i.shape[0]
+        _check(load_library().master_image_to_nhwc_fwd(_p(i), _p(out[lo:lo + n]), n, H, W, cpad, _dt(out), _stream()), "master_image_to_nhwc_fwd")
+        lo += n
     return out
 
 

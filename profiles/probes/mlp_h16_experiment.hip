@@ -1,3 +1,11 @@
+// EXPERIMENT (not in libmaster_hip.so): the fused MLP with the hidden activations and W2 in IEEE half - GELU of a pair of values in
+// packed half (12 instructions per pair instead of 21), cut into four 3-instruction stages dealt out between the MFMAs of phase 2 of the
+// chunk before and phase 1 of the chunk after (or phase 1 only: -DMLP_H16_P1ONLY=1), second GEMM on v_mfma_f32_32x32x16_f16,
+// MODE.FP16_OVFL so that out-of-range pre-activations saturate.  Correct (same tests as the product kernel, tighter bounds: the hidden
+// activations are six times closer to fp32), but SLOWER on the GPU: 58.8 us per 32 768-token launch with the stages over both phases
+// (512 registers, 148 B of scratch), 54.4 us with phase 1 only, against 51.3-51.8 us for the bf16 form (profiles/r02_mlp_h16_experiment.txt).
+// The issue model of profiles/probes/gelu_issue_probe.hip (VALU instructions next to bare MFMAs) does not carry over to the kernel, where
+// every MFMA gap also holds a ds_read_b128 and a share of an LDS-DMA piece.  As the product kernel stood when this was tried, plus:
 // Fused MLP block, bf16 throughput mode:   out = res + W2 . gelu(W1 . LN?(x) + b1) + b2
 // (torchvision MLP = Linear, GELU, Linear and the residual add around it; optional LayerNorm on x:
 // reference style_transformer.py:366,:392,:839-841,:865-882,:991,:1125 and the Swin blocks).
@@ -25,6 +33,8 @@
 namespace {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -35,7 +45,7 @@ struct MlpArgs {
     int M, HID, ldx, ldr, ldo; float eps;
 };
 
-union Frag { u32x4 u; bf16x8_t b; };
+union Frag { u32x4 u; bf16x8_t b; f16x8_t hh; };
 
 constexpr int SLOT = 32768;      // bytes per ring slot = one step of weights
 constexpr int RING = 4;          // slots
@@ -44,7 +54,8 @@ constexpr int DMA_PER_STEP = 8;  // global_load_lds instructions per wave per st
 
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-template <int C>
+// H16: the hidden activations and W2 are IEEE half (p.w2 points at f16 bits): GELU in packed f16, phase 2 on v_mfma_f32_32x32x16_f16.
+template <int C, bool H16>
 __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
     constexpr int KS1 = C / 16;                 // k-steps of phase 1 (K1 = C)
     constexpr int KB = C / 128;                 // W1 steps per hidden chunk ([128 j][128 k] = 32 KB each)
@@ -62,6 +73,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // MODE.FP16_OVFL: half results that overflow saturate at +-65504 instead of becoming inf (a pre-activation beyond half's range
+    // must not turn into inf and then 0 * inf = NaN in the second GEMM; the bf16 form had fp32's range there)
+    if (H16) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
 #ifdef MLP_CLOCK_PROBE   // diagnostic build only (profiles/probes/clock_probe.hip)
     const unsigned long long probe_t0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -280,6 +294,57 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
         for (int q = 0; q < 4; ++q) gelu_pair(jt, s, q);
         gelu_swap(jt, s);
     };
+    // H16 form (r02): the GELU of a PAIR of hidden values in packed IEEE half - 12 instructions per pair instead of 21 - cut into four
+    // stages of three instructions, so that a chunk's 128 stages can be dealt out one (C = 256) or two (C = 128) per MFMA over BOTH the
+    // phase-2 MFMAs of the chunk before and the phase-1 MFMAs of the chunk after (profiles/r02_gelu_issue_probe.txt: a wave's own VALU
+    // work hides under its MFMAs only ~3 instructions at a time: 10 fp32 instructions per value in phase 1 alone = 59.5 clocks per MFMA
+    // over the chunk, packed half dealt over both phases = 34).   gelu(x) = x clamp01(0.5 + x R(u)), u = 2 clamp01(x^2/16) - 1, R a
+    // degree-6 fit of (Phi(x) - 0.5)/x on |x| <= 4 in the centred variable (monomials in x^2 cancel catastrophically in half); beyond
+    // |x| = 4 the clamps pin Phi to 0 or 1.  Emulated in numpy float16 over N(0,1), N(0,3) and U(-8,8) inputs: rms error 5.1e-4 (max
+    // 3.9e-3 at |x| ~ 8 = half's spacing there) against 3.1e-3 rms for the exact GELU rounded to bf16, which is what phase 2 consumed
+    // before - the hidden activations are six times closer to the fp32 reference than in the bf16 form.
+#define H2C(v) (h2{(_Float16)(v), (_Float16)(v)})
+    h2 g_x, g_t, g_u, g_R;
+    auto gelu_stage = [&](int st) __attribute__((always_inline)) {       // st = 0..127 (a constant after unrolling): pair st >> 2, stage st & 3
+        const int pr = st >> 2, ks = pr >> 2, jtg = ks >> 1, sg = ks & 1, q = pr & 3;
+        const int e0 = 4 * (2 * sg + (q >> 1)) + 2 * (q & 1);
+        switch (st & 3) {
+        case 0: {
+            // round to nearest.  volatile: the two arms of the chunk loop start with the same conversions of hprev, and LLVM otherwise
+            // hoists all sixteen above the branch (sixteen more live registers and no dealing)
+            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(g_x) : "v"(hprev[jtg][e0]), "v"(hprev[jtg][e0 + 1]));
+            const h2 xq = g_x * H2C(0.0625f);
+            asm("v_pk_mul_f16 %0, %1, %2 clamp" : "=v"(g_t) : "v"(g_x), "v"(xq));
+            asm volatile("" :: "v"(g_t)); break; }
+        case 1:
+            g_u = g_t * H2C(2.0f) + H2C(-1.0f);
+            g_R = g_t * H2C(2.0 * 7.04386136e-03) + H2C(-1.75341913e-02 - 7.04386136e-03);             // c6 u + c5 with u = 2t - 1
+            g_R = g_R * g_u + H2C(2.3155236e-02);
+            asm volatile("" :: "v"(g_R)); break;
+        case 2:
+            g_R = g_R * g_u + H2C(-3.46384121e-02);
+            g_R = g_R * g_u + H2C(5.55682496e-02);
+            g_R = g_R * g_u + H2C(-8.45508472e-02);
+            asm volatile("" :: "v"(g_R)); break;
+        default: {
+            g_R = g_R * g_u + H2C(1.75968805e-01);
+            h2 pp;
+            asm("v_pk_fma_f16 %0, %1, %2, 0.5 op_sel_hi:[1,1,0] clamp" : "=v"(pp) : "v"(g_x), "v"(g_R));
+            const h2 y = g_x * pp;
+            gu[q] = __builtin_bit_cast(unsigned, y);
+            if (q == 3) gelu_swap(jtg, sg);
+            asm volatile("" :: "v"(gu[q])); break; }
+        }
+    };
+    auto gelu_burst = [&](int st0, int st1) __attribute__((always_inline)) {
+#pragma unroll
+        for (int st = st0; st < st1; ++st) gelu_stage(st);
+    };
+#ifndef MLP_H16_P1ONLY
+#define MLP_H16_P1ONLY 0
+#endif
+    constexpr bool P1ONLY = MLP_H16_P1ONLY;      // probe switch: all 128 stages between the phase-1 MFMAs of the next chunk, phase 2 untouched
+    constexpr int SPM = 2 / (C / 128);           // stages per MFMA when 64 stages are dealt over one phase: 1 (C = 256) or 2 (C = 128)
 
     const int x256 = (h ^ (r & 15)) << 4;            // swizzle term for 256-B rows: chunk (2s+h) ^ (row&15)
     const int x128 = (h ^ ((r >> 1) & 7)) << 4;      //                  128-B rows: chunk (2g+h) ^ ((row>>1)&7)
@@ -305,7 +370,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
             LDS_READ128(a[buf][0], ad, 0); LDS_READ128(a[buf][1], ad, 8192);
             LDS_READ128(a[buf][2], ad, 16384); LDS_READ128(a[buf][3], ad, 24576);
         };
-#ifdef MLP_X_NORD1          // probe builds: no fragment reads in phase 1 (timing only, garbage operands)
+#ifdef MLP_X_NORD1
 #pragma unroll
         for (int i = 0; i < 4; ++i) { asm volatile("" : "=v"(a[0][i])); asm volatile("" : "=v"(a[1][i])); }
 #else
@@ -333,8 +398,14 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
                 if (pipe) {
                     constexpr int VPM = 64 / (KB * 32);          // hidden values per MFMA: 1 (C = 256) or 2 (C = 128)
                     SB();
+                    if (H16) {                                   // second half of the previous chunk's stages (the first went out in its phase 2)
 #pragma unroll
-                    for (int u = 0; u < VPM; ++u) gelu_fine(((kb * 8 + s) * 4 + jt) * VPM + u);
+                        for (int u = 0; u < (P1ONLY ? 2 * SPM : SPM); ++u)
+                            gelu_stage(P1ONLY ? ((kb * 8 + s) * 4 + jt) * 2 * SPM + u : 64 + ((kb * 8 + s) * 4 + jt) * SPM + u);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < VPM; ++u) gelu_fine(((kb * 8 + s) * 4 + jt) * VPM + u);
+                    }
                     SB();
                 }
 #endif
@@ -352,10 +423,42 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
 #endif
         }
     };
-    auto phase2_step = [&](const unsigned char* slot, int sb) __attribute__((always_inline)) {
+    auto phase2_step = [&](const unsigned char* slot, int sb, bool deal) __attribute__((always_inline)) {
         constexpr int NG = ROW2 == 128 ? 4 : 8;                 // k-steps of 16 hidden units in this slot
         const unsigned base = lds_off(slot) + r * ROW2;
         const int xs = ROW2 == 128 ? x128 : x256;
+        if (H16 && NT2 == 8 && !P1ONLY) {
+            // half k-steps: 4 fragment reads + 4 MFMAs, double-buffered in 32 registers instead of 64 (the H16 form keeps the next chunk's
+            // raw accumulators AND the GELU temporaries live through this phase: with 64 the allocator spilled)
+            u32x4 a4[2][4];
+            auto rd4 = [&](int buf, int hs) {
+                const unsigned ad = base + ((32 * (hs >> 1)) ^ xs);
+                if (hs & 1) { LDS_READ128(a4[buf][0], ad, 16384); LDS_READ128(a4[buf][1], ad, 20480); LDS_READ128(a4[buf][2], ad, 24576); LDS_READ128(a4[buf][3], ad, 28672); }
+                else { LDS_READ128(a4[buf][0], ad, 0); LDS_READ128(a4[buf][1], ad, 4096); LDS_READ128(a4[buf][2], ad, 8192); LDS_READ128(a4[buf][3], ad, 12288); }
+            };
+            rd4(0, 0);
+#pragma unroll
+            for (int hs = 0; hs < 2 * NG; ++hs) {
+                if (hs + 1 < 2 * NG) { rd4((hs + 1) & 1, hs + 1); LGKM_WAIT(4); } else { LGKM_WAIT(0); }
+                const int g = hs >> 1, jt = sb * 2 + (g >> 1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int nt = (hs & 1) * 4 + i;
+                    Frag f; f.u = a4[hs & 1][i];
+                    oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.hh, hf[jt][g & 1].hh, oacc[nt], 0, 0, 0);
+                    if (i == 1) { SB(); dma_piece(hs); SB(); }
+                    if (deal) {
+                        // first half of the NEXT chunk's GELU stages (its accumulators are in hprev).  Fragment f of the next chunk is
+                        // written by the stage 16f+15, i.e. after MFMA 16f+15 of this phase, and this phase's last read of fragment f
+                        // is MFMA 8f+7: every hf register is overwritten only after its last use.
+                        SB();
+                        gelu_stage((sb * NG + g) * NT2 + nt);
+                        SB();
+                    }
+                }
+            }
+            return;
+        }
         u32x4 a[2][NT2];
         auto rd = [&](int buf, int g) {
             const unsigned ad = base + ((32 * g) ^ xs);
@@ -371,7 +474,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
                 LDS_READ128(a[buf][2], ad, 16384); LDS_READ128(a[buf][3], ad, 24576);
             }
         };
-#ifdef MLP_X_NORD2          // probe builds: no fragment reads in phase 2
+#ifdef MLP_X_NORD2          // probe builds: no fragment reads in phase 2 (timing only, garbage operands)
 #pragma unroll
         for (int i = 0; i < NT2; ++i) { asm volatile("" : "=v"(a[0][i])); asm volatile("" : "=v"(a[1][i])); }
 #else
@@ -389,11 +492,21 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
 #pragma unroll
             for (int nt = 0; nt < NT2; ++nt) {
                 Frag f; f.u = a[g & 1][nt];
-                oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, hf[jt][g & 1].b, oacc[nt], 0, 0, 0);
+                if (H16) oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.hh, hf[jt][g & 1].hh, oacc[nt], 0, 0, 0);
+                else oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, hf[jt][g & 1].b, oacc[nt], 0, 0, 0);
 #ifndef MLP_X_NODMA2
                 if (NG == 4) { if (nt == 1 || nt == 5) { SB(); dma_piece(2 * g + (nt > 1)); SB(); } }
                 else if (nt == 1) { SB(); dma_piece(g); SB(); }
 #endif
+                if (H16 && deal && !P1ONLY) {
+                    // first half of the NEXT chunk's GELU stages (its accumulators are in hprev).  Fragment f of the next chunk is
+                    // written by the stage 16f+15, i.e. after MFMA 16f+15 (8f+7 for C = 128) of this phase, and this phase's last read
+                    // of fragment f is MFMA 8f+7 (4f+3): every hf register is overwritten only after its last use.
+                    SB();
+#pragma unroll
+                    for (int u = 0; u < SPM; ++u) gelu_stage(((sb * NG + g) * NT2 + nt) * SPM + u);
+                    SB();
+                }
             }
         }
     };
@@ -417,6 +530,28 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) { phase1_step(begin_step(), kb, false); PROBE_ADD(2); }
 
+    if (H16 && !P1ONLY) {
+        // chunk hc's 128 GELU stages: 0..63 between the MFMAs of phase 2 of chunk hc-1, 64..127 between those of phase 1 of chunk hc+1.
+        // The first chunk has no phase 2 before it and the last no phase 1 after it: those two halves run as bursts (2 x ~800 clocks).
+#pragma unroll
+        for (int t = 0; t < 4; ++t) hprev[t] = hacc[t];
+        gelu_burst(0, 64);
+        for (int hc = 0; hc < nhc; ++hc) {
+            if (hc + 1 < nhc) {
+                init_hacc(hc + 1);
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) { phase1_step(begin_step(), kb, true); PROBE_ADD(2); }     // + stages 64..127 of chunk hc
+#pragma unroll
+                for (int t = 0; t < 4; ++t) hprev[t] = hacc[t];
+#pragma unroll
+                for (int sb = 0; sb < S2; ++sb) { phase2_step(begin_step(), sb, true); PROBE_ADD(3); }     // + stages 0..63 of chunk hc+1
+            } else {
+                gelu_burst(64, 128);
+#pragma unroll
+                for (int sb = 0; sb < S2; ++sb) { phase2_step(begin_step(), sb, false); PROBE_ADD(3); }
+            }
+        }
+    } else
     for (int hc = 0; hc < nhc; ++hc) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) hprev[t] = hacc[t];
@@ -424,6 +559,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
             init_hacc(hc + 1);
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) { phase1_step(begin_step(), kb, true); PROBE_ADD(2); }    // + GELU(hc) in the gaps
+        } else if (H16) {
+            gelu_burst(0, 128);
         } else {
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt)
@@ -431,7 +568,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
                 for (int s = 0; s < 2; ++s) gelu_kstep(jt, s);
         }
 #pragma unroll
-        for (int sb = 0; sb < S2; ++sb) { phase2_step(begin_step(), sb); PROBE_ADD(3); }
+        for (int sb = 0; sb < S2; ++sb) { phase2_step(begin_step(), sb, false); PROBE_ADD(3); }
     }
 
     // ---- epilogue.  O^T tile: lane = token, registers = channels, which would mean 8-byte stores strided by the row
@@ -511,13 +648,13 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
 #endif
 }
 
-template <int C>
+template <int C, bool H16>
 int launch(const MlpArgs& p, hipStream_t s) {
     const size_t lds = (size_t)RING * SLOT + (size_t)(p.HID + 3 * C) * sizeof(float) + 4 * 1024;      // ring | b1, b2, ln | 1-KB DMA dummy per wave
     if (lds > 160 * 1024) { master_set_error("mlp: hidden width %d needs %zu B of LDS", p.HID, lds); return MASTER_ERR_UNSUPPORTED; }
     static LdsLimit lds_limit;
-    lds_limit.ensure((const void*)mlp_bf16_kernel<C>, (int)((int)lds));
-    hipLaunchKernelGGL((mlp_bf16_kernel<C>), dim3((p.M + 127) / 128), dim3(256), lds, s, p);
+    lds_limit.ensure((const void*)mlp_bf16_kernel<C, H16>, (int)((int)lds));
+    hipLaunchKernelGGL((mlp_bf16_kernel<C, H16>), dim3((p.M + 127) / 128), dim3(256), lds, s, p);
     return master_check_launch("mlp_bf16");
 }
 
@@ -525,11 +662,11 @@ int launch(const MlpArgs& p, hipStream_t s) {
 
 int mlp_bf16(const bf16_t* x, const float* ln_g, const float* ln_b, const bf16_t* w1, const float* b1, const bf16_t* w2,
              const float* b2, const bf16_t* res, bf16_t* out, int M, int C, int HID, int ldx, int ldr, int ldo, float eps,
-             hipStream_t s) {
+             bool w2_f16, hipStream_t s) {
     MlpArgs p{x, ln_g, ln_b, w1, b1, w2, b2, res, out, M, HID, ldx, ldr, ldo, eps};
     if (HID % 128 != 0) { master_set_error("mlp: hidden width must be a multiple of 128 (got %d)", HID); return MASTER_ERR_INVALID; }
-    if (C == 256) return launch<256>(p, s);
-    if (C == 128) return launch<128>(p, s);
+    if (C == 256) return w2_f16 ? launch<256, true>(p, s) : launch<256, false>(p, s);
+    if (C == 128) return w2_f16 ? launch<128, true>(p, s) : launch<128, false>(p, s);
     master_set_error("mlp(bf16): channel width %d not built (128, 256)", C);
     return MASTER_ERR_UNSUPPORTED;
 }
