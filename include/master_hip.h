@@ -143,7 +143,7 @@ int master_instnorm_fwd(const void* x, void* out, const void* pad_row_in, void* 
 
 /* Swin patch embedding: Conv2d(3, E, 4, stride 4) on an fp32 NCHW image, NHWC output, LayerNorm(E)
  * fused.  w is the conv weight [E, 3, 4, 4] flattened to [E, 48].  (torchvision swin_b.features[0];
- * reference codes/utils.py:89-93.)  H % 4 == 0, W % 4 == 0, E == 128. */
+ * reference codes/utils.py:89-93.)  H % 4 == 0, W % 4 == 0; E == 128 (swin_B), or 96 (swin_T / swin_S: MASTER_F32 only). */
 int master_patch_embed_fwd(const float* img, const void* w, const void* bias, const void* gamma,
                            const void* beta, void* out, int B, int H, int W, int E, float eps, int dtype,
                            master_stream_t stream);

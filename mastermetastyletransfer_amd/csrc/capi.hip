@@ -65,7 +65,7 @@ int window_attn_bf16(const bf16_t*, const bf16_t*, const bf16_t*, const bf16_t*,
                      bf16_t*, int, int, int, int, int, int, float, hipStream_t);
 template <typename T> int layernorm_launch(const void*, const void*, const void*, void*, int, int, float, int, int, int, int, hipStream_t);
 template <typename T> int instnorm_launch(const void*, void*, const void*, void*, int, int, int, int, float, int, hipStream_t);
-template <typename T> int patch_embed_launch(const float*, const void*, const void*, const void*, const void*, void*, int, int, int, float, hipStream_t);
+template <typename T> int patch_embed_launch(const float*, const void*, const void*, const void*, const void*, void*, int, int, int, int, float, hipStream_t);
 int convert_launch(const void*, void*, size_t, int, int, hipStream_t);
 int linear_ts_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const bf16_t*, bf16_t*,
                    int, int, int, int, int, int, float, hipStream_t, int mH = 0, int mW = 0, int mC = 0);
@@ -661,10 +661,11 @@ int master_patch_embed_fwd(const float* img, const void* w, const void* bias, co
                            void* out, int B, int H, int W, int E, float eps, int dtype, master_stream_t stream) {
     REQUIRE(img && w && bias && gamma && beta && out, "patch_embed: null operand");
     REQUIRE(B > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, "patch_embed: H,W must be multiples of 4");
-    if (E != 128) { master_set_error("patch_embed: embed dim %d unsupported (swin_B = 128)", E); return MASTER_ERR_UNSUPPORTED; }
+    if (E != 128 && E != 96) { master_set_error("patch_embed: embed dim %d not built (128 = swin_B, 96 = swin_T / swin_S)", E); return MASTER_ERR_UNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_PATCH_EMBED, s);
-    if (dtype == MASTER_F32) return patch_embed_launch<float>(img, w, bias, gamma, beta, out, B, H, W, eps, s);
+    if (dtype == MASTER_F32) return patch_embed_launch<float>(img, w, bias, gamma, beta, out, B, H, W, E, eps, s);
+    if (dtype == MASTER_BF16 && E != 128) { master_set_error("patch_embed(bf16): the matrix-core kernel is built for embed 128 (swin_B); embed %d runs in the fp32 mode", E); return MASTER_ERR_UNSUPPORTED; }
     if (dtype == MASTER_BF16)      // matrix-core version (bf16 operands, fp32 accumulate and LayerNorm)
         return patch_embed_bf16(img, (const float*)w, (const float*)bias, (const float*)gamma, (const float*)beta, (bf16_t*)out, B, H, W, eps, s);
     master_set_error("patch_embed: bad dtype %d", dtype);

@@ -248,14 +248,15 @@ __global__ __launch_bounds__(256) void instnorm_kernel(const T* __restrict__ x, 
         Vec4<T>::store(pad_out + (size_t)b * C + c0 + cq * 4, (pr - mean) * rstd);
 }
 
-// ---- Swin patch embedding: Conv2d(3,128,4,4) + LayerNorm(128).  Block = 64 patches of one patch row.
-//      Thread (patch p, quarter eq) produces channels [32eq, 32eq+32) of patch p. ---------------------
-template <typename T>
+// ---- Swin patch embedding: Conv2d(3,E,4,4) + LayerNorm(E), E = 128 (swin_B) or 96 (swin_T / swin_S).  Block = 64 patches of one
+//      patch row.  Thread (patch p, quarter eq) produces channels [32eq, 32eq+32) of patch p; with E = 96 the fourth thread of a
+//      patch computes nothing and adds zeros to the LayerNorm sums. ---------------------
+template <typename T, int E>
 __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                           const float* __restrict__ bias, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, T* __restrict__ out, int H, int W,
                                                           float eps) {
-    constexpr int E = 128, KP = 48, PSTR = 49;
+    constexpr int KP = 48, PSTR = 49;
     __shared__ __attribute__((aligned(16))) float pix[64 * PSTR];
     __shared__ __attribute__((aligned(16))) float wt[KP * E];   // [k][e]
     const int PW = W >> 2, PH = H >> 2;
@@ -279,12 +280,13 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
     __syncthreads();
 
     const int p = tid >> 2, eq = tid & 3;
+    const bool live = eq * 32 < E;
     float acc[32];
 #pragma unroll
     for (int e = 0; e < 32; ++e) {
-        acc[e] = bias[eq * 32 + e];
+        acc[e] = live ? bias[eq * 32 + e] : 0.f;
     }
-    for (int k = 0; k < KP; ++k) {
+    for (int k = 0; live && k < KP; ++k) {
         const float a = pix[p * PSTR + k];
         const f32x4* wr = (const f32x4*)(wt + k * E + eq * 32);
 #pragma unroll
@@ -301,10 +303,10 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
     const float mean = s / (float)E;
     float sq = 0.f;
 #pragma unroll
-    for (int e = 0; e < 32; ++e) { const float d = acc[e] - mean; sq += d * d; }
+    for (int e = 0; e < 32; ++e) { const float d = acc[e] - mean; sq += live ? d * d : 0.f; }
     sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64);
     const float rstd = rsqrtf(sq / (float)E + eps);
-    if (px0 + p < PW) {
+    if (live && px0 + p < PW) {
         T* op = out + ((((size_t)b * PH + py) * PW + px0 + p) * E) + eq * 32;
 #pragma unroll
         for (int e4 = 0; e4 < 8; ++e4) {
@@ -327,6 +329,63 @@ __global__ __launch_bounds__(256) void convert_kernel(const S* __restrict__ src,
             float v = sizeof(S) == 4 ? ((const float*)src)[t] : bf16_to_f32(((const bf16_t*)src)[t]);
             if (sizeof(D) == 4) ((float*)dst)[t] = v; else ((bf16_t*)dst)[t] = f32_to_bf16(v);
         }
+}
+
+// ---- LayerNorm for widths whose vector count is not a power of two (swin_T / swin_S: 96, 192, 384 channels): one wave per row,
+//      lane l holds the 16-byte vectors l, l+64, l+128, l+192 of the row (C <= 256 vectors), sums over the whole wave. ----------------
+template <typename T, bool MERGE>
+__global__ __launch_bounds__(256) void layernorm_any_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ out, int M, int C,
+                                                            float eps, int H, int W, int Cin) {
+    constexpr int VEC = Vec16<T>::N;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;                                        // whole waves leave together: no barrier in this kernel
+    const int chunks = C / VEC;
+    size_t base[4] = {0, 0, 0, 0};
+    if (MERGE) {
+        const int W2 = W >> 1, H2 = H >> 1;
+        const int b = row / (H2 * W2), rem = row - b * (H2 * W2), y2 = rem / W2, x2 = rem - y2 * W2;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) base[s] = (((size_t)b * H + 2 * y2 + (s & 1)) * W + 2 * x2 + (s >> 1)) * Cin;
+    }
+    float v[4][VEC];
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (lane + 64 * i) * VEC;
+        if (lane + 64 * i < chunks) {
+            const int seg = MERGE ? c / Cin : 0;
+            const T* src = MERGE ? x + (seg == 0 ? base[0] : seg == 1 ? base[1] : seg == 2 ? base[2] : base[3]) + (c - seg * Cin) : x + (size_t)row * C + c;
+            Vec16<T>::load(src, v[i]);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) sum += v[i][e];
+        }
+    }
+    sum = wave_sum(sum);
+    const float mean = sum / (float)C;
+    float sq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (lane + 64 * i < chunks)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+    sq = wave_sum(sq);
+    const float rstd = rsqrtf(sq / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (lane + 64 * i) * VEC;
+        if (lane + 64 * i < chunks) {
+            float o_[VEC];
+#pragma unroll
+            for (int e4 = 0; e4 < VEC / 4; ++e4) {
+                const f32x4 gm = *(const f32x4*)(gamma + c + 4 * e4), bt = *(const f32x4*)(beta + c + 4 * e4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o_[4 * e4 + e] = (v[i][4 * e4 + e] - mean) * rstd * gm[e] + bt[e];
+            }
+            Vec16<T>::store(out + (size_t)row * C + c, o_);
+        }
+    }
 }
 
 }  // namespace
@@ -355,9 +414,16 @@ int layernorm_launch(const void* x, const void* g, const void* b, void* out, int
                      int W, int Cin, hipStream_t s) {
     constexpr int VEC = Vec16<T>::N;
     const int chunks = C / VEC;
-    if (C % VEC != 0 || (chunks & (chunks - 1)) != 0 || chunks > 256 || (merge && Cin % VEC != 0)) {
-        master_set_error("layernorm: C/%d must be a power of two <= 256 (C=%d)", VEC, C);
+    if (C % VEC != 0 || chunks > 256 || (merge && Cin % VEC != 0)) {
+        master_set_error("layernorm: C must be a multiple of %d and at most %d (C=%d)", VEC, 256 * VEC, C);
         return MASTER_ERR_INVALID;
+    }
+    if ((chunks & (chunks - 1)) != 0) {          // not a power of two: the one-wave-per-row kernel
+        if (merge) hipLaunchKernelGGL((layernorm_any_kernel<T, true>), dim3((M + 3) / 4), dim3(256), 0, s, (const T*)x, (const float*)g,
+                                      (const float*)b, (T*)out, M, C, eps, H, W, Cin);
+        else hipLaunchKernelGGL((layernorm_any_kernel<T, false>), dim3((M + 3) / 4), dim3(256), 0, s, (const T*)x, (const float*)g,
+                                (const float*)b, (T*)out, M, C, eps, 0, 0, C);
+        return master_check_launch("layernorm");
     }
     if (merge) layernorm_dispatch<T, true>(x, g, b, out, M, C, eps, H, W, Cin, s);
     else layernorm_dispatch<T, false>(x, g, b, out, M, C, eps, 0, 0, C, s);
@@ -386,14 +452,19 @@ template int instnorm_launch<bf16_t>(const void*, void*, const void*, void*, int
 
 template <typename T>
 int patch_embed_launch(const float* img, const void* w, const void* bias, const void* g, const void* b, void* out,
-                       int B, int H, int W, float eps, hipStream_t s) {
+                       int B, int H, int W, int E, float eps, hipStream_t s) {
     const int PW = W / 4, PH = H / 4, chunks = (PW + 63) / 64;
-    hipLaunchKernelGGL((patch_embed_kernel<T>), dim3(B * PH * chunks), dim3(256), 0, s, img, (const float*)w,
-                       (const float*)bias, (const float*)g, (const float*)b, (T*)out, H, W, eps);
+    if (E == 128)
+        hipLaunchKernelGGL((patch_embed_kernel<T, 128>), dim3(B * PH * chunks), dim3(256), 0, s, img, (const float*)w,
+                           (const float*)bias, (const float*)g, (const float*)b, (T*)out, H, W, eps);
+    else if (E == 96)
+        hipLaunchKernelGGL((patch_embed_kernel<T, 96>), dim3(B * PH * chunks), dim3(256), 0, s, img, (const float*)w,
+                           (const float*)bias, (const float*)g, (const float*)b, (T*)out, H, W, eps);
+    else { master_set_error("patch_embed: embed dim %d not built (128 = swin_B, 96 = swin_T / swin_S)", E); return MASTER_ERR_UNSUPPORTED; }
     return master_check_launch("patch_embed");
 }
-template int patch_embed_launch<float>(const float*, const void*, const void*, const void*, const void*, void*, int, int, int, float, hipStream_t);
-template int patch_embed_launch<bf16_t>(const float*, const void*, const void*, const void*, const void*, void*, int, int, int, float, hipStream_t);
+template int patch_embed_launch<float>(const float*, const void*, const void*, const void*, const void*, void*, int, int, int, int, float, hipStream_t);
+template int patch_embed_launch<bf16_t>(const float*, const void*, const void*, const void*, const void*, void*, int, int, int, int, float, hipStream_t);
 
 int convert_launch(const void* src, void* dst, size_t n, int sdt, int ddt, hipStream_t s) {
     size_t blocks = (n / 4 + 255) / 256;

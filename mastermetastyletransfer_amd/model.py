@@ -28,9 +28,6 @@ def _load_swin_encoder(path: Optional[str], variant: str, allow_random: bool = F
     if variant not in _SWIN_VARIANTS:        # same message as codes/utils.py:71-72
         raise ValueError("Invalid Swin Transformer variant. Please choose one of the following: swin_T, swin_S, swin_B")
     embed, heads, depths, (sd_prob, total) = _SWIN_VARIANTS[variant]
-    if variant != "swin_B":
-        # embed 96 is head_dim 32 too (96/3, 192/6), but the patch-embed and row-norm kernels are built for power-of-two widths
-        raise NotImplementedError(f"{variant}: the encoder kernels are built for swin_B (embed 128); swin_T / swin_S (embed 96) are not")
     enc = SwinEncoder(embed_dim=embed, depths=depths, num_heads=heads, stochastic_depth_prob=sd_prob, total_blocks=total)
     if path and os.path.exists(path):
         # the reference pickles the whole torchvision nn.Sequential (utils.py:93-102); a plain state dict works too
@@ -99,6 +96,7 @@ class MasterStyleTransferModel(nn.Module):
         else:
             swin_path = os.path.join(project_absolute_path, "models", f"{swin_variant}_first_2_stages.pt")
         self.swin_encoder = _load_swin_encoder(swin_path, swin_variant, allow_random_swin_encoder)
+        self.swin_variant = swin_variant
 
         self.style_transformer = StyleTransformer(
             encoder_dim=style_encoder_dim, decoder_dim=style_decoder_dim,
@@ -156,6 +154,9 @@ class MasterStyleTransferModel(nn.Module):
         """torch.float32: exact-fp32 matrix cores, parity mode.  torch.bfloat16: bf16 MFMA, throughput mode."""
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("compute_dtype must be torch.float32 or torch.bfloat16")
+        if dtype == torch.bfloat16 and self.swin_variant != "swin_B":
+            # the bf16 kernels are specialised for swin_B's widths (128 / 256 channels, 4 / 8 heads); embed 96 runs in the fp32 mode
+            raise NotImplementedError(f"{self.swin_variant}: the bf16 throughput mode is built for swin_B widths; use torch.float32")
         self.compute_dtype = dtype
         for m in self.modules():
             if isinstance(m, (_HipModule, SwinEncoder)):
@@ -170,11 +171,19 @@ class MasterStyleTransferModel(nn.Module):
             return self._forward_train(content_image, style_image, transformer_layer_count)
         # the two encoder passes of full_model.py:219-220 are independent -> one batch of 2B images
         x, _, h, w = self.swin_encoder.run(content_image, style_image)
+        self._check_widths(x.shape[1])
         fc, fs = x[: B * h * w], x[B * h * w:]
         fcs = self.style_transformer.run(fc, fs, transformer_layer_count, B, h, w)
         # the reference permutes NHWC->NCHW here (:222); the decoder kernels read NHWC directly and the
         # last convolution writes the NCHW image
         return self.decoder.run_nhwc(fcs.view(B, h, w, -1))
+
+    def _check_widths(self, c: int) -> None:
+        """the encoder's output width (256 for swin_B, 192 for swin_T / swin_S) feeds both halves of the StyleTransformer and the
+        decoder; the reference fails in its first nn.Linear with the same kind of error"""
+        if c != self.style_encoder_dim or c != self.style_decoder_dim:
+            raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied: the {self.swin_variant} encoder produces {c}-channel tokens, "
+                               f"style_encoder_dim = {self.style_encoder_dim}, style_decoder_dim = {self.style_decoder_dim}")
 
     def _forward_train(self, content_image: Tensor, style_image: Tensor, k: int) -> Tensor:
         """train-mode forward (train_only_inner_loop.py:523): autograd graph over the HIP forward/backward kernels.  The Swin encoder
@@ -187,6 +196,7 @@ class MasterStyleTransferModel(nn.Module):
         B = content_image.shape[0]
         with torch.no_grad():
             x, _, h, w = self.swin_encoder.run(content_image, style_image)
+        self._check_widths(x.shape[1])
         fc, fs = x[: B * h * w], x[B * h * w:]
         fcs = TF.style_transformer(self.style_transformer, fc, fs, k, B, h, w, TF.sd_masks)
         return TF.image_decoder(self.decoder, fcs.view(B, h, w, -1))

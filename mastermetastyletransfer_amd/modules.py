@@ -644,21 +644,43 @@ class Decoder(_HipModule):
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
 
+    def padded_channels(self, i: int) -> Tuple[int, int]:
+        """(Cout, Cin) of conv i as the kernels see them: channel counts that are not multiples of 32 (channel_dim = 192: the 48- and
+        24-channel layers) are carried zero-padded to the next multiple - zero weights and biases, so the padding channels stay 0
+        through every ReLU and contribute nothing to the next layer.  The last convolution keeps its 3 outputs."""
+        conv = self.decoder[i]
+        pad = lambda n: (n + 31) // 32 * 32
+        return (conv.out_channels if i == self.CONV_IDX[-1] else pad(conv.out_channels)), pad(conv.in_channels)
+
     def run_nhwc(self, x: Tensor) -> Tensor:
         """x: NHWC [B,H,W,C] in the compute dtype -> fp32 NCHW image [B,3,8H,8W]"""
         last, prev = self.CONV_IDX[-1], self.CONV_IDX[-2]
 
         def packed(i):
             conv = self.decoder[i]
-            return self._derived(f"conv{i}", [conv.weight],
-                                 lambda: ops.convert(conv.weight.detach().permute(0, 2, 3, 1).contiguous(), self.compute_dtype))
+            co, ci = self.padded_channels(i)
+
+            def build():
+                w = conv.weight.detach()
+                if (co, ci) != tuple(w.shape[:2]):
+                    w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, ci - w.shape[1], 0, co - w.shape[0]))
+                return ops.convert(w.permute(0, 2, 3, 1).contiguous(), self.compute_dtype)
+            return self._derived(f"conv{i}", [conv.weight], build)
+
+        def bias(i):
+            conv = self.decoder[i]
+            co = self.padded_channels(i)[0]
+            if co == conv.out_channels:
+                return self._b(f"conv{i}", conv.bias)
+            return self._derived(f"b:conv{i}:padded", [conv.bias],
+                                 lambda: torch.nn.functional.pad(conv.bias.detach().float(), (0, co - conv.out_channels)).contiguous())
         for i in self.CONV_IDX:
             conv = self.decoder[i]
             if i == prev and prev in self.UPSAMPLE_BEFORE and ops.decoder_tail_supported(x, conv.out_channels):
                 # bf16 mode: Upsample + Conv(32->32) + ReLU + Conv(32->3) in one launch, intermediate kept in LDS
                 return ops.decoder_tail(x, packed(prev), self._b(f"conv{prev}", conv.bias), packed(last),
                                         self._b(f"conv{last}", self.decoder[last].bias))
-            x = ops.conv3x3_reflect(x, packed(i), self._b(f"conv{i}", conv.bias), upsample=i in self.UPSAMPLE_BEFORE,
+            x = ops.conv3x3_reflect(x, packed(i), bias(i), upsample=i in self.UPSAMPLE_BEFORE,
                                     relu=i != last, out_nchw=i == last)
         return x
 

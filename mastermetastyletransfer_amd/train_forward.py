@@ -275,5 +275,10 @@ def image_decoder(dec, x_nhwc: Tensor) -> Tensor:
     x = x_nhwc
     for i in dec.CONV_IDX:
         conv = dec.decoder[i]
-        x = ConvReflectFn.apply(x, conv.weight, conv.bias, i in dec.UPSAMPLE_BEFORE, i != last, i == last)
+        w, b = conv.weight, conv.bias
+        co, ci = dec.padded_channels(i)                      # channel counts the kernels take (multiples of 32): zero-padded weights
+        if (co, ci) != tuple(w.shape[:2]):
+            w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, ci - w.shape[1], 0, co - w.shape[0]))
+            b = torch.nn.functional.pad(b, (0, co - b.shape[0]))
+        x = ConvReflectFn.apply(x, w, b, i in dec.UPSAMPLE_BEFORE, i != last, i == last)
     return x

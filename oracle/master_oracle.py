@@ -403,9 +403,10 @@ def swin_encoder(img: Tensor, p: Dict[str, Tensor], prefix: str = "", ws=(7, 7),
 # --------------------------------------------------------------------------------------
 # full forward (codes/full_model.py:214-226)
 # --------------------------------------------------------------------------------------
-def full_forward(content: Tensor, style: Tensor, k: int, swin_sd, st_sd, dec_sd, cfg=None) -> Tensor:
-    fc = swin_encoder(content, swin_sd)
-    fs = swin_encoder(style, swin_sd)
+def full_forward(content: Tensor, style: Tensor, k: int, swin_sd, st_sd, dec_sd, cfg=None, swin_heads=(4, 8)) -> Tensor:
+    """swin_heads: (4, 8) for swin_B, (3, 6) for swin_T / swin_S (head_dim 32 in all three: codes/utils.py:82-88)"""
+    fc = swin_encoder(content, swin_sd, heads=swin_heads)
+    fs = swin_encoder(style, swin_sd, heads=swin_heads)
     fcs = style_transformer(fc, fs, k, st_sd, cfg).permute(0, 3, 1, 2)
     return image_decoder(fcs, dec_sd)
 

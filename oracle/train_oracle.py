@@ -35,7 +35,8 @@ def train_forward_loss(fc: Tensor, fs: Tensor, content: Tensor, style: Tensor, k
 
 
 def train_step_grads(content: Tensor, style: Tensor, k: int, swin_sd, st_sd, dec_sd, vgg_sd, masks=None, lambda_value: float = 10.0,
-                     distance_content: str = "euclidian", distance_style: str = "euclidian", cfg=None, trainable=None, swin_masks=None):
+                     distance_content: str = "euclidian", distance_style: str = "euclidian", cfg=None, trainable=None, swin_masks=None,
+                     swin_heads=(4, 8)):
     """One forward + backward.  Returns (losses dict, grads dict keyed 'style_transformer.<name>' / 'decoder.<name>').
     `trainable`: optional predicate on the key (fast adaptation trains only 'style_transformer.encoder.*',
     train_only_inner_loop.py:306-318).  `swin_masks`: the 2 x O.SWIN_SD_CALLS StochasticDepth masks of the two frozen-encoder calls
@@ -52,8 +53,8 @@ def train_step_grads(content: Tensor, style: Tensor, k: int, swin_sd, st_sd, dec
     with torch.no_grad():
         sdc = O.SDMasks(swin_masks[:O.SWIN_SD_CALLS]) if swin_masks is not None else None
         sds = O.SDMasks(swin_masks[O.SWIN_SD_CALLS:]) if swin_masks is not None else None
-        fc = O.swin_encoder(content, swin_sd, sd=sdc)
-        fs = O.swin_encoder(style, swin_sd, sd=sds)
+        fc = O.swin_encoder(content, swin_sd, heads=swin_heads, sd=sdc)          # (3, 6) heads: swin_T / swin_S
+        fs = O.swin_encoder(style, swin_sd, heads=swin_heads, sd=sds)
 
     def leaf(prefix, sd):
         out = {}

@@ -195,6 +195,49 @@ def full_model(dev, seed=31):
     return m.to(dev).eval(), sds
 
 
+def small_swin_model(dev, variant, seed=41):
+    """swin_T / swin_S: embed 96 -> 192-channel tokens, 3 / 6 heads; the StyleTransformer and the decoder are built 192 wide with 6 heads"""
+    from mastermetastyletransfer_amd import MasterStyleTransferModel
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = MasterStyleTransferModel(swin_variant=variant, style_encoder_dim=192, style_decoder_dim=192, style_encoder_num_heads=6,
+                                     style_decoder_num_heads=6, style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7],
+                                     allow_random_swin_encoder=True)
+    sds = (seeded_state_dict(O.swin_shapes(embed=96, heads=(3, 6)), seed), seeded_state_dict(O.style_transformer_shapes(dim=192, heads=6), seed + 1),
+           seeded_state_dict(O.decoder_shapes(192), seed + 2))
+    m.swin_encoder.load_state_dict(sds[0]); m.style_transformer.load_state_dict(sds[1]); m.decoder.load_state_dict(sds[2])
+    return m.to(dev).eval(), sds
+
+
+@pytest.mark.parametrize("variant,B,S,k", [("swin_T", 2, 64, 1), ("swin_S", 1, 256, 1), ("swin_T", 1, 200, 2)])
+def test_swin_t_s_full_forward_vs_oracle(cuda, variant, B, S, k):
+    """codes/utils.py:59-88 offers swin_T and swin_S next to swin_B: 96-wide embedding, 3 / 6 heads, 192-channel tokens into a 192-wide
+    StyleTransformer and decoder (whose 48- and 24-channel layers run zero-padded to 64 / 32).  fp32 mode; the bf16 mode is swin_B's."""
+    m, (swin_sd, st_sd, dec_sd) = small_swin_model(cuda, variant)
+    cfg = dict(O.DEFAULT_ST_CFG, encoder_num_heads=6, decoder_num_heads=6)
+    c = seeded_input(f"ct{S}", (B, 3, S, S), 8, kind="image")
+    s = seeded_input(f"st{S}", (B, 3, S, S), 9, kind="image")
+    with torch.no_grad():
+        got = m(c.to(cuda), s.to(cuda), k)
+        ref = O.full_forward(c, s, k, swin_sd, st_sd, dec_sd, cfg=cfg, swin_heads=(3, 6))
+        assert_close(m.swin_encoder(c.to(cuda)), O.swin_encoder(c, swin_sd, heads=(3, 6)), f"{variant} encoder", 2e-4)
+    assert got.shape == ref.shape and got.dtype == torch.float32
+    assert_close(got, ref, f"{variant} full forward B{B} S{S} k{k}")
+    with pytest.raises(NotImplementedError):
+        m.set_compute_dtype(torch.bfloat16)
+
+
+def test_swin_t_width_mismatch_raises(cuda):
+    """a swin_T encoder in front of the default 256-wide StyleTransformer fails like the reference's first nn.Linear would"""
+    from mastermetastyletransfer_amd import MasterStyleTransferModel
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = MasterStyleTransferModel(swin_variant="swin_T", allow_random_swin_encoder=True).to(cuda).eval()
+    x = torch.rand(1, 3, 64, 64, device=cuda)
+    with pytest.raises(RuntimeError, match="shapes cannot be multiplied"), torch.no_grad():
+        m(x, x, 1)
+
+
 @pytest.mark.parametrize("B,S", [(1, 64), (2, 256)])
 def test_swin_encoder_vs_oracle(cuda, B, S):
     m, (swin_sd, _, _) = full_model(cuda)

@@ -38,7 +38,8 @@ def check(name, got, ref, tol=TOL, floor=0.0):
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # single kernels
 # ---------------------------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N,K", [(8192, 256, 256), (1000, 768, 256), (4100, 1024, 256), (333, 256, 1024), (64, 32, 64), (50, 512, 128)])
+@pytest.mark.parametrize("M,N,K", [(8192, 256, 256), (1000, 768, 256), (4100, 1024, 256), (333, 256, 1024), (64, 32, 64), (50, 512, 128),
+                                   (1000, 576, 192), (300, 192, 768), (130, 288, 96)])      # the last three: swin_T / swin_S widths
 def test_linear_backward(cuda, M, N, K):
     from mastermetastyletransfer_amd.autograd import LinearFn
     g = torch.Generator().manual_seed(M + N)
@@ -54,7 +55,7 @@ def test_linear_backward(cuda, M, N, K):
     check("da", ad.grad, a.grad); check("dw", wd.grad, w.grad); check("db", bd.grad, b.grad)
 
 
-@pytest.mark.parametrize("M,C,HID,ln", [(2048, 256, 1024, True), (700, 256, 1024, False), (130, 128, 512, True)])
+@pytest.mark.parametrize("M,C,HID,ln", [(2048, 256, 1024, True), (700, 256, 1024, False), (130, 128, 512, True), (500, 192, 768, True)])
 def test_mlp_backward(cuda, M, C, HID, ln):
     from mastermetastyletransfer_amd.autograd import MLPFn
     g = torch.Generator().manual_seed(M)
@@ -75,7 +76,7 @@ def test_mlp_backward(cuda, M, C, HID, ln):
             check(n, d.grad, r.grad)
 
 
-@pytest.mark.parametrize("M,C", [(1024, 256), (77, 128), (300, 512), (64, 1024)])
+@pytest.mark.parametrize("M,C", [(1024, 256), (77, 128), (300, 512), (64, 1024), (200, 192), (100, 96), (65, 384)])
 def test_layernorm_backward(cuda, M, C):
     from mastermetastyletransfer_amd.autograd import LayerNormFn
     g = torch.Generator().manual_seed(C)
@@ -89,7 +90,7 @@ def test_layernorm_backward(cuda, M, C):
     check("dx", xd.grad, x.grad); check("dgamma", wd.grad, gw.grad); check("dbeta", bd.grad, gb.grad)
 
 
-@pytest.mark.parametrize("B,T,C,n_pad", [(2, 1024, 256, 201), (3, 64, 256, 132), (2, 100, 64, 0), (1, 4096, 128, 0)])
+@pytest.mark.parametrize("B,T,C,n_pad", [(2, 1024, 256, 201), (3, 64, 256, 132), (2, 100, 64, 0), (1, 4096, 128, 0), (2, 100, 192, 30)])
 def test_instnorm_backward(cuda, B, T, C, n_pad):
     """InstanceNorm over T rows + n_pad copies of a parameter row; gradients w.r.t. x and the row (style_transformer.py:520-530)"""
     from mastermetastyletransfer_amd.autograd import InstNormFn
@@ -192,7 +193,8 @@ def test_sigma_mu_attention_backward(cuda, B, H, W):
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,up,relu,nchw", [(2, 8, 8, 256, 128, False, True, False), (1, 16, 16, 128, 128, True, True, False),
                                                          (2, 12, 20, 64, 32, True, True, False), (2, 16, 16, 32, 3, False, False, True),
-                                                         (1, 2, 2, 32, 32, True, True, False), (1, 6, 10, 128, 64, False, True, False)])
+                                                         (1, 2, 2, 32, 32, True, True, False), (1, 6, 10, 128, 64, False, True, False),
+                                                         (1, 8, 8, 192, 96, False, True, False), (2, 6, 6, 96, 64, True, True, False)])
 def test_conv_reflect_backward(cuda, B, H, W, Cin, Cout, up, relu, nchw):
     """Upsample? -> ReflectionPad -> Conv3x3 -> ReLU? (decoder.py:24-54): data, weight and bias gradients"""
     from mastermetastyletransfer_amd.autograd import ConvReflectFn
@@ -399,6 +401,49 @@ def test_full_train_step(cuda, B, S):
     T.adam_step(before, dev_grads, {}, 1e-3, 1)
     for n, p in named:
         assert torch.allclose(p.detach().cpu(), before[n], rtol=1e-5, atol=2e-7), n
+
+
+def test_full_train_step_swin_t(cuda):
+    """the same step with the swin_T encoder (embed 96, 3 / 6 heads, StochasticDepth 0.2 over 12 blocks) and a 192-wide
+    StyleTransformer / decoder with 6 heads: the widths that are not powers of two, and the decoder layers that run zero-padded"""
+    from mastermetastyletransfer_amd import MasterStyleTransferModel, custom_loss
+    from mastermetastyletransfer_amd import train_forward as TF
+    B, S, k = 2, 128, 1                 # 16 x 16 tokens per image: the 8 x 8 maps of a 64-pixel image leave InstanceNorm 64 samples per channel
+    sds = (seeded_state_dict(O.swin_shapes(embed=96, heads=(3, 6)), 11), seeded_state_dict(O.style_transformer_shapes(dim=192, heads=6), 12),
+           seeded_state_dict(O.decoder_shapes(192), 13))
+    vgg = seeded_state_dict(L.vgg19_shapes(), 4)
+    cfg = dict(O.DEFAULT_ST_CFG, encoder_num_heads=6, decoder_num_heads=6)
+    c = seeded_input("ftt_c", (B, 3, S, S), 5, kind="image"); s = seeded_input("ftt_s", (B, 3, S, S), 6, kind="image")
+    g = torch.Generator().manual_seed(9)
+    probs = [0.2 * n / 11.0 for n in range(1, 4)]
+    swin_masks = [torch.empty(B).bernoulli_(1 - p, generator=g).div_(1 - p) for _ in range(2) for p in probs for _ in range(2)]
+    masks = O.SDMasks.draw(O.SD_CALLS_PER_LAYER * k, B, 0.1, g)
+    losses, ref32 = T.train_step_grads(c, s, k, *sds, vgg, masks, 10.0, cfg=cfg, swin_masks=swin_masks, swin_heads=(3, 6))
+    _, ref64 = T.train_step_grads(c.double(), s.double(), k, *sds, vgg, masks, 10.0, cfg=cfg, swin_masks=swin_masks, swin_heads=(3, 6))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = MasterStyleTransferModel(swin_variant="swin_T", style_encoder_dim=192, style_decoder_dim=192, style_encoder_num_heads=6,
+                                     style_decoder_num_heads=6, style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7],
+                                     allow_random_swin_encoder=True)
+    m.swin_encoder.load_state_dict(sds[0]); m.style_transformer.load_state_dict(sds[1]); m.decoder.load_state_dict(sds[2])
+    m = m.to(cuda).train()
+    for p in m.swin_encoder.parameters():
+        p.requires_grad = False
+    loss_fn = custom_loss(default_lambda_value=10.0, vgg_state_dict=vgg).to(cuda)
+    TF.sd_masks.set_masks(swin_masks + masks)
+    try:
+        out = m(c.to(cuda), s.to(cuda), k)
+        assert TF.sd_masks.remaining() == 0
+    finally:
+        TF.sd_masks.set_masks(None)
+    check("output", out, losses["output"], 1e-3)
+    total = loss_fn(c.to(cuda), s.to(cuda), out)
+    assert abs(float(total) - float(losses["total"])) <= 5e-4 * abs(float(losses["total"]))
+    total.backward()
+    named = [("style_transformer." + n, p) for n, p in m.style_transformer.named_parameters()] + \
+            [("decoder." + n, p) for n, p in m.decoder.named_parameters()]
+    wh, mh, wc, mc = _compare_grads(named, ref64, ref32)
+    print(f"swin_T B={B} S={S} k={k}: gradient error vs float64 oracle: HIP worst {wh:.2e} median {mh:.2e} | CPU fp32 oracle worst {wc:.2e} median {mc:.2e}")
 
 
 def test_reptile_outer_step_and_fast_adaptation(cuda):
