@@ -385,7 +385,7 @@ def train_bench(device, steps=10, warmup=3, B=8, S=256, max_layers=4, roofline=T
            "dtype": "fp32" if loss_dtype == "fp32" else "fp32 model + bf16 frozen VGG-19 loss network", "images_per_s": round(B * steps / dt, 1),
            "transformer_layer_counts": kt,
            "alg_tflop_per_step": round(gf / steps / 1e3, 3), "alg_tflops": round(gf / dt / 1e3, 2),
-           "frac_of_fp32_mfma_peak": round(gf / dt / 1e3 / PEAK_TFLOPS["fp32"], 4), "final_loss": float(last)}
+           "frac_of_fp32_mfma_peak": round(gf / dt / 1e3 / PEAK_TFLOPS["fp32"], 4), "final_loss": float(last.detach())}
     if roofline:
         ops.prof_reset(); ops.count_reset(); ops.prof_enable(True); ops.count_enable(True)
         step(2)
