@@ -1,7 +1,7 @@
 // In-kernel clock of the fused MLP kernel: stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) around the
 // whole kernel in wave 0 of every workgroup (diagnostic build only: the stamps go to a buffer of their own).
 // Ablation switches (probe builds only): -DMLP_X_NOGELU (note: the phase-1 MFMAs then become dead code too), -DMLP_X_NODMA1, -DMLP_X_NORD1.
-// build+run on the GPU box:  hipcc -O3 --offload-arch=gfx950 -std=c++17 -Iinclude -DMLP_CLOCK_PROBE profiles/probes/clock_probe.hip -o /tmp/clock_probe && /tmp/clock_probe
+// build+run on the GPU box:  hipcc -O3 --offload-arch=gfx950 -std=c++17 -Iinclude -DMLP_CLOCK_PROBE profiles/probes/clock_probe.hip -o /tmp/clock_probe && /tmp/clock_probe [C=256] [M=32768]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -13,7 +13,7 @@ int master_check_launch(const char*) { return hipGetLastError() == hipSuccess ? 
 #include "../../mastermetastyletransfer_amd/csrc/mlp_bf16.hip"
 
 int main(int argc, char** argv) {
-    const int C = argc > 1 ? atoi(argv[1]) : 256, HID = 4 * C, M = 32768, WGS = M / 128;
+    const int C = argc > 1 ? atoi(argv[1]) : 256, HID = 4 * C, M = argc > 2 ? atoi(argv[2]) : 32768, WGS = M / 128;      // M = 128: one tile alone on the chip
     unsigned short *x, *w1, *w2, *out; float *b1, *b2; unsigned long long* probe;
     hipMalloc(&x, (size_t)M * C * 2); hipMalloc(&out, (size_t)M * C * 2); hipMalloc(&w1, (size_t)HID * C * 2); hipMalloc(&w2, (size_t)HID * C * 2);
     hipMalloc(&b1, HID * 4); hipMalloc(&b2, C * 4); hipMalloc(&probe, WGS * 10 * 8);
