@@ -97,25 +97,35 @@ __global__ __launch_bounds__(HPW * 64, 2) void window_attn_pw_kernel(PwArgs p) {
 
     // ---- LDS-DMA gather of one window, the channels of this workgroup's heads: every tile = 64 rows x 256 B = 16 pieces of 1 KB
     //      (4 rows each); wave w moves pieces 4w..4w+3 of each tile.  Position p of a row holds source chunk p ^ (row & 15). ---------
+    // Address arithmetic per piece (r02): one 24-bit multiply for the token row (tokens < 2^24, row pitch < 2^24 bytes: checked by the
+    // launcher) and 32-bit offsets from wave-uniform bases; a padded slot selects the pad row's (base, offset) pair instead.  The
+    // 64-bit multiply-adds the compiler made of  p.k + tk * p.ldk + ...  were ~40 quarter-rate instructions per window in a kernel
+    // that is issue-bound (profiles/r02_window_attn_bound_study.txt).
+    const bool same_ld = p.ldq == p.ldk && p.ldq == p.ldv;
     auto gather = [&](int win) __attribute__((always_inline)) {
         const int b = win / p.nW, w = win - b * p.nW;
         const int32_t* src = srcs + w * 64;
-        const size_t tok0 = (size_t)b * p.T;
+        const unsigned tok0 = (unsigned)b * (unsigned)p.T;
+        const unsigned kpad0 = (unsigned)b * (unsigned)p.k_pad_bs * 2u, vpad0 = (unsigned)b * (unsigned)p.v_pad_bs * 2u;     // bytes
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int I = wave * 4 + i;
             const int row = 4 * I + (lane >> 4);
-            const int qc = hg * (HPW * 4) + ((lane & 15) ^ (row & 15));    // source chunk (8 channels) of this lane within the full token row
+            const unsigned qcb = (unsigned)(hg * (HPW * 4) + ((lane & 15) ^ (row & 15))) * 16u;   // byte offset of the lane's source chunk (8 channels) in a token row
             const int idx = row < p.N ? src[row] : -1;
-            const size_t tk = tok0 + (idx < 0 ? 0 : idx);
-            const bf16_t* sq = p.q + tk * p.ldq + qc * 8;                  // padded query rows are never stored: any row will do
-            const bf16_t* sk = idx >= 0 ? p.k + tk * p.ldk + qc * 8 : p.k_pad + (size_t)b * p.k_pad_bs + qc * 8;
-            const bf16_t* s0 = idx >= 0 ? p.v0 + tk * p.ldv + qc * 8 : p.v0_pad + (size_t)b * p.v_pad_bs + qc * 8;
+            const bool real = idx >= 0;
+            const unsigned tk = tok0 + (real ? (unsigned)idx : 0u);
+            const unsigned oq = __umul24(tk, (unsigned)p.ldq * 2u) + qcb;           // padded query rows are never stored: any row will do
+            const unsigned ok = same_ld ? oq : __umul24(tk, (unsigned)p.ldk * 2u) + qcb;
+            const unsigned ov = same_ld ? oq : __umul24(tk, (unsigned)p.ldv * 2u) + qcb;
+            const char* sq = (const char*)p.q + oq;
+            const char* sk = real ? (const char*)p.k + ok : (const char*)p.k_pad + (kpad0 + qcb);
+            const char* s0 = real ? (const char*)p.v0 + ov : (const char*)p.v0_pad + (vpad0 + qcb);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sq, (__attribute__((address_space(3))) void*)(Qs + I * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sk, (__attribute__((address_space(3))) void*)(Ks + I * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s0, (__attribute__((address_space(3))) void*)(V0s + I * 1024), 16, 0, 0);
             if (DUAL) {
-                const bf16_t* s1 = idx >= 0 ? p.v1 + tk * p.ldv + qc * 8 : p.v1_pad + (size_t)b * p.v_pad_bs + qc * 8;
+                const char* s1 = real ? (const char*)p.v1 + ov : (const char*)p.v1_pad + (vpad0 + qcb);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s1, (__attribute__((address_space(3))) void*)(V1s + I * 1024), 16, 0, 0);
             }
         }
@@ -280,6 +290,10 @@ int window_attn_pw_bf16(const bf16_t* q, const bf16_t* k, const bf16_t* v0, cons
                         const float* bias, const int32_t* src, const uint8_t* region, bf16_t* out0, bf16_t* out1, int ldo,
                         int B, int T, int heads, int nW, int N, float scale, hipStream_t s) {
     if (heads != HEADS) return MASTER_ERR_UNSUPPORTED;
+    // the gather's 24-bit x 24-bit row offsets: token count, row pitches in bytes and every row offset below 2^24 / 2^32
+    if ((long long)B * T >= (1ll << 24) || ldq * 2 >= (1 << 24) || ldk * 2 >= (1 << 24) || ldv * 2 >= (1 << 24) ||
+        (long long)B * T * 2 * (ldq > ldk ? (ldq > ldv ? ldq : ldv) : (ldk > ldv ? ldk : ldv)) >= (1ll << 32) ||
+        (long long)B * 2 * (k_pad_bs > v_pad_bs ? k_pad_bs : v_pad_bs) >= (1ll << 32)) return MASTER_ERR_UNSUPPORTED;
     const int lds = (v1 ? 4 : 3) * TILE + nW * 64 * 5;
     if (lds > 160 * 1024) return MASTER_ERR_UNSUPPORTED;
     PwArgs p{q, k, v0, v1, ldq, ldk, ldv, k_pad, v0_pad, v1_pad, k_pad_bs, v_pad_bs, bias, src, region, out0, out1, ldo,
