@@ -17,6 +17,16 @@ INCLUDE = os.path.abspath(os.path.join(CSRC, "..", "..", "include"))
 LIB = os.path.join(CSRC, "libmaster_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", f"-I{INCLUDE}"]
+# Per-file extras.  -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs instead of AGPRs.  By default hipcc gives every accumulator an
+# AGPR, and each value the VALU touches afterwards (bias, ReLU, softmax, bf16 packing) is first copied out with v_accvgpr_read_b32:
+# 345 of them per window in the fused attention block, 320 + 320 moves in conv_ring, all of the GEMM epilogues.  With the flag those
+# kernels lose the moves (and 30-70 registers).  Measured per kernel on MI355X (profiles/r02_mfma_vgpr_form_ab.txt): attention block
+# -3 %, ring convolutions -2...-10 %, the fp32 GEMMs / window attention of the parity mode and the train step -1...-4 %;  NOT for the
+# two fused MLP kernels (they need the AGPR half of the register file: +5 % slower, or spills) nor linear_ts (neutral).
+VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+EXTRA_FLAGS = {f: VGPR_FORM for f in (
+    "attn_block_bf16.hip", "conv_ring_bf16.hip", "conv_tail_bf16.hip", "gemm_bf16.hip", "gemm_f32.hip", "gemm_f32_t.hip",
+    "window_attn_f32.hip", "window_attn_bwd_f32.hip", "window_attn_bf16.hip", "patch_embed_bf16.hip")}
 
 
 def _sources():
@@ -32,13 +42,14 @@ def _stale(target: str, deps) -> bool:
 
 def build_library(force: bool = False, verbose: bool = True) -> str:
     srcs = _sources()
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INCLUDE, "master_hip.h")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INCLUDE, "master_hip.h"),
+                                                                                        os.path.abspath(__file__)]     # the flags live here
     objs, jobs = [], []
     for s in srcs:
         src, obj = os.path.join(CSRC, s), os.path.join(CSRC, s[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([HIPCC, *FLAGS, "-c", src, "-o", obj])
+            jobs.append([HIPCC, *FLAGS, *EXTRA_FLAGS.get(s, []), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
