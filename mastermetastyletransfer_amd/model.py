@@ -154,13 +154,20 @@ class MasterStyleTransferModel(nn.Module):
         """torch.float32: exact-fp32 matrix cores, parity mode.  torch.bfloat16: bf16 MFMA, throughput mode."""
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("compute_dtype must be torch.float32 or torch.bfloat16")
-        if dtype == torch.bfloat16 and self.swin_variant != "swin_B":
-            # the bf16 kernels are specialised for swin_B's widths (128 / 256 channels, 4 / 8 heads); embed 96 runs in the fp32 mode
-            raise NotImplementedError(f"{self.swin_variant}: the bf16 throughput mode is built for swin_B widths; use torch.float32")
         self.compute_dtype = dtype
         for m in self.modules():
             if isinstance(m, (_HipModule, SwinEncoder)):
                 m.compute_dtype = dtype
+        # swin_T / swin_S: stage 1 is 96 channels wide and the bf16 GEMMs step K in 64s, so the patch embedding, the two stage-1 blocks
+        # and the patch merging stay in fp32 (SwinEncoder.run converts once, after the merge); stage 2, the StyleTransformer and the
+        # decoder (192 / 768 / 384 wide) run on the generic bf16 kernels - the fused ones are specialised for swin_B's 128 / 256.
+        self.swin_encoder.stage1_dtype = dtype
+        if dtype == torch.bfloat16 and self.swin_encoder[0][0].out_channels % 64 != 0:
+            self.swin_encoder.stage1_dtype = torch.float32
+            for part in (self.swin_encoder[1], self.swin_encoder[2]):
+                for m in part.modules():
+                    if isinstance(m, _HipModule):
+                        m.compute_dtype = torch.float32
         return self
 
     def forward(self, content_image: Tensor, style_image: Tensor, transformer_layer_count: int = 1) -> Tensor:

@@ -797,14 +797,15 @@ class SwinEncoder(nn.Sequential):
             raise ValueError("image sides must be multiples of 4 (the 4x4 patch embedding has stride 4 and no padding)")
         conv, ln = self[0][0], self[0][2]
         B = sum(int(i.shape[0]) for i in imgs)
-        x = torch.empty((B, H // 4, W // 4, conv.weight.shape[0]), dtype=self.compute_dtype, device=imgs[0].device)
+        dt1 = getattr(self, "stage1_dtype", None) or self.compute_dtype          # fp32 for embed 96 in the bf16 mode (model.set_compute_dtype)
+        x = torch.empty((B, H // 4, W // 4, conv.weight.shape[0]), dtype=dt1, device=imgs[0].device)
         b0 = 0
         for img in imgs:
             if img.shape[1:] != imgs[0].shape[1:]:
                 raise ValueError("all image batches must have the same size")
             ops.patch_embed(img.contiguous().float(), conv.weight.detach().reshape(conv.weight.shape[0], -1).float().contiguous(),
                             conv.bias.detach().float(), ln.weight.detach().float(), ln.bias.detach().float(),
-                            self.compute_dtype, ln.eps, out=x[b0:b0 + img.shape[0]])
+                            dt1, ln.eps, out=x[b0:b0 + img.shape[0]])
             b0 += img.shape[0]
         # train mode: torchvision's blocks apply StochasticDepth; each image batch (one reference encoder call) draws its masks
         # in call order - all of content's, then all of style's - and the per-block masks of the 2B batch are their concatenation
@@ -821,6 +822,8 @@ class SwinEncoder(nn.Sequential):
         for blk in self[1]:
             x = blk.run(x, B, h, w, masks.get(id(blk)))
         x = self[2].run(x, B, h, w)
+        if x.dtype != self.compute_dtype:
+            x = ops.convert(x, self.compute_dtype)
         h, w = (h + 1) // 2, (w + 1) // 2
         for blk in self[3]:
             x = blk.run(x, B, h, w, masks.get(id(blk)))

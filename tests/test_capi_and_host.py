@@ -188,8 +188,10 @@ def test_swin_t_and_s_variants_have_torchvision_key_shapes(lib):
         probs = [b.stochastic_depth_prob for stage in (m.swin_encoder[1], m.swin_encoder[3]) for b in stage]
         assert probs == pytest.approx([p * n / (total - 1) for n in range(4)])
         assert m.decoder.padded_channels(14) == (32, 64) and m.decoder.padded_channels(19) == (3, 32)      # 48 -> 24 and 24 -> 3 layers
-        with pytest.raises(NotImplementedError, match="swin_B widths"):
-            m.set_compute_dtype(torch.bfloat16)
+        m.set_compute_dtype(torch.bfloat16)                        # 96-wide stage 1 stays fp32, the rest goes bf16
+        assert m.swin_encoder.stage1_dtype == torch.float32 and m.swin_encoder[1][0].compute_dtype == torch.float32
+        assert m.swin_encoder[2].compute_dtype == torch.float32 and m.swin_encoder[3][0].compute_dtype == torch.bfloat16
+        assert m.style_transformer.encoder.compute_dtype == torch.bfloat16 and m.decoder.compute_dtype == torch.bfloat16
 
 
 def test_missing_swin_weights_fail_loudly(lib):
