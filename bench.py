@@ -184,18 +184,25 @@ PMC_KERNELS = {"mlp": ("mlp_bf16_kernel", "mlp_c128_kernel"), "linear": ("linear
                "patch_embed": ("patch_embed_bf16_kernel", "patch_embed_kernel")}
 
 
+def latest_profile(suffix):
+    """newest committed profiles/rNN_<suffix> (the PMC passes are re-collected every round on the final tree), or None"""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return hits[-1] if hits else None
+
+
 def pmc_traffic(family, args):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes of THIS command line
     (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/pmc_traffic.py); None when no matching profile exists."""
-    path = os.path.join(ROOT, "profiles", "r02_bf16_bs32_pmc_traffic.json")
-    if args.dtype != "bf16" or args.batch != 32 or args.size != 256 or args.layers != 1 or not os.path.exists(path):
+    path = latest_profile("bf16_bs32_pmc_traffic.json")
+    if args.dtype != "bf16" or args.batch != 32 or args.size != 256 or args.layers != 1 or path is None:
         return None, None
     prof = json.load(open(path))
     tot_b = tot_n = 0.0
     for name, v in prof.items():
         if any(name.startswith(pfx) for pfx in PMC_KERNELS.get(family, ())):
             tot_b += v["hbm_bytes_per_launch"] * v["launches"]; tot_n += v["launches"]
-    return (round(tot_b / tot_n) if tot_n else None), "profiles/r02_bf16_bs32_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    return (round(tot_b / tot_n) if tot_n else None), os.path.relpath(path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
 
 
 def extras(model, content, style, k, args, ops):
@@ -219,6 +226,8 @@ def extras(model, content, style, k, args, ops):
                          "tflops": round(c["flops"] / (ms * 1e-3) / 1e12, 2) if c.get("flops") else None,
                          "alg_gbytes_per_s": round(c["bytes"] / (ms * 1e-3) / 1e9, 1) if c.get("bytes") else None}
     out["kernels"] = fam
+    # every launch of a replayed step is one of the library's kernels (the torch copies a kernel trace shows all sit before the capture)
+    out["launches_per_step"] = sum(v["launches_per_step"] for v in fam.values())
     # roofline of the DOMINANT kernel family of this step (largest summed duration)
     mfma_fams = ("linear", "conv3x3", "mlp", "decoder_tail", "window_attn")
     dom = max((k for k in fam if prof[k][0]), key=lambda k: prof[k][1])
@@ -254,12 +263,12 @@ def extras(model, content, style, k, args, ops):
     # 49x49x32 problem occupies a 64x64x32 MFMA tile, so at 100 % issue only 58.6 % of the matrix-core work is useful, and QK^T is
     # 8 of the 40 MFMAs the dual-stream kernel spends per (window, head) (8 bias-through-identity, 8 ones-denominators, 16 P.V)
     busy = None
-    mp = os.path.join(ROOT, "profiles", "r02_bf16_bs32_pmc_mfma_util.json")
-    if args.dtype == "bf16" and os.path.exists(mp):
+    mp = latest_profile("bf16_bs32_pmc_mfma_util.json")
+    if args.dtype == "bf16" and mp is not None:
         for name, v in json.load(open(mp)).items():
             if name.startswith("window_attn_pw_kernel<true>"):
                 busy = v.get("mfma_util_pct", v.get("mfma_util"))
-    out["attn_core"].update({"cross_attn_kernel_mfma_busy_pct_pmc": busy, "pmc_source": "profiles/r02_bf16_bs32_pmc_mfma_util.json",
+    out["attn_core"].update({"cross_attn_kernel_mfma_busy_pct_pmc": busy, "pmc_source": os.path.relpath(mp, ROOT) if mp else None,
                              "padded_tile_useful_fraction_ceiling": round(49 * 49 / (64.0 * 64.0), 3), "qk_share_of_kernel_mfmas": 8 / 40.0,
                              "target": ">= 50 % of bf16 MFMA peak on the cross-attention QK^T: NOT met and not reachable by a "
                                        "49x49x32 problem fused into a softmax kernel (VALU/HBM-bound); reported as measured"})
@@ -398,6 +407,9 @@ def train_bench(device, steps=10, warmup=3, B=8, S=256, max_layers=4, roofline=T
                 c = counts.get(name, {})
                 fam[name] = {"launches": n, "ms": round(ms, 3), "tflops": round(c["flops"] / (ms * 1e-3) / 1e12, 2) if c.get("flops") else None}
         res["kernels_k2_step"] = fam
+        # launches of one k = 2 step: the library's own (counted at the C ABI) + torch's (index plumbing, [B,C] loss arithmetic), the
+        # latter from the committed kernel trace of this command (profiles/rNN_train_trace_by_shape*.txt)
+        res["launches_k2_step"] = {"library": sum(v["launches"] for v in fam.values()), "torch": torch_launches_from_trace()}
         cand = [k for k in fam if counts.get(k, {}).get("flops")]
         dom = max(cand, key=lambda k: prof[k][1])
         n, ms = prof[dom]
@@ -411,6 +423,19 @@ def train_bench(device, steps=10, warmup=3, B=8, S=256, max_layers=4, roofline=T
                            "alg_bytes_per_launch": counts[dom].get("bytes", 0.0) / n,
                            "share_of_step_kernel_time": round(ms / sum(v[1] for v in prof.values()), 3)}
     return res
+
+
+def torch_launches_from_trace():
+    """torch / runtime kernel launches per train step in the newest committed trace_by_shape of `bench.py --mode train`"""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_train_trace_by_shape*.txt")))
+    if not hits:
+        return None
+    n = 0.0
+    for line in open(hits[-1]):
+        if "n/step=" in line and (line.startswith("at::") or line.startswith("__amd_rocclr") or line.startswith("void at::")):
+            n += float(line.split("n/step=")[1].split()[0])
+    return {"per_step": round(n, 1), "source": os.path.relpath(hits[-1], ROOT)}
 
 
 def train_main(args):

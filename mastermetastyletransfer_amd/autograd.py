@@ -495,7 +495,7 @@ class PerceptualLossFn(torch.autograd.Function):
         for i in range(30):
             if i in VGG19_CONVS:
                 w, b = vgg._weights(i)
-                h = ops.conv3x3_zero(h, w, b, relu=True)
+                h = ops.conv3x3_zero(h, w, b, relu=True, logical_cin=vgg.features[i].weight.shape[1])
                 acts[i] = h
             elif i in VGG19_POOLS:
                 h = ops.maxpool2x2(h)

@@ -83,7 +83,7 @@ class VGG19_custom(nn.Module):
         for i in range(30):
             if i in VGG19_CONVS:
                 w, b = self._weights(i)
-                h = ops.conv3x3_zero(h, w, b, relu=True)                           # conv i and the ReLU at i+1 in one launch
+                h = ops.conv3x3_zero(h, w, b, relu=True, logical_cin=VGG19_CONVS[i][0])                           # conv i and the ReLU at i+1 in one launch
             elif i in VGG19_POOLS:
                 h = ops.maxpool2x2(h)
             elif i in VGG19_TAPS:

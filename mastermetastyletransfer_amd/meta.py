@@ -43,17 +43,29 @@ def allreduce_gradients(params: Iterable[nn.Parameter], average: bool = True) ->
     SURVEY 8e; one large collective suits the per-link-bound xGMI ring better than 69 small ones)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
-    ps = [p for p in params if p.grad is not None]
+    # the flat buffer covers EVERY trainable parameter, in the caller's order, whether or not this rank produced a gradient for it
+    # (a parameter unused on one rank contributes zeros), followed by one "has a gradient" flag per parameter: the buffer has the same
+    # size on every rank by construction, so ranks that disagree about which gradients exist can neither hang the collective nor
+    # mis-align it.  A parameter without a gradient on ANY rank keeps grad = None (the optimizer skips it, like torch).
+    ps = [p for p in params if p.requires_grad]
     if not ps:
         return
-    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    dev = ps[0].device
+    has = torch.tensor([0.0 if p.grad is None else 1.0 for p in ps], dtype=ps[0].dtype, device=dev)
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ps] + [has])
     dist.all_reduce(flat)
+    counts = flat[-len(ps):].tolist()
     if average:
         flat /= dist.get_world_size()
     off = 0
-    for p in ps:
-        n = p.grad.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+    for p, c in zip(ps, counts):
+        n = p.numel()
+        if c > 0.0:
+            g = flat[off:off + n].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
         off += n
 
 
@@ -65,6 +77,8 @@ class ReptileTrainer:
         self.outer_lr, self.num_inner_updates, self.max_layers = outer_lr, num_inner_updates, max_layers
         for p in model.swin_encoder.parameters():                     # freeze_encoder (the reference's default)
             p.requires_grad = False
+        for m in list(model.style_transformer.modules()) + list(model.decoder.modules()):
+            m.__dict__.pop("_derived_cache", None)                    # device copies derived from theta's weights: not part of omega
         self.omega_st = copy.deepcopy(model.style_transformer).train()
         self.omega_dec = copy.deepcopy(model.decoder).train()
         self.optimizer = FusedAdam(list(self.omega_st.parameters()) + list(self.omega_dec.parameters()), lr=inner_lr)     # train.py:398
@@ -76,9 +90,11 @@ class ReptileTrainer:
         enc = self.model.swin_encoder
         was = enc.training
         enc.train(True)                                               # the reference's model is in train mode (StochasticDepth active)
-        with torch.no_grad():
-            x, _, h, w = enc.run(content, style)
-        enc.train(was)
+        try:
+            with torch.no_grad():
+                x, _, h, w = enc.run(content, style)
+        finally:
+            enc.train(was)                                            # also when an explicit mask list runs out mid-call
         fc, fs = x[: B * h * w], x[B * h * w:]
         fcs = TF.style_transformer(self.omega_st, fc, fs, k, B, h, w, TF.sd_masks)
         return TF.image_decoder(self.omega_dec, fcs.view(B, h, w, -1))
@@ -97,6 +113,8 @@ class ReptileTrainer:
             total.backward()
             if self.on_inner_step is not None:
                 self.on_inner_step(i, total)
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:      # data-parallel meta-training
+                allreduce_gradients(list(self.omega_st.parameters()) + list(self.omega_dec.parameters()))
             self.optimizer.step()
             losses.append(float(total.detach()))
         # theta += outer_lr * (omega - theta): every tensor of both modules in one launch  (train.py:524-534)

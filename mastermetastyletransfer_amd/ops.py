@@ -296,7 +296,9 @@ def attn_block(x, ln_gamma, ln_beta, wqkv, bqkv, wproj, bproj, bias64, src, regi
     assert M == B * T and wqkv.shape == (3 * C, C) and wproj.shape == (C, C) and wqkv.is_contiguous() and wproj.is_contiguous()
     out = torch.empty_like(x)
     if _COUNT_ON:
-        _count("attn_block", flops=2.0 * B * nW * 64 * C * 4 * C + 4.0 * B * nW * heads * N * N * 32, bytes=4.0 * x.numel())
+        # algorithmic work = what the reference computes: the projections on the N (= 49) tokens of a window (642 MFLOP per
+        # image and block at C = 256 / 25 windows), not on the kernel's 64-slot tiles
+        _count("attn_block", flops=2.0 * B * nW * N * C * 4 * C + 4.0 * B * nW * heads * N * N * 32, bytes=4.0 * x.numel())
     _check(load_library().master_attn_block_fwd(_p(x), _p(ln_gamma), _p(ln_beta), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj),
                                                  _p(bias64), _p(src), _p(region), _p(out), B, T, C, heads, nW, N, eps,
                                                  float(scale), _dt(x), _stream()), "master_attn_block_fwd")
@@ -463,14 +465,18 @@ def image_to_nhwc(img, cpad: int, dtype: torch.dtype) -> torch.Tensor:
 
 
 @_on_device
-def conv3x3_zero(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, relu: bool = True) -> torch.Tensor:
-    """nn.Conv2d(Cin, Cout, 3, padding=1) (+ReLU) on NHWC x; w_packed = [Cout,3,3,Cin]"""
+def conv3x3_zero(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, relu: bool = True,
+                 logical_cin: Optional[int] = None) -> torch.Tensor:
+    """nn.Conv2d(Cin, Cout, 3, padding=1) (+ReLU) on NHWC x; w_packed = [Cout,3,3,Cin].  logical_cin: the reference layer's input
+    channels when x carries zero-padded ones (VGG conv1_1: 3 of 32) - only the work counters use it."""
     _dev(x, w_packed)
     B, H, W, Cin = x.shape
     Cout = w_packed.shape[0]
     out = torch.empty((B, H, W, Cout), dtype=x.dtype, device=x.device)
     if _COUNT_ON:
-        _count("conv3x3", flops=2.0 * B * H * W * Cout * 9 * Cin, bytes=x.element_size() * (x.numel() + w_packed.numel() + out.numel()))
+        lc = Cin if logical_cin is None else logical_cin
+        _count("conv3x3", flops=2.0 * B * H * W * Cout * 9 * lc,
+               bytes=x.element_size() * (B * H * W * lc + Cout * 9 * lc + out.numel()))
     _check(load_library().master_conv3x3_zero_fwd(_p(x), _p(w_packed), _p(bias), _p(out), B, H, W, Cin, Cout, int(relu), _dt(x), _stream()),
            "master_conv3x3_zero_fwd")
     return out

@@ -17,14 +17,57 @@ from . import ops
 from .ops import _check, _p, _stream, load_library
 
 
-def _table(recs: Sequence[Sequence[int]], device) -> tuple:
-    """recs: (p_ptr, g_ptr, m_ptr, v_ptr, numel) per tensor -> (device int64 table [n,6], total blocks)"""
+def _rows(recs: Sequence[Sequence[int]]) -> tuple:
+    """recs: (p_ptr, g_ptr, m_ptr, v_ptr, numel) per tensor -> (host rows [n][6], total blocks)"""
     chunk = load_library().master_adam_chunk()
     rows, first = [], 0
     for p, g, m, v, n in recs:
         rows.append([p, g, m, v, n, first])
         first += (n + chunk - 1) // chunk
+    return rows, first
+
+
+def _table(recs: Sequence[Sequence[int]], device) -> tuple:
+    """-> (device int64 table [n,6], total blocks); a one-off, synchronous upload (reptile_update: once per outer iteration)"""
+    rows, first = _rows(recs)
     return torch.tensor(rows, dtype=torch.int64).to(device), first
+
+
+class _PointerTable:
+    """The device table of one param group, refreshed WITHOUT a host-device synchronisation: `zero_grad(set_to_none=True)` (every
+    caller's default) makes backward allocate fresh gradient tensors, so the gradient pointers may change every step.  The rows are
+    written into one of two pinned host buffers and copied with a stream-ordered non-blocking copy; the event recorded after the copy
+    guards the buffer's reuse two refreshes later (it has long completed by then)."""
+
+    def __init__(self, n: int, device):
+        self.dev = torch.empty((n, 6), dtype=torch.int64, device=device)
+        self.host = [torch.empty((n, 6), dtype=torch.int64).pin_memory() for _ in range(2)]
+        self.done = [None, None]
+        self.turn = 0
+        self.key, self.nblocks = None, 0
+
+    def refresh(self, key, recs):
+        if key == self.key:
+            return
+        rows, self.nblocks = _rows(recs)
+        i = self.turn
+        self.turn ^= 1
+        if self.done[i] is not None:
+            self.done[i].synchronize()
+        self.host[i].copy_(torch.tensor(rows, dtype=torch.int64))
+        self.dev.copy_(self.host[i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.done[i] = ev
+        self.key = key
+
+
+def _mark_written(tensors: Iterable[Tensor]) -> None:
+    """The kernels above write parameters through raw pointers, which torch cannot see: bump every tensor's version counter so that
+    caches keyed on it (the modules' derived-weight cache: fused qkv concatenations, packed convolution weights, bf16 copies) notice
+    the update and an in-process eval forward after training uses the new weights."""
+    for t in tensors:
+        torch.autograd.graph.increment_version(t)
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -34,7 +77,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._tables: Dict[int, tuple] = {}
+        self._tables: Dict[int, _PointerTable] = {}
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -66,14 +109,15 @@ class FusedAdam(torch.optim.Optimizer):
             if len(steps) != 1:
                 raise ops.MasterHipError("FusedAdam: the tensors of a param group must share their step count")
             key = tuple(r[:5] for r in recs)
-            hit = self._tables.get(gi)
-            if hit is None or hit[0] != key:
-                table, nblocks = _table([r[:5] for r in recs], dev)
-                hit = self._tables[gi] = (key, table, nblocks)
             b1, b2 = group["betas"]
             with torch.cuda.device(dev):
-                _check(lib.master_adam_step(_p(hit[1]), len(recs), hit[2], float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                tab = self._tables.get(gi)
+                if tab is None or tab.dev.shape[0] != len(recs) or tab.dev.device != dev:
+                    tab = self._tables[gi] = _PointerTable(len(recs), dev)
+                tab.refresh(key, [r[:5] for r in recs])
+                _check(lib.master_adam_step(_p(tab.dev), len(recs), tab.nblocks, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                             float(group["weight_decay"]), int(steps.pop()), _stream()), "master_adam_step")
+            _mark_written(ps)
         return loss
 
 
@@ -92,3 +136,4 @@ def reptile_update(theta: Iterable[Tensor], omega: Iterable[Tensor], eta: float)
     table, nblocks = _table(recs, dev)
     with torch.cuda.device(dev):
         _check(load_library().master_lerp(_p(table), len(recs), nblocks, float(eta), _stream()), "master_lerp")
+    _mark_written(th)

@@ -128,11 +128,14 @@ def _worker_grads(rank, world, port, q):
     try:
         from mastermetastyletransfer_amd.meta import allreduce_gradients
         g = torch.Generator().manual_seed(rank)
-        ps = [torch.nn.Parameter(torch.zeros(s)) for s in ((5, 3), (7,), (2, 2, 2))] + [torch.nn.Parameter(torch.zeros(4))]
+        ps = [torch.nn.Parameter(torch.zeros(s)) for s in ((5, 3), (7,), (2, 2, 2))] + [torch.nn.Parameter(torch.zeros(4)),
+                                                                                       torch.nn.Parameter(torch.zeros(3))]
         for p in ps[:3]:
             p.grad = torch.randn(p.shape, generator=g)
-        allreduce_gradients(ps)                       # the last parameter has no gradient: skipped on every rank
-        q.put((rank, [p.grad.clone() for p in ps[:3]], ps[3].grad is None))
+        if rank == 1:
+            ps[4].grad = torch.full((3,), 2.0)        # a gradient on ONE rank only (a parameter the other rank's step did not use)
+        allreduce_gradients(ps)                       # ps[3] has no gradient anywhere: stays None on every rank
+        q.put((rank, [p.grad.clone() for p in ps[:3]], ps[3].grad is None, ps[4].grad.clone()))
     finally:
         dist.destroy_process_group()
 
@@ -157,7 +160,8 @@ def test_gradient_allreduce_world_2():
     # generators advance tensor by tensor: rebuild in the same order
     gens = [torch.Generator().manual_seed(r) for r in range(2)]
     want = [sum(torch.randn(shape, generator=gens[r]) for r in range(2)) / 2 for shape in ((5, 3), (7,), (2, 2, 2))]
-    for rank, grads, none_kept in res:
+    for rank, grads, none_kept, lonely in res:
         assert none_kept
+        assert torch.equal(lonely, torch.full((3,), 1.0))         # (0 + 2) / 2 on both ranks: buffers aligned although the ranks disagreed
         for a, b in zip(grads, want):
             assert torch.allclose(a, b, atol=1e-7)
