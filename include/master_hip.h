@@ -115,6 +115,18 @@ int master_window_attn_fwd(const void* q, const void* k, const void* v0, const v
                            const uint8_t* region, void* out0, void* out1, int ldo, int B, int T, int heads,
                            int nW, int N, float scale, int dtype, master_stream_t stream);
 
+/* master_window_attn_fwd (one value stream) with the output projection and the block's residual folded into the same launch:
+ *     out[token, :] = res[token, :] + wproj . concat_heads(P V) + bproj         (res optional = NULL)
+ * wproj [C, C] row-major as nn.Linear stores it, bproj fp32 [C]; res / out token matrices [B*T, C] with row strides ldr / ldo.
+ * A workgroup is a whole window (wave = head); the attention output never goes to HBM.  Replaces style_transformer.py:120-168
+ * (attention core, proj :156, window reverse / un-pad) and the residual add of :391 for the calls with ONE value stream.
+ * MASTER_BF16 with heads == 8 (C == 256) and nW <= ~100 windows per image only; MASTER_ERR_UNSUPPORTED otherwise (callers then use
+ * master_window_attn_fwd + master_linear_fwd). */
+int master_window_attn_proj_fwd(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const void* k_pad,
+                                const void* v_pad, int k_pad_bstride, int v_pad_bstride, const float* bias, const int32_t* src,
+                                const uint8_t* region, const void* wproj, const float* bproj, const void* res, int ldr, void* out,
+                                int ldo, int B, int T, int heads, int nW, int N, float scale, int dtype, master_stream_t stream);
+
 /* Whole attention half of a (Style)SwinTransformerBlock with q = k = v in ONE launch:
  *     out = x + proj( window_attention( qkv( LayerNorm?(x) ) ) )
  * x, out: token matrices [B*T, C]; wqkv [3C, C] = rows of Wq | Wk | Wv (torchvision's fused qkv.weight), bqkv [3C] fp32;

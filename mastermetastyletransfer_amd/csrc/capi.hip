@@ -12,6 +12,9 @@
 int gemm_f32_linear(const float*, const float*, const float*, const float*, const float*, float*, int, int, int, int,
                     int, int, int, hipStream_t, float* aux = nullptr);
 // ---- train step (gemm_f32.hip, gemm_f32_t.hip, norms_bwd.hip, window_attn_bwd_f32.hip, train_misc.hip) ----
+int window_attn_proj_bf16(const bf16_t*, const bf16_t*, const bf16_t*, int, int, int, const bf16_t*, const bf16_t*, int, int, const float*,
+                          const int32_t*, const uint8_t*, const bf16_t*, const float*, const bf16_t*, int, bf16_t*, int, int, int, int, int,
+                          int, float, hipStream_t);
 int gemm_f32_conv3x3_dgrad(const float*, const float*, float*, const float*, const float*, int, int, int, int, int, int, hipStream_t);
 size_t gemm_f32_t_workspace(int, int);
 int gemm_f32_dgrad(const float*, const float*, float*, const float*, int, int, int, int, int, int, hipStream_t);
@@ -612,6 +615,27 @@ int master_window_attn_fwd(const void* q, const void* k, const void* v0, const v
     }
     master_set_error("window_attn: bad dtype %d", dtype);
     return MASTER_ERR_INVALID;
+}
+
+int master_window_attn_proj_fwd(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const void* k_pad,
+                                const void* v_pad, int k_pad_bstride, int v_pad_bstride, const float* bias, const int32_t* src,
+                                const uint8_t* region, const void* wproj, const float* bproj, const void* res, int ldr, void* out,
+                                int ldo, int B, int T, int heads, int nW, int N, float scale, int dtype, master_stream_t stream) {
+    REQUIRE(q && k && v && out && bias && src && wproj && bproj, "window_attn_proj: null operand");
+    REQUIRE(k_pad && v_pad, "window_attn_proj: pad rows are required (pass the projection bias)");
+    REQUIRE(B > 0 && T > 0 && heads > 0 && nW > 0 && N > 0 && N <= 64, "window_attn_proj: window of %d tokens unsupported (max 64)", N);
+    REQUIRE(out != q && out != k && out != v, "window_attn_proj: in-place call");
+    if (dtype != MASTER_BF16) { master_set_error("window_attn_proj: bf16 only (the fp32 mode runs master_window_attn_fwd + master_linear_fwd)"); return MASTER_ERR_UNSUPPORTED; }
+    REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0 && (res == nullptr || ldr % 4 == 0), "window_attn_proj: leading dims must be multiples of 8 (q/k/v) and 4 (res/out)");
+    REQUIRE(al16(q) && al16(k) && al16(v) && al16(k_pad) && al16(v_pad) && al16(wproj) && al16(out) && (res == nullptr || al16(res)),
+            "window_attn_proj: operands must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_ATTN, s);
+    const int rc = window_attn_proj_bf16((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, (const bf16_t*)k_pad,
+                                         (const bf16_t*)v_pad, k_pad_bstride, v_pad_bstride, bias, src, region, (const bf16_t*)wproj, bproj,
+                                         (const bf16_t*)res, ldr, (bf16_t*)out, ldo, B, T, heads, nW, N, scale, s);
+    if (rc == MASTER_ERR_UNSUPPORTED) master_set_error("window_attn_proj: geometry outside the fused kernel (heads %d, %d windows per image)", heads, nW);
+    return rc;
 }
 
 int master_attn_block_fwd(const void* x, const float* ln_gamma, const float* ln_beta, const void* wqkv, const float* bqkv,

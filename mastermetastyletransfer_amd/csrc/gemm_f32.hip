@@ -12,6 +12,7 @@
 // pairs column s (half 0) with column 16+s (half 1).  A and W use the same k permutation, so the sum
 // is unchanged.  One barrier per K chunk; the next chunk's global loads are issued before the MFMAs.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -189,6 +190,264 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(Ge
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// r03: the same tile computed from an LDS ring filled by LDS-DMA (global_load_lds, 16 B per lane, 1-KB pieces = 8 rows x 128 B).
+// Nothing is staged through registers any more: the old form held a chunk in 8 VGPR quads, waited for it mid-iteration
+// (vmcnt(0) before its ds_write_b128s) and paid the tap / reflect arithmetic of the convolution gather on every 32-wide chunk.
+//   * LDS rows are 128 B (BK = 32 floats), un-padded (a DMA piece lands contiguously); 16-B chunk position c of row R holds source
+//     chunk c ^ ((R >> 1) & 7): the 16 rows of a ds_read_b128 lane group ({0-3,12-15,20-27} / {4-11,16-19,28-31}) alternate
+//     between the two bank halves and their (R >> 1) & 7 are distinct, so the fragment reads stay conflict-free.
+//   * NSTAGE-deep ring, one s_barrier per chunk: at step kt every wave waits for ITS pieces of chunk kt (counted vmcnt: the NSTAGE - 2
+//     younger chunks stay in flight), the barrier makes the chunk visible and frees the slot read at step kt - 1, which is refilled
+//     at once with chunk kt + NSTAGE - 1.
+//   * convolution gather: a lane's source pixel moves only when the TAP changes (every Cin / 32 chunks), so the reflect / upsample /
+//     zero-pad arithmetic runs 9 times per tile instead of 9 Cin / 32 times; out-of-image taps of a zero-padded convolution read a
+//     512-float zero block.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) float g_zero_row[512];          // never written: zero-initialised by the loader
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <int BM, int BN, int WM, int WN, bool CONV, int NSTAGE>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_dma_kernel(GemmArgs p) {
+    constexpr int NWN = BN / WN;
+    constexpr int NWAVES = (BM / WM) * NWN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int APW = BM / 8 / NWAVES, WPW = BN / 8 / NWAVES;          // 1-KB pieces per wave and chunk
+    constexpr int PPW = APW + WPW;
+    constexpr int STAGE = (BM + BN) * 128;                                // bytes per ring slot: A rows, then W rows
+    static_assert((BM / 8) % NWAVES == 0 && (BN / 8) % NWAVES == 0, "pieces must divide over the waves");
+    static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave / NWN) * WM, wn = (wave % NWN) * WN;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int MT = (p.M + BM - 1) / BM, NTN = (p.N + BN - 1) / BN;
+    const int id = blockIdx.x;
+    const int j8 = id >> 3;
+    const int mt = (j8 / NTN) * 8 + (id & 7), nt = j8 % NTN;           // XCD-aware order, as above
+    if (mt >= MT) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // ---- per-lane DMA sources: piece j of this wave = tile rows (wave * XPW + j) * 8 + (lane >> 3), LDS chunk position lane & 7 ------
+    const int prow = lane >> 3, ppos = lane & 7;
+    const float* a_src[APW];
+    int cy[CONV ? APW : 1], cx[CONV ? APW : 1], cimg[CONV ? APW : 1], csw[CONV ? APW : 1];
+#pragma unroll
+    for (int j = 0; j < APW; ++j) {
+        const int row = (wave * APW + j) * 8 + prow;
+        const int sw = (ppos ^ ((row >> 1) & 7)) * 4;                  // float offset of the lane's source chunk within the 32-wide k chunk
+        int m = m0 + row; m = m < p.M ? m : p.M - 1;
+        if (CONV) {
+            const int hw = p.Hout * p.Wout;
+            const int b = m / hw, pix = m - b * hw;
+            cy[j] = pix / p.Wout; cx[j] = pix - cy[j] * p.Wout; cimg[j] = b * p.Hin * p.Win; csw[j] = sw;
+            a_src[j] = p.a;
+        } else {
+            a_src[j] = p.a + (size_t)m * p.lda + sw;
+        }
+    }
+    const float* w_src[WPW];
+#pragma unroll
+    for (int j = 0; j < WPW; ++j) {
+        const int row = (wave * WPW + j) * 8 + prow;
+        int n = n0 + row; n = n < p.N ? n : p.N - 1;
+        w_src[j] = p.w + (size_t)n * p.K + (ppos ^ ((row >> 1) & 7)) * 4;
+    }
+    auto set_tap = [&](int tap) __attribute__((always_inline)) {       // CONV: the lane's source pixel of every A piece for this tap
+        const int dy = tap / 3 - 1 - p.off, dx = tap % 3 - 1 - p.off;
+        const int Hs = p.Hin << p.up, Ws = p.Win << p.up;
+#pragma unroll
+        for (int j = 0; j < APW; ++j) {
+            const int yy = cy[j] + dy, xx = cx[j] + dx;
+            const int sy = reflect1(yy, Hs) >> p.up, sx = reflect1(xx, Ws) >> p.up;
+            const bool outside = p.zero_pad && ((unsigned)yy >= (unsigned)Hs || (unsigned)xx >= (unsigned)Ws);
+            a_src[j] = outside ? (const float*)g_zero_row + csw[j]
+                               : p.a + ((size_t)(cimg[j] + sy * p.Win + sx)) * p.Cin + csw[j];
+        }
+    };
+    int i_tap = 0, i_c0 = 0;                                           // (tap, channel offset) of the next chunk to issue (CONV)
+    if (CONV) set_tap(0);
+    auto issue = [&](int kt) __attribute__((always_inline)) {
+        unsigned char* slot = ring + (kt % NSTAGE) * STAGE;
+        const int ka = CONV ? i_c0 : kt * BK;
+#pragma unroll
+        for (int j = 0; j < APW; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + ka),
+                                             (__attribute__((address_space(3))) void*)(slot + (wave * APW + j) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < WPW; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(slot + BM * 128 + (wave * WPW + j) * 1024), 16, 0, 0);
+        if (CONV) {
+            i_c0 += BK;
+            if (i_c0 == p.Cin) { i_c0 = 0; ++i_tap; if (i_tap < 9) set_tap(i_tap); }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.0f;
+
+    const int nk = p.K / BK;
+#pragma unroll
+    for (int t = 0; t < NSTAGE - 1; ++t) if (t < nk) issue(t);
+
+    const int fsw = (r >> 1) & 7;                                      // swizzle of this lane's fragment rows (tile rows are multiples of 32 apart)
+    for (int kt = 0; kt < nk; ++kt) {
+        if (NSTAGE == 3 && kt + 1 < nk) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1);
+        const unsigned char* ab = ring + (kt % NSTAGE) * STAGE + (wm + r) * 128;
+        const unsigned char* wb = ring + (kt % NSTAGE) * STAGE + BM * 128 + (wn + r) * 128;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int off = ((4 * h + q) ^ fsw) << 4;
+            f32x4 av[TM], wv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = *(const f32x4*)(ab + i * 32 * 128 + off);
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) wv[jn] = *(const f32x4*)(wb + jn * 32 * 128 + off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < TN; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], wv[jn][e], acc[i][jn], 0, 0, 0);
+        }
+        asm volatile("" ::: "memory");                                 // the slot is refilled behind the next barrier: no read may sink below it
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------------------------------------------------
+    // r02's element-wise form (one 4-byte load / store per accumulator register behind per-element branches; hipcc serialised it into
+    // load -> s_waitcnt vmcnt(0) -> store chains, ~35 k clocks per 128 x 128 tile: it, not the main loop, bounded the Linear shapes)
+    // is kept only for outputs it alone can address (NCHW image, N % 4 != 0, unaligned operands).  Everything else goes through the
+    // idle ring: the accumulators are written as the [BM][BN] fp32 tile (32 consecutive floats per half-wave: conflict-free), then
+    // every thread takes whole 16-byte pieces of rows: coalesced float4 loads of bias / r1 / r2, float4 stores, no per-element branch.
+    const bool vec_ok = (p.N & 3) == 0 && !(CONV && p.out_nchw) && (p.ldo & 3) == 0 && (((uintptr_t)p.out) & 15) == 0 &&
+                        (!p.aux || (((uintptr_t)p.aux) & 15) == 0) && (!p.bias || (((uintptr_t)p.bias) & 15) == 0) &&
+                        ((!p.r1 && !p.r2) || ((p.ldr & 3) == 0 && ((((uintptr_t)p.r1) | ((uintptr_t)p.r2)) & 15) == 0));
+    if (vec_ok) {
+        constexpr int NT = NWAVES * 64;
+        constexpr int VPR = BN / 4;                                       // float4 pieces per tile row
+        constexpr int PIECES = BM * VPR / NT;
+        static_assert((BM * VPR) % NT == 0, "row pieces must divide over the threads");
+        static_assert(BM * BN * 4 <= NSTAGE * STAGE, "the output tile must fit in the ring");
+        float* tile = (float*)ring;
+        __builtin_amdgcn_s_barrier();                                      // every wave has left the main loop: the ring is free
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    tile[(wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * BN + wn + jn * 32 + r] = acc[i][jn][e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int c4 = tid % VPR, row0 = tid / VPR;
+        int n = n0 + c4 * 4;
+        const bool n_ok = n < p.N;
+        n = n_ok ? n : p.N - 4;                                            // clamped: loads stay in bounds, the store is predicated
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *(const f32x4*)(p.bias + n);
+        constexpr int BATCH = PIECES < 4 ? PIECES : 4;                    // pieces in flight per thread: 4 x (tile + r1 + r2) = 48 registers
+#pragma unroll
+        for (int b0 = 0; b0 < PIECES; b0 += BATCH) {
+            f32x4 v[BATCH], a1[BATCH], a2[BATCH];
+            size_t orow[BATCH];
+            bool ok[BATCH];
+#pragma unroll
+            for (int it = 0; it < BATCH; ++it) {
+                const int row = row0 + (b0 + it) * (NT / VPR);
+                int m = m0 + row;
+                ok[it] = n_ok && m < p.M;
+                m = m < p.M ? m : p.M - 1;
+                orow[it] = (size_t)m;
+                v[it] = *(const f32x4*)(tile + row * BN + c4 * 4);
+                if (p.r1) a1[it] = *(const f32x4*)(p.r1 + (size_t)m * p.ldr + n);
+                if (p.r2) a2[it] = *(const f32x4*)(p.r2 + (size_t)m * p.ldr + n);
+            }
+#pragma unroll
+            for (int it = 0; it < BATCH; ++it) {
+                f32x4 x = v[it] + bv;
+                if (p.aux && ok[it]) *(f32x4*)(p.aux + orow[it] * p.ldo + n) = x;
+                if (p.act == MASTER_ACT_GELU) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[c] = gelu_erf(x[c]);
+                } else if (p.act == MASTER_ACT_RELU) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[c] = fmaxf(x[c], 0.0f);
+                }
+                if (p.mask_relu) {
+                    if (p.r2) x += a2[it];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[c] = a1[it][c] > 0.0f ? x[c] : 0.0f;
+                } else {
+                    if (p.r1) x *= a1[it];
+                    if (p.r2) x += a2[it];
+                }
+                if (ok[it]) *(f32x4*)(p.out + orow[it] * p.ldo + n) = x;
+            }
+            __builtin_amdgcn_sched_barrier(0);                             // keep the batches apart (max-ilp would hoist every load: 246 VGPRs)
+        }
+        return;
+    }
+    const int hw_out = p.Hout * p.Wout;
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int n = n0 + wn + jn * 32 + r;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m >= p.M) continue;
+                float v = acc[i][jn][e] + bv;
+                if (p.aux) p.aux[(size_t)m * p.ldo + n] = v;
+                if (p.act == MASTER_ACT_GELU) v = gelu_erf(v);
+                else if (p.act == MASTER_ACT_RELU) v = fmaxf(v, 0.0f);
+                if (p.mask_relu) {
+                    if (p.r2) v += p.r2[(size_t)m * p.ldr + n];
+                    if (!(p.r1[(size_t)m * p.ldr + n] > 0.0f)) v = 0.0f;
+                } else {
+                    if (p.r1) v *= p.r1[(size_t)m * p.ldr + n];
+                    if (p.r2) v += p.r2[(size_t)m * p.ldr + n];
+                }
+                if (CONV && p.out_nchw) {
+                    const int b = m / hw_out, pix = m - b * hw_out;
+                    p.out[((size_t)b * p.N + n) * hw_out + pix] = v;
+                } else {
+                    p.out[(size_t)m * p.ldo + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool CONV, int NSTAGE>
+int launch_dma(const GemmArgs& p, hipStream_t s) {
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    const int MT = (p.M + BM - 1) / BM, NTN = (p.N + BN - 1) / BN;
+    const int grid = ((MT + 7) / 8) * 8 * NTN;
+    const size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
+    static LdsLimit lds_limit;
+    lds_limit.ensure((const void*)gemm_f32_dma_kernel<BM, BN, WM, WN, CONV, NSTAGE>, (int)lds);
+    hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, WM, WN, CONV, NSTAGE>), dim3(grid), dim3(NT), lds, s, p);
+    return master_check_launch("gemm_f32_dma");
+}
+
 template <int BM, int BN, int WM, int WN, bool CONV>
 int launch(const GemmArgs& p, hipStream_t s) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
@@ -201,11 +460,36 @@ int launch(const GemmArgs& p, hipStream_t s) {
     return master_check_launch("gemm_f32");
 }
 
+// MASTER_GEMM_F32 = "reg": the register-staged r01 / r02 kernel; "dma" (default): the LDS-DMA ring.  MASTER_GEMM_F32_SMALL = 0 / 1:
+// 64x64 tiles (3-deep ring, 4-5 workgroups per CU) for problems with fewer than 256 tiles of 128x128 (train step: 8 192-token matrices).
+static int gemm_variant() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MASTER_GEMM_F32"); v = (e && e[0] == 'r') ? 0 : 1; }
+    return v;
+}
+static int gemm_small64() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MASTER_GEMM_F32_SMALL"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
 template <bool CONV>
 int dispatch(const GemmArgs& p, hipStream_t s) {
+    const bool few_tiles = p.N > 64 && (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) < 256;
+    const bool dma_ok = (p.K % BK) == 0 && (!CONV || (p.Cin % BK == 0 && p.Cin <= 512)) &&
+                        (((uintptr_t)p.a | (uintptr_t)p.w) & 15) == 0 && (CONV || (p.lda % 4) == 0);
+    if (gemm_variant() == 1 && dma_ok) {
+        if (few_tiles) {
+            if (gemm_small64()) return launch_dma<64, 64, 32, 32, CONV, 3>(p, s);
+            return launch_dma<64, 128, 32, 64, CONV, 2>(p, s);
+        }
+        if (p.N > 64) return launch_dma<128, 128, 64, 64, CONV, 2>(p, s);
+        if (p.N > 32) return launch_dma<128, 64, 64, 32, CONV, 2>(p, s);
+        return launch_dma<256, 32, 64, 32, CONV, 2>(p, s);
+    }
     // fewer than one 128x128 tile per CU (train step: 8 192-token matrices): 64-row tiles double the number of workgroups
     // (forcing 64-row tiles on the larger inference shapes was measured 5-10 % slower: profiles/r02_ops_fp32_gemm_{base,tile64}.txt)
-    if (p.N > 64 && (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) < 256) return launch<64, 128, 32, 64, CONV>(p, s);
+    if (few_tiles) return launch<64, 128, 32, 64, CONV>(p, s);
     if (p.N > 64) return launch<128, 128, 64, 64, CONV>(p, s);
     if (p.N > 32) return launch<128, 64, 64, 32, CONV>(p, s);
     return launch<256, 32, 64, 32, CONV>(p, s);

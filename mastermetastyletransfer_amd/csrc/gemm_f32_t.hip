@@ -198,7 +198,60 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_t_kernel(
         }
     }
 
-    // ---- epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ------------------------------------------------
+    // ---- epilogue --------------------------------------------------------------------------------------------------------------------
+    // r03: through the idle staging buffers as the [BM][BN] fp32 tile, then whole 16-byte row pieces per thread (coalesced float4
+    // loads of the GELU pre-activation, float4 stores); the element-wise form below (4-byte accesses behind per-element branches,
+    // serialised by hipcc into load -> wait -> store chains) stays for outputs it alone can address.
+    const bool vec_ok = (p.N & 3) == 0 && (p.ldo & 3) == 0 && (((uintptr_t)outp) & 15) == 0 &&
+                        (!p.aux || ((p.ld_aux & 3) == 0 && (((uintptr_t)p.aux) & 15) == 0));
+    if (vec_ok) {
+        constexpr int VPR = BN / 4;
+        constexpr int PIECES = BM * VPR / NT;
+        static_assert((BM * VPR) % NT == 0, "row pieces must divide over the threads");
+        static_assert(BM * BN <= 2 * (A_ELEMS + W_ELEMS), "the output tile must fit in the staging buffers");
+        float* tile = smem;
+        __syncthreads();                                                   // every wave has left the main loop
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    tile[(wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * BN + wn + jn * 32 + r] = acc[i][jn][e];
+        __syncthreads();
+        const int c4 = tid % VPR, row0 = tid / VPR;
+        int n = n0 + c4 * 4;
+        const bool n_ok = n < p.N;
+        n = n_ok ? n : p.N - 4;
+        constexpr int BATCH = PIECES < 4 ? PIECES : 4;
+#pragma unroll
+        for (int b0 = 0; b0 < PIECES; b0 += BATCH) {
+            f32x4 v[BATCH], ax[BATCH];
+            size_t orow[BATCH];
+            bool ok[BATCH];
+#pragma unroll
+            for (int it = 0; it < BATCH; ++it) {
+                const int row = row0 + (b0 + it) * (NT / VPR);
+                int m = m0 + row;
+                ok[it] = n_ok && m < p.M;
+                m = m < p.M ? m : p.M - 1;
+                orow[it] = (size_t)m;
+                v[it] = *(const f32x4*)(tile + row * BN + c4 * 4);
+                if (p.aux) ax[it] = *(const f32x4*)(p.aux + (size_t)m * p.ld_aux + n);
+            }
+#pragma unroll
+            for (int it = 0; it < BATCH; ++it) {
+                f32x4 x = v[it];
+                if (p.aux) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[c] *= gelu_grad(ax[it][c]);
+                }
+                if (ok[it]) *(f32x4*)(outp + orow[it] * p.ldo + n) = x;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
         const int n = n0 + wn + jn * 32 + r;

@@ -225,8 +225,16 @@ class ShiftedWindowAttention(_WindowAttentionBase):
         if len(vs) > 2:
             raise NotImplementedError("at most two value streams per attention call")
         kp, vp = self._row("k", self.Wk.bias), self._row("v", self.Wv.bias)
-        cores = self._core(q, k, vs, kp, [vp, vp], B, H, W)
         pw, pb = self._w("proj", self.proj.weight), self._b("proj", self.proj.bias)
+        plan = window_plan(H, W, self.window_size, self.shift_size, q.device)
+        if len(vs) == 1 and len({None if r_ is None else id(r_) for r_ in residuals}) == 1 and \
+                ops.window_attn_proj_supported(q, self.num_heads, plan.nW):
+            # one value stream, one residual (the self-attention calls, and Scale is Shift in the first layer): attention core,
+            # proj and the residual add in ONE launch
+            o = ops.window_attn_proj(q, k, vs[0], kp, vp, self._bias64(), plan.src, plan.region, pw, pb, residuals[0], B, H * W,
+                                     self.num_heads, plan.nW, plan.N, HEAD_DIM ** -0.5)
+            return [o for _ in residuals]
+        cores = self._core(q, k, vs, kp, [vp, vp], B, H, W)
         outs, done = [], {}
         for i, res in zip(uniq, residuals):
             key = (i, None if res is None else id(res))
@@ -716,6 +724,11 @@ class _SwinAttention(_WindowAttentionBase):
         qkv = ops.linear_ln(x, self._b("n1w", norm.weight), self._b("n1b", norm.bias), self._w("qkv", self.qkv.weight),
                             self._b("qkv", self.qkv.bias), eps=norm.eps)
         rows = self._derived("rows", [self.qkv.bias], lambda: ops.convert(self.qkv.bias.detach().contiguous(), self.compute_dtype))
+        plan = window_plan(H, W, self.window_size, self.shift_size, x.device)
+        if ops.window_attn_proj_supported(qkv, self.num_heads, plan.nW):
+            return ops.window_attn_proj(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], rows[C:2 * C], rows[2 * C:], self._bias64(), plan.src,
+                                        plan.region, self._w("proj", self.proj.weight), self._b("proj", self.proj.bias), residual, B, H * W,
+                                        self.num_heads, plan.nW, plan.N, HEAD_DIM ** -0.5)
         o = self._core(qkv[:, :C], qkv[:, C:2 * C], [qkv[:, 2 * C:]], rows[C:2 * C], [rows[2 * C:], None], B, H, W)[0]
         return ops.linear(o, self._w("proj", self.proj.weight), self._b("proj", self.proj.bias), r2=residual)
 

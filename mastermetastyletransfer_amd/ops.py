@@ -23,7 +23,7 @@ K_FAMILIES = ("linear", "conv3x3", "window_attn", "layernorm", "instnorm", "patc
 EXPORTS = (
     "master_version", "master_last_error_string", "master_linear_fwd", "master_conv3x3_reflect_fwd",
     "master_window_attn_fwd", "master_layernorm_fwd", "master_instnorm_fwd", "master_patch_embed_fwd",
-    "master_patch_merge_ln_fwd", "master_patch_merge_linear_fwd", "master_resize_plan", "master_preprocess_fwd", "master_postprocess_fwd", "master_image_to_nhwc_fwd", "master_conv3x3_zero_fwd", "master_maxpool2x2_fwd", "master_channel_stats_fwd", "master_stats_slices", "master_instnorm_distance_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_linear_ln_fwd", "master_attn_block_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
+    "master_patch_merge_ln_fwd", "master_patch_merge_linear_fwd", "master_resize_plan", "master_preprocess_fwd", "master_postprocess_fwd", "master_image_to_nhwc_fwd", "master_conv3x3_zero_fwd", "master_maxpool2x2_fwd", "master_channel_stats_fwd", "master_stats_slices", "master_instnorm_distance_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_linear_ln_fwd", "master_attn_block_fwd", "master_window_attn_proj_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
     # train step
     "master_linear_act_fwd", "master_linear_dgrad", "master_linear_wgrad", "master_gemm_workspace_floats", "master_colsum",
     "master_colsum_workspace_floats", "master_reduce_slabs", "master_layernorm_bwd", "master_layernorm_bwd_workspace_floats",
@@ -99,6 +99,7 @@ def load_library() -> ctypes.CDLL:
     lib.master_linear_ln_fwd.argtypes = [vp] * 8 + [ci] * 6 + [cf, ci, vp]
     lib.master_attn_block_fwd.argtypes = [vp] * 11 + [ci] * 6 + [cf, cf, ci, vp]
     lib.master_decoder_tail_fwd.argtypes = [vp] * 6 + [ci] * 4 + [vp]
+    lib.master_window_attn_proj_fwd.argtypes = [vp] * 3 + [ci] * 3 + [vp] * 2 + [ci] * 2 + [vp] * 6 + [ci, vp, ci] + [ci] * 5 + [cf, ci, vp]
     lib.master_prof_read.argtypes = [ci, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]
     # ---- train step ----
     cz, cll = ctypes.c_size_t, ctypes.c_longlong
@@ -344,6 +345,32 @@ def window_attn(q, k, v0, v1, k_pad, v0_pad, v1_pad, bias64, src, region, B: int
         kbs, vbs, _p(bias64), _p(src), _p(region), _p(out0), _p(out1), C, B, T, heads, nW, N, float(scale), _dt(q),
         _stream()), "master_window_attn_fwd")
     return out0, out1
+
+
+def window_attn_proj_supported(q: torch.Tensor, heads: int, nW: int) -> bool:
+    """the fused attention + proj + residual launch: bf16, 8 heads (C = 256), tables of the geometry next to four 32-KB tiles in LDS"""
+    return q.dtype == torch.bfloat16 and heads == 8 and 4 * 32768 + nW * 64 * 5 <= 160 * 1024 and os.environ.get("MASTER_ATTN_PROJ", "1") != "0"
+
+
+@_on_device
+def window_attn_proj(q, k, v, k_pad, v_pad, bias64, src, region, wproj, bproj, res, B: int, T: int, heads: int, nW: int, N: int,
+                     scale: float) -> torch.Tensor:
+    """res + proj(window_attention(q, k, v)) in one launch (bf16, 8 heads).  q/k/v: [B*T, 256] views (row stride free)."""
+    _dev(q, k, v, wproj)
+    C = heads * 32
+    out = torch.empty((B * T, C), dtype=q.dtype, device=q.device)
+    assert wproj.shape == (C, C) and wproj.is_contiguous() and bproj.dtype == torch.float32
+    assert res is None or (res.shape == (B * T, C) and res.stride(1) == 1 and res.dtype == q.dtype)
+    kbs = k_pad.stride(0) if k_pad.dim() == 2 else 0
+    vbs = v_pad.stride(0) if v_pad.dim() == 2 else 0
+    if _COUNT_ON:
+        _count("window_attn", flops=2.0 * B * nW * heads * N * N * 32 * 2 + 2.0 * B * T * C * C, qk_flops=2.0 * B * nW * heads * N * N * 32,
+               bytes=q.element_size() * (B * T * C * (4 + (res is not None)) + C * C))
+    _check(load_library().master_window_attn_proj_fwd(
+        _p(q), _p(k), _p(v), q.stride(0), k.stride(0), v.stride(0), _p(k_pad), _p(v_pad), kbs, vbs, _p(bias64), _p(src), _p(region),
+        _p(wproj), _p(bproj), _p(res), res.stride(0) if res is not None else 0, _p(out), out.stride(0), B, T, heads, nW, N,
+        float(scale), _dt(q), _stream()), "master_window_attn_proj_fwd")
+    return out
 
 
 @_on_device
