@@ -228,7 +228,7 @@ class ShiftedWindowAttention(_WindowAttentionBase):
         pw, pb = self._w("proj", self.proj.weight), self._b("proj", self.proj.bias)
         plan = window_plan(H, W, self.window_size, self.shift_size, q.device)
         if len(vs) == 1 and len({None if r_ is None else id(r_) for r_ in residuals}) == 1 and \
-                ops.window_attn_proj_supported(q, self.num_heads, plan.nW):
+                ops.window_attn_proj_supported(q, self.num_heads, plan.nW, plan.N):
             # one value stream, one residual (the self-attention calls, and Scale is Shift in the first layer): attention core,
             # proj and the residual add in ONE launch
             o = ops.window_attn_proj(q, k, vs[0], kp, vp, self._bias64(), plan.src, plan.region, pw, pb, residuals[0], B, H * W,
@@ -725,7 +725,7 @@ class _SwinAttention(_WindowAttentionBase):
                             self._b("qkv", self.qkv.bias), eps=norm.eps)
         rows = self._derived("rows", [self.qkv.bias], lambda: ops.convert(self.qkv.bias.detach().contiguous(), self.compute_dtype))
         plan = window_plan(H, W, self.window_size, self.shift_size, x.device)
-        if ops.window_attn_proj_supported(qkv, self.num_heads, plan.nW):
+        if ops.window_attn_proj_supported(qkv, self.num_heads, plan.nW, plan.N):
             return ops.window_attn_proj(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], rows[C:2 * C], rows[2 * C:], self._bias64(), plan.src,
                                         plan.region, self._w("proj", self.proj.weight), self._b("proj", self.proj.bias), residual, B, H * W,
                                         self.num_heads, plan.nW, plan.N, HEAD_DIM ** -0.5)

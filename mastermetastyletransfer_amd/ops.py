@@ -347,9 +347,12 @@ def window_attn(q, k, v0, v1, k_pad, v0_pad, v1_pad, bias64, src, region, B: int
     return out0, out1
 
 
-def window_attn_proj_supported(q: torch.Tensor, heads: int, nW: int) -> bool:
-    """the fused attention + proj + residual launch: bf16, 8 heads (C = 256), tables of the geometry next to four 32-KB tiles in LDS"""
-    return q.dtype == torch.bfloat16 and heads == 8 and 4 * 32768 + nW * 64 * 5 <= 160 * 1024 and os.environ.get("MASTER_ATTN_PROJ", "1") != "0"
+def window_attn_proj_supported(q: torch.Tensor, heads: int, nW: int, N: int = 49) -> bool:
+    """the fused attention + proj + residual launch: bf16, 8 heads (C = 256), windows of up to 49 tokens, tables of the geometry next
+    to three 32-KB tiles and the 50-KB output stage in LDS (up to 45 windows per image: 32x32 maps have 25).  Measured no faster than
+    attention + Linear as two launches (window_attn_proj_bf16.hip, "MEASURED OUTCOME"), so it is opt-in: MASTER_ATTN_PROJ=1."""
+    return (q.dtype == torch.bfloat16 and heads == 8 and N <= 49 and 3 * 32768 + 51200 + nW * 64 * 5 <= 160 * 1024
+            and os.environ.get("MASTER_ATTN_PROJ", "0") == "1")
 
 
 @_on_device
