@@ -13,6 +13,7 @@
 // over blockIdx.y: every split writes its partial tile to a workspace slab and reduce_slabs_kernel (train_misc.hip) adds the slabs in a fixed order
 // (deterministic, no atomics).
 #include "common.h"
+#include <stdlib.h>
 
 int reduce_slabs_launch(const float* part, float* out, size_t n, size_t slab, int splits, hipStream_t s);   // train_misc.hip
 
@@ -315,7 +316,13 @@ int gemm_f32_dgrad(const float* g, const float* w, float* out, const float* aux,
     TArgs p{g, w, out, M, Kc, Nc, ldg, Kc, ldo, 0, 0, aux, ld_aux, 0, 0, 0, 0, 0, 0, 0};
     if (Kc > 64) {
         // fewer than one 128x128 tile per CU (the StyleTransformer's 8 192-token matrices): 64-row tiles double the workgroups
-        if ((long long)((M + 127) / 128) * ((Kc + 127) / 128) < 256) return launch_t<64, 128, 32, 64, false, false>(p, out, nullptr, 0, 1, s);
+        // (r03: 64x64 tiles, four workgroups per CU, for the 8 192-token matrices: 512+ workgroups instead of 256 one-per-CU ones)
+        if ((long long)((M + 127) / 128) * ((Kc + 127) / 128) < 256) {
+            static int small64 = -1;
+            if (small64 < 0) { const char* e = getenv("MASTER_GEMM_F32_SMALL"); small64 = e ? atoi(e) : 1; }
+            if (small64) return launch_t<64, 64, 32, 32, false, false>(p, out, nullptr, 0, 1, s);
+            return launch_t<64, 128, 32, 64, false, false>(p, out, nullptr, 0, 1, s);
+        }
         return launch_t<128, 128, 64, 64, false, false>(p, out, nullptr, 0, 1, s);
     }
     return launch_t<128, 64, 64, 32, false, false>(p, out, nullptr, 0, 1, s);

@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 //      gradients of those copies.  With N = T + n_pad:
 //        dx_t  = rstd * (g_t - S1/N - y_t * S2/N),          S1 = sum g (all N),  S2 = sum g*y (all N)
 //        dpad  = rstd * (g_pad - n_pad * S1/N - n_pad * y_pad * S2/N)         (per image; the caller adds the images up) ----------------------
+template <int REG>
 __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ pad_in,
                                                            const float* __restrict__ g_pad, float* __restrict__ dx, float* __restrict__ dpad, int Tn,
                                                            int C, int n_pad, float eps) {
@@ -108,11 +109,33 @@ __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restri
         __syncthreads();
         return s;
     };
+    // REG > 0 (maps of up to 32 REG tokens: the 32x32 maps of the train step): x and g are read ONCE into registers (2 REG float4
+    // per thread) instead of four and two times from memory - with 64 workgroups on 256 CUs the kernel is a chain of latency-bound
+    // passes, so the passes that disappear are its time (r03: 40.6 -> see profiles/r03_train_trace_by_shape.txt).
+    f32x4 xs[REG > 0 ? REG : 1], gs[REG > 0 ? REG : 1];
+    if (REG > 0) {
+#pragma unroll
+        for (int i = 0; i < REG; ++i) {
+            const int t = tg + 32 * i;
+            xs[i] = gs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t < Tn) { xs[i] = *(const f32x4*)(x + base + (size_t)t * C); gs[i] = *(const f32x4*)(g + base + (size_t)t * C); }
+        }
+    }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int t = tg; t < Tn; t += 32) acc += *(const f32x4*)(x + base + (size_t)t * C);
+    if (REG > 0) {
+#pragma unroll
+        for (int i = 0; i < REG; ++i) acc += xs[i];                       // rows past Tn hold zeros
+    } else {
+        for (int t = tg; t < Tn; t += 32) acc += *(const f32x4*)(x + base + (size_t)t * C);
+    }
     f32x4 mean = (block_sum(acc) + pr * np) / cnt;
     acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int t = tg; t < Tn; t += 32) { const f32x4 d = *(const f32x4*)(x + base + (size_t)t * C) - mean; acc += d * d; }
+    if (REG > 0) {
+#pragma unroll
+        for (int i = 0; i < REG; ++i) if (tg + 32 * i < Tn) { const f32x4 d = xs[i] - mean; acc += d * d; }
+    } else {
+        for (int t = tg; t < Tn; t += 32) { const f32x4 d = *(const f32x4*)(x + base + (size_t)t * C) - mean; acc += d * d; }
+    }
     const f32x4 dp = pr - mean;
     const f32x4 var = (block_sum(acc) + dp * dp * np) / cnt;
     f32x4 rstd;
@@ -120,16 +143,29 @@ __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restri
     for (int e = 0; e < 4; ++e) rstd[e] = rsqrtf(var[e] + eps);
     const f32x4 ypad = dp * rstd;
     f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
-    for (int t = tg; t < Tn; t += 32) {
-        const f32x4 gv = *(const f32x4*)(g + base + (size_t)t * C);
-        const f32x4 y = (*(const f32x4*)(x + base + (size_t)t * C) - mean) * rstd;
-        a1 += gv; a2 += gv * y;
+    if (REG > 0) {
+#pragma unroll
+        for (int i = 0; i < REG; ++i) if (tg + 32 * i < Tn) { const f32x4 y = (xs[i] - mean) * rstd; a1 += gs[i]; a2 += gs[i] * y; }
+    } else {
+        for (int t = tg; t < Tn; t += 32) {
+            const f32x4 gv = *(const f32x4*)(g + base + (size_t)t * C);
+            const f32x4 y = (*(const f32x4*)(x + base + (size_t)t * C) - mean) * rstd;
+            a1 += gv; a2 += gv * y;
+        }
     }
     const f32x4 s1 = (block_sum(a1) + gp) / cnt, s2 = (block_sum(a2) + gp * ypad) / cnt;
-    for (int t = tg; t < Tn; t += 32) {
-        const f32x4 gv = *(const f32x4*)(g + base + (size_t)t * C);
-        const f32x4 y = (*(const f32x4*)(x + base + (size_t)t * C) - mean) * rstd;
-        *(f32x4*)(dx + base + (size_t)t * C) = rstd * (gv - s1 - y * s2);
+    if (REG > 0) {
+#pragma unroll
+        for (int i = 0; i < REG; ++i) {
+            const int t = tg + 32 * i;
+            if (t < Tn) { const f32x4 y = (xs[i] - mean) * rstd; *(f32x4*)(dx + base + (size_t)t * C) = rstd * (gs[i] - s1 - y * s2); }
+        }
+    } else {
+        for (int t = tg; t < Tn; t += 32) {
+            const f32x4 gv = *(const f32x4*)(g + base + (size_t)t * C);
+            const f32x4 y = (*(const f32x4*)(x + base + (size_t)t * C) - mean) * rstd;
+            *(f32x4*)(dx + base + (size_t)t * C) = rstd * (gv - s1 - y * s2);
+        }
     }
     if (n_pad > 0 && dpad && tg == 0)
         *(f32x4*)(dpad + (size_t)b * C + c0 + cq * 4) = rstd * (gp - s1 * np - ypad * s2 * np);
@@ -152,6 +188,7 @@ int layernorm_bwd_launch(const float* x, const float* gamma, const float* g, flo
 int instnorm_bwd_launch(const float* x, const float* g, const float* pad_in, const float* g_pad, float* dx, float* dpad, int B, int Tn, int C,
                         int n_pad, float eps, hipStream_t s) {
     if (C % 32 != 0) { master_set_error("instnorm_bwd: C %% 32 == 0 (C=%d)", C); return MASTER_ERR_INVALID; }
-    hipLaunchKernelGGL(instnorm_bwd_kernel, dim3(B * (C / 32)), dim3(256), 0, s, x, g, pad_in, g_pad, dx, dpad, Tn, C, n_pad, eps);
+    if (Tn <= 32 * 32) hipLaunchKernelGGL(instnorm_bwd_kernel<32>, dim3(B * (C / 32)), dim3(256), 0, s, x, g, pad_in, g_pad, dx, dpad, Tn, C, n_pad, eps);
+    else hipLaunchKernelGGL(instnorm_bwd_kernel<0>, dim3(B * (C / 32)), dim3(256), 0, s, x, g, pad_in, g_pad, dx, dpad, Tn, C, n_pad, eps);
     return master_check_launch("instnorm_bwd");
 }

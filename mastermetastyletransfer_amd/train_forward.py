@@ -74,8 +74,32 @@ def _ones(B: int, device) -> Tensor:
     return _ONES[key]
 
 
+# Tensors derived from parameters inside ONE StyleTransformer call (k layers share their weights, :1239: the shared encoder block runs
+# 2k times, the decoder's two attention modules k times each): the [heads,64,64] bias tiles and the Wq|Wk|Wv concatenations are built
+# once per call and reused as the same autograd node - its backward (index scatter into the table, splits of the fused weight
+# gradient) then runs once per module instead of once per use, and autograd sums the uses' gradients in between.
+_MEMO: Optional[dict] = None
+
+
+def _memo(key, build: Callable[[], Tensor]) -> Tensor:
+    if _MEMO is None:
+        return build()
+    hit = _MEMO.get(key)
+    if hit is None:
+        hit = _MEMO[key] = build()
+    return hit
+
+
+def _cat(tag: str, owner, *params: Tensor) -> Tensor:
+    return _memo((tag, id(owner)), lambda: torch.cat(list(params), dim=0))
+
+
 def _bias64(attn) -> Tensor:
     """differentiable [heads,64,64] bias tile from the relative-position table (style_transformer.py:21-28); key slots >= N = -1e30"""
+    return _memo(("bias64", id(attn)), lambda: _bias64_build(attn))
+
+
+def _bias64_build(attn) -> Tensor:
     N = attn.window_size[0] * attn.window_size[1]
     t = attn.relative_position_bias_table
     b = t[attn.relative_position_index].view(N, N, -1).permute(2, 0, 1)                  # [heads,N,N]
@@ -123,15 +147,15 @@ def attention(attn, xq: Tensor, xk: Tensor, xvs: Sequence[Tensor], B: int, H: in
         raise NotImplementedError("at most two value streams per attention call")
     bias64 = _bias64(attn)
     if xq is xk and len(uniq_v) == 1 and uniq_v[0] is xq:
-        w = torch.cat([attn.Wq.weight, attn.Wk.weight, attn.Wv.weight], dim=0)
-        b = torch.cat([attn.Wq.bias, attn.Wk.bias, attn.Wv.bias], dim=0)
+        w = _cat("wqkv", attn, attn.Wq.weight, attn.Wk.weight, attn.Wv.weight)
+        b = _cat("bqkv", attn, attn.Wq.bias, attn.Wk.bias, attn.Wv.bias)
         qkv = LinearFn.apply(xq, w, b)
         o0, _ = WindowAttnFn.apply(qkv, qkv, qkv, None, attn.Wk.bias, attn.Wv.bias, None, bias64, (0, C, 2 * C, 0), plan, B, T,
                                    attn.num_heads, scale)
         cores = [o0]
     else:
         if xq is xk:
-            qk = LinearFn.apply(xq, torch.cat([attn.Wq.weight, attn.Wk.weight], dim=0), torch.cat([attn.Wq.bias, attn.Wk.bias], dim=0))
+            qk = LinearFn.apply(xq, _cat("wqk", attn, attn.Wq.weight, attn.Wk.weight), _cat("bqk", attn, attn.Wq.bias, attn.Wk.bias))
             tq, tk, oq, ok = qk, qk, 0, C
         else:
             tq, tk, oq, ok = LinearFn.apply(xq, attn.Wq.weight, attn.Wq.bias), LinearFn.apply(xk, attn.Wk.weight, attn.Wk.bias), 0, 0
@@ -262,11 +286,16 @@ def style_decoder(dec, fcs: Tensor, key: Tensor, scale: Tensor, shift: Tensor, B
 
 
 def style_transformer(st, fc: Tensor, fs: Tensor, k: int, B, H, W, sd: StochasticDepthMasks) -> Tensor:
-    scale = shift = fs                                                                                # :1235-1236
-    for _ in range(k):
-        fs, scale, shift = style_encoder(st.encoder, fs, scale, shift, B, H, W, sd)
-        fc = style_decoder(st.decoder, fc, fs, scale, shift, B, H, W, sd)
-    return fc
+    global _MEMO
+    outer, _MEMO = _MEMO, {}
+    try:
+        scale = shift = fs                                                                            # :1235-1236
+        for _ in range(k):
+            fs, scale, shift = style_encoder(st.encoder, fs, scale, shift, B, H, W, sd)
+            fc = style_decoder(st.decoder, fc, fs, scale, shift, B, H, W, sd)
+        return fc
+    finally:
+        _MEMO = outer
 
 
 def image_decoder(dec, x_nhwc: Tensor) -> Tensor:
