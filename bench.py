@@ -99,12 +99,18 @@ def main():
     if not args.eager:
         try:
             from mastermetastyletransfer_amd import GraphedStylizer
-            graphed = GraphedStylizer(model, B, S, S, k)
+            # N > 1: two captures with alternating static output buffers - the asynchronous all-gather of step i reads buffer i % 2 in
+            # place while step i + 1 replays into the other one (no per-step clone); before a buffer is written again the stream waits
+            # for the gather that still reads it
+            graphed = GraphedStylizer(model, B, S, S, k, copies=2 if world > 1 else 1)
             graphed.content.copy_(content); graphed.style.copy_(style)
-            if world > 1:
-                forward = lambda: (graphed.graph.replay(), graphed.out.clone())[1]     # private copy: the async gather of step i reads it while step i+1 replays
-            else:
-                forward = lambda: (graphed.graph.replay(), graphed.out)[1]
+            counter = [0]
+
+            def forward():
+                i = counter[0]; counter[0] += 1
+                if world > 1:
+                    gather.release_source(graphed.outs[i % 2])
+                return graphed.replay(i)
             launch_mode = "hipGraph replay"
         except Exception as e:                      # a capture problem must not cost the scaling run: fall back to kernel-by-kernel enqueue
             print(f"[rank {rank}] hipGraph capture failed ({e!r}); running eager", file=sys.stderr, flush=True)
@@ -418,11 +424,34 @@ def train_bench(device, steps=10, warmup=3, B=8, S=256, max_layers=4, roofline=T
                  "conv_wgrad": "gemm_f32_t_kernel<.., GATHER> (decoder weight gradients)", "linear": "gemm_f32_kernel (projections, MLPs)",
                  "linear_bwd": "gemm_f32_t_kernel (Linear data / weight gradients)"}
         res["roofline"] = {"kernel": names.get(dom, dom), "family": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS["fp32"],
-                           "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS["fp32"], 4), "traffic": None, "launches_per_step": n,
+                           "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS["fp32"], 4), "traffic": train_traffic(dom)[0],
+                           "traffic_source": train_traffic(dom)[1], "launches_per_step": n,
                            "avg_launch_us": round(ms / n * 1e3, 2), "alg_flop_per_launch": counts[dom]["flops"] / n,
                            "alg_bytes_per_launch": counts[dom].get("bytes", 0.0) / n,
                            "share_of_step_kernel_time": round(ms / sum(v[1] for v in prof.values()), 3)}
     return res
+
+
+TRAIN_PMC_KERNELS = {"conv3x3": ("gemm_f32_dma_kernel<128, 128, 64, 64, true", "gemm_f32_dma_kernel<128, 64, 64, 32, true", "gemm_f32_dma_kernel<256, 32, 64, 32, true",
+                                 "gemm_f32_dma_kernel<64, 64, 32, 32, true", "gemm_f32_kernel<"),
+                     "conv_dgrad": ("gemm_f32_dma_kernel<128, 128, 64, 64, true", "gemm_f32_dma_kernel<128, 64, 64, 32, true", "gemm_f32_dma_kernel<256, 32, 64, 32, true"),
+                     "linear": ("gemm_f32_dma_kernel<128, 128, 64, 64, false", "gemm_f32_dma_kernel<64, 64, 32, 32, false"),
+                     "linear_bwd": ("gemm_f32_t_kernel",), "conv_wgrad": ("gemm_f32_t_kernel",)}
+
+
+def train_traffic(family):
+    """HBM bytes per launch of the kernels that serve a train-step family, from the committed PMC passes of `bench.py --mode train`
+    (profiles/rNN_train_pmc_traffic.json; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE).  The implicit-GEMM convolution kernel serves
+    the forward convolutions AND their data gradients under one name, so the figure is the average over both."""
+    path = latest_profile("train_pmc_traffic.json")
+    if path is None:
+        return None, None
+    prof = json.load(open(path))
+    tot_b = tot_n = 0.0
+    for name, v in prof.items():
+        if any(name.startswith(pfx) for pfx in TRAIN_PMC_KERNELS.get(family, ())):
+            tot_b += v["hbm_bytes_per_launch"] * v["launches"]; tot_n += v["launches"]
+    return (round(tot_b / tot_n) if tot_n else None), os.path.relpath(path, ROOT) + " (average over the launches of the family's kernels; forward convolutions and conv data gradients share one kernel)"
 
 
 def torch_launches_from_trace():

@@ -89,7 +89,12 @@ def all_gather_images(local: torch.Tensor, batch: int, rank: int, world: int) ->
 class AsyncImageGather:
     """All-gather of the stylized images that overlaps with the next forward: the collective is enqueued
     asynchronously (RCCL runs it on its own stream) and at most `depth` gathers are in flight; wait() drains them.
-    Results are identical to all_gather_images; only the point where the host/stream waits moves."""
+    Results are identical to all_gather_images; only the point where the host/stream waits moves.
+
+    The collective reads `local` IN PLACE (no copy is made of a contiguous shard).  A producer that reuses its output buffers - two
+    captured graphs writing alternating static buffers, graph.GraphedStylizer(copies=2) - calls release_source(buffer) before it
+    overwrites one: the stream then waits for the gather that still reads it.  Destination buffers come from a pool of depth + 1 and
+    are recycled after `depth` further submits; pass `out=` to own the destination instead."""
 
     def __init__(self, batch: int, rank: int, world: int, depth: int = 2):
         if batch % max(world, 1) != 0:
@@ -98,28 +103,42 @@ class AsyncImageGather:
         self.pending = []          # (work, output buffer, local shard kept alive)
         self.buffers = []
 
-    def submit(self, local: torch.Tensor) -> torch.Tensor:
+    def submit(self, local: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         if self.world == 1:
             return local
         while len(self.pending) >= self.depth:
             self._retire()
         local = local.contiguous()
-        out = self.buffers.pop() if self.buffers else local.new_empty((self.batch,) + tuple(local.shape[1:]))
+        pooled = out is None
+        if pooled:
+            out = self.buffers.pop() if self.buffers else local.new_empty((self.batch,) + tuple(local.shape[1:]))
         work = all_gather_tensor(out, local, async_op=True)
-        self.pending.append((work, out, local))
+        self.pending.append((work, out, local, pooled))
         return out                 # valid after wait() (or after `depth` further submits)
 
-    def _retire(self):
-        work, out, _ = self.pending.pop(0)
+    def _retire(self, i: int = 0):
+        work, out, _, pooled = self.pending.pop(i)
         work.wait()
-        self.buffers.append(out)   # recycled: callers that keep results must copy them before `depth` more submits
+        if pooled:
+            self.buffers.append(out)   # recycled: callers that keep pooled results must copy them before `depth` more submits
+
+    def release_source(self, buf: torch.Tensor):
+        """make the current stream wait for every pending gather that still reads `buf` (call before overwriting it)"""
+        i = 0
+        while i < len(self.pending):
+            if self.pending[i][2].data_ptr() == buf.data_ptr():
+                self._retire(i)
+            else:
+                i += 1
 
     def wait(self):
-        last = None
+        last, last_pooled = None, False
         while self.pending:
-            work, out, _ = self.pending.pop(0)
+            work, out, _, pooled = self.pending.pop(0)
             work.wait()
-            last = out
+            if last is not None and last_pooled:
+                self.buffers.append(last)
+            last, last_pooled = out, pooled
         return last
 
 

@@ -19,9 +19,15 @@ class GraphedStylizer:
     """stylize = GraphedStylizer(model, batch, H, W, k); out = stylize(content, style)
 
     `out` is the graph's static output buffer: it is overwritten by the next call (pass copy=True to get a private tensor).
+
+    copies > 1 captures the same forward that many times, each capture with its own static OUTPUT buffer (the inputs are shared):
+    `replay(i)` runs capture i % copies and returns outs[i % copies].  A consumer that reads step i's output asynchronously - the
+    all-gather of a multi-GPU run (distributed.AsyncImageGather) - then reads it in place while step i + 1 writes the other buffer:
+    no per-step clone.  The caller must make the stream wait for that consumer before replaying into the same buffer again
+    (AsyncImageGather.release_source).
     """
 
-    def __init__(self, model, batch: int, height: int, width: int, transformer_layer_count: int = 1, warmup: int = 2):
+    def __init__(self, model, batch: int, height: int, width: int, transformer_layer_count: int = 1, warmup: int = 2, copies: int = 1):
         p = next(model.parameters())
         if p.device.type != "cuda":
             raise ValueError("GraphedStylizer needs the model on a GPU (there is no CPU path)")
@@ -35,11 +41,21 @@ class GraphedStylizer:
                 model(self.content, self.style, self.k)
         torch.cuda.current_stream(p.device).wait_stream(side)
         torch.cuda.synchronize(p.device)
-        self.graph = torch.cuda.CUDAGraph()
-        # thread_local: only this thread's calls are checked during capture (a process-group watchdog thread of a multi-rank run may
-        # query events concurrently)
-        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.out = model(self.content, self.style, self.k)
+        self.graphs, self.outs = [], []
+        for _ in range(max(1, int(copies))):
+            g = torch.cuda.CUDAGraph()
+            # thread_local: only this thread's calls are checked during capture (a process-group watchdog thread of a multi-rank run
+            # may query events concurrently)
+            with torch.no_grad(), torch.cuda.graph(g, capture_error_mode="thread_local"):
+                out = model(self.content, self.style, self.k)
+            self.graphs.append(g); self.outs.append(out)
+        self.graph, self.out = self.graphs[0], self.outs[0]
+
+    def replay(self, i: int = 0) -> Tensor:
+        """run capture i % copies on the inputs currently in self.content / self.style; returns that capture's static output buffer"""
+        j = i % len(self.graphs)
+        self.graphs[j].replay()
+        return self.outs[j]
 
     def __call__(self, content_image: Tensor, style_image: Tensor, copy: bool = False) -> Tensor:
         if content_image.shape != self.content.shape or style_image.shape != self.style.shape:

@@ -1,16 +1,41 @@
 #!/bin/bash
 # Collect the round's profile set on the GPU box (run through gpurun from the repo root):
-#   kernel trace + stats of the bench command, FETCH_SIZE / WRITE_SIZE / MFMA-busy PMC passes (separate runs, counters only
-#   with --kernel-trace), the full bench line.  Outputs land in gpurun_out/<tag>/; copy what should be judged into profiles/.
+#   bf16 headline:  kernel trace + stats of the bench command, FETCH_SIZE / WRITE_SIZE / MFMA-busy PMC passes (separate runs, counters
+#                   only with --kernel-trace), the full bench line;
+#   train step:     the same four passes of `bench.py --mode train` (BASELINE config 4);
+#   fp32 mode:      kernel trace of `bench.py --dtype fp32`.
+# Outputs land in gpurun_out/<tag>/ with the names profiles/ uses (r03_...); copy what should be judged into profiles/.
+# usage: profiles/collect.sh [tag=r03] [what=all|bf16|train|fp32]
 set -e
-tag=${1:-v5}; out=gpurun_out/$tag; mkdir -p $out
+tag=${1:-r03}; what=${2:-all}; out=gpurun_out/$tag; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+if [ $what = all ] || [ $what = bf16 ]; then
 rocprofv3 --kernel-trace --stats -d $out/trace -o t --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-extras > $out/trace.log 2>&1
-python profiles/trace_by_shape.py $out/trace/t_kernel_trace.csv 23 > $out/trace_by_shape.txt
+python profiles/trace_by_shape.py $out/trace/t_kernel_trace.csv 23 > $out/${tag}_bf16_bs32_trace_by_shape.txt
+cp $out/trace/t_kernel_stats.csv $out/${tag}_bf16_bs32_kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o f --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-extras > $out/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o w --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-extras > $out/write.log 2>&1
-python profiles/pmc_traffic.py $out/fetch/f_counter_collection.csv $out/write/w_counter_collection.csv $out/pmc_traffic.json > $out/pmc_traffic.txt
+python profiles/pmc_traffic.py $out/fetch/f_counter_collection.csv $out/write/w_counter_collection.csv $out/${tag}_bf16_bs32_pmc_traffic.json > $out/${tag}_bf16_bs32_pmc_traffic.txt
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out/mfma -o m --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-extras > $out/mfma.log 2>&1
-python profiles/pmc_mfma_util.py $out/mfma/m_counter_collection.csv $out/pmc_mfma_util.json > $out/pmc_mfma_util.txt
-python bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err
-tail -c 600 $out/bench.json
+python profiles/pmc_mfma_util.py $out/mfma/m_counter_collection.csv $out/${tag}_bf16_bs32_pmc_mfma_util.json > $out/${tag}_bf16_bs32_pmc_mfma_util.txt
+echo "bf16 passes done"
+fi
+if [ $what = all ] || [ $what = train ]; then
+rocprofv3 --kernel-trace --stats -d $out/ttrace -o t --output-format csv -- python3 bench.py --mode train --steps 6 --warmup 2 --no-extras > $out/ttrace.log 2>&1
+python profiles/trace_by_shape.py $out/ttrace/t_kernel_trace.csv 8 > $out/${tag}_train_trace_by_shape.txt
+cp $out/ttrace/t_kernel_stats.csv $out/${tag}_train_kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/tfetch -o f --output-format csv -- python3 bench.py --mode train --steps 2 --warmup 1 --no-extras > $out/tfetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/twrite -o w --output-format csv -- python3 bench.py --mode train --steps 2 --warmup 1 --no-extras > $out/twrite.log 2>&1
+python profiles/pmc_traffic.py $out/tfetch/f_counter_collection.csv $out/twrite/w_counter_collection.csv $out/${tag}_train_pmc_traffic.json > $out/${tag}_train_pmc_traffic.txt
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out/tmfma -o m --output-format csv -- python3 bench.py --mode train --steps 2 --warmup 1 --no-extras > $out/tmfma.log 2>&1
+python profiles/pmc_mfma_util.py $out/tmfma/m_counter_collection.csv $out/${tag}_train_pmc_mfma_util.json > $out/${tag}_train_pmc_mfma_util.txt
+echo "train passes done"
+fi
+if [ $what = all ] || [ $what = fp32 ]; then
+rocprofv3 --kernel-trace --stats -d $out/ftrace -o t --output-format csv -- python3 bench.py --dtype fp32 --steps 8 --warmup 2 --no-extras > $out/ftrace.log 2>&1
+python profiles/trace_by_shape.py $out/ftrace/t_kernel_trace.csv 10 > $out/${tag}_fp32_bs32_trace_by_shape.txt
+echo "fp32 pass done"
+fi
+# the raw traces are large: keep the summaries only
+rm -rf $out/trace $out/fetch $out/write $out/mfma $out/ttrace $out/tfetch $out/twrite $out/tmfma $out/ftrace
+ls $out

@@ -42,6 +42,19 @@ def _worker(rank, world, port, batch, q):
             outs = [ag.submit(_fake_forward(c[lo:hi], s[lo:hi], kk)) for kk in (1, 2)]
             last = ag.wait()
             ok = ok and torch.equal(last, _fake_forward(c, s, 2)) and torch.equal(outs[0], _fake_forward(c, s, 1))
+            # the in-place form bench.py uses at N > 1: a producer with TWO alternating output buffers (two captured graphs); the
+            # gather reads them in place, release_source() fences a buffer before it is overwritten, results land in caller-owned
+            # destinations
+            ag2 = AsyncImageGather(batch, rank, world, depth=2)
+            bufs = [torch.empty_like(c[lo:hi]) for _ in range(2)]
+            dests = [torch.empty_like(c) for _ in range(5)]
+            for i in range(5):
+                ag2.release_source(bufs[i % 2])
+                bufs[i % 2].copy_(_fake_forward(c[lo:hi], s[lo:hi], i + 1))
+                got = ag2.submit(bufs[i % 2], out=dests[i])
+                ok = ok and got is dests[i]
+            ag2.wait()
+            ok = ok and all(torch.equal(dests[i], _fake_forward(c, s, i + 1)) for i in range(5)) and not ag2.pending
         q.put((rank, ok, tuple(out.shape)))
     finally:
         dist.destroy_process_group()

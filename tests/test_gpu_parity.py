@@ -327,6 +327,15 @@ def test_graph_replay_matches_eager(cuda, mode):
         assert torch.equal(got, want)
     with pytest.raises(ValueError):
         stylize(torch.zeros(1, 3, 64, 96, device=cuda), torch.zeros(1, 3, 64, 96, device=cuda))
+    # two captures with alternating output buffers (the multi-GPU bench: the all-gather of step i reads buffer i % 2 in place)
+    two = GraphedStylizer(m, 2, 64, 96, transformer_layer_count=2, copies=2)
+    assert len(two.outs) == 2 and two.outs[0].data_ptr() != two.outs[1].data_ptr()
+    two.content.copy_(c); two.style.copy_(s)
+    a = two.replay(0)
+    two.content.copy_(c.flip(0)); two.style.copy_(s.flip(0))
+    b = two.replay(1)
+    torch.cuda.synchronize()
+    assert torch.equal(a, want) and torch.equal(b, m(c.flip(0), s.flip(0), 2)) and two.replay(2) is a
 
 
 @pytest.mark.gpu
