@@ -460,6 +460,63 @@ int launch(const GemmArgs& p, hipStream_t s) {
     return master_check_launch("gemm_f32");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// r03: 3x3 convolution with a handful of output channels (the decoder's last layer, decoder.py:54: 32 -> 3) as a direct
+// convolution on the vector ALUs.  On the implicit-GEMM kernel the 3 outputs occupy a 32-wide N tile (10x wasted matrix work:
+// 555 us at bs = 32 for 3.6 GFLOP); the layer is a stream of 128-byte pixels, so one thread takes one output pixel, walks its
+// nine taps with 16-byte loads (neighbouring lanes share six of them through L1 / L2) and keeps COUT accumulators; the weights
+// (COUT x 288 floats) sit in LDS and are read as wave-wide broadcasts.  Same reflect / upsample / zero-pad index rules as the gather
+// above; fp32 FMA chains (exact products, a different summation order than the MFMA's: ~1e-6).
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3x3_small_cout_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];            // [COUT][9][Cin]
+    const int K = 9 * p.Cin;
+    for (int i = threadIdx.x; i < COUT * K; i += 256) wl[i] = p.w[i];
+    __syncthreads();
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= p.M) return;
+    const int hw = p.Hout * p.Wout;
+    const int b = m / hw, pix = m - b * hw, y = pix / p.Wout, x = pix - y * p.Wout;
+    const int Hs = p.Hin << p.up, Ws = p.Win << p.up;
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = p.bias ? p.bias[co] : 0.0f;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        if (p.zero_pad && ((unsigned)yy >= (unsigned)Hs || (unsigned)xx >= (unsigned)Ws)) continue;
+        const int sy = reflect1(yy, Hs) >> p.up, sx = reflect1(xx, Ws) >> p.up;
+        const float* src = p.a + ((size_t)(b * p.Hin + sy) * p.Win + sx) * p.Cin;
+        const float* wt = wl + tap * p.Cin;
+        for (int c = 0; c < p.Cin; c += 4) {
+            const f32x4 xv = *(const f32x4*)(src + c);
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                const f32x4 wv = *(const f32x4*)(wt + co * K + c);       // same address in every lane: LDS broadcast
+                acc[co] = fmaf(xv[0], wv[0], acc[co]); acc[co] = fmaf(xv[1], wv[1], acc[co]);
+                acc[co] = fmaf(xv[2], wv[2], acc[co]); acc[co] = fmaf(xv[3], wv[3], acc[co]);
+            }
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+        float v = acc[co];
+        if (p.act == MASTER_ACT_GELU) v = gelu_erf(v);
+        else if (p.act == MASTER_ACT_RELU) v = fmaxf(v, 0.0f);
+        if (p.out_nchw) p.out[((size_t)b * COUT + co) * hw + pix] = v;
+        else p.out[(size_t)m * p.ldo + co] = v;
+    }
+}
+
+template <int COUT>
+int launch_small_cout(const GemmArgs& p, hipStream_t s) {
+    const size_t lds = (size_t)COUT * 9 * p.Cin * sizeof(float);
+    static LdsLimit lds_limit;
+    lds_limit.ensure((const void*)conv3x3_small_cout_kernel<COUT>, (int)lds);
+    hipLaunchKernelGGL(conv3x3_small_cout_kernel<COUT>, dim3((p.M + 255) / 256), dim3(256), lds, s, p);
+    return master_check_launch("conv3x3_small_cout");
+}
+
 // MASTER_GEMM_F32 = "reg": the register-staged r01 / r02 kernel; "dma" (default): the LDS-DMA ring.  MASTER_GEMM_F32_SMALL = 0 / 1:
 // 64x64 tiles (3-deep ring, 4-5 workgroups per CU) for problems with fewer than 256 tiles of 128x128 (train step: 8 192-token matrices).
 static int gemm_variant() {
@@ -475,6 +532,15 @@ static int gemm_small64() {
 
 template <bool CONV>
 int dispatch(const GemmArgs& p, hipStream_t s) {
+    if (CONV && p.N <= 4 && p.N >= 1 && gemm_variant() == 1 && !p.r1 && !p.r2 && !p.aux && !p.mask_relu && p.off == 0 && (p.Cin & 3) == 0 &&
+        p.Cin <= 1024 && (((uintptr_t)p.a) & 15) == 0) {
+        switch (p.N) {
+            case 1: return launch_small_cout<1>(p, s);
+            case 2: return launch_small_cout<2>(p, s);
+            case 3: return launch_small_cout<3>(p, s);
+            default: return launch_small_cout<4>(p, s);
+        }
+    }
     const bool few_tiles = p.N > 64 && (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) < 256;
     const bool dma_ok = (p.K % BK) == 0 && (!CONV || (p.Cin % BK == 0 && p.Cin <= 512)) &&
                         (((uintptr_t)p.a | (uintptr_t)p.w) & 15) == 0 && (CONV || (p.lda % 4) == 0);
