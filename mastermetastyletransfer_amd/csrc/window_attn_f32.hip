@@ -43,6 +43,11 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
     const int32_t* src = p.src + w * 64;
     const size_t tok0 = (size_t)b * p.T;
     const int coff = head * 32;
+    // r03: the window's gather table is read ONCE (one coalesced load, slot = lane) and handed around with shuffles / readlanes.  The
+    // kernel is a chain of dependent loads - table entry -> token row - and r02 walked it 100 times per problem (2 557 instructions,
+    // 79 vmcnt waits, ~70 k clocks for 8 k clocks of MFMA); with the table in a register every row address is known at once, and the
+    // V rows are requested before the S^T MFMAs instead of after the softmax.
+    const int my_src = lane < p.N ? src[lane] : -1;
 
     // ---- Q (B operand of S^T = K Q^T) and K (A operand): lane (row r, half h) holds channels
     //      [16h, 16h+16) of its token row; k-step s pairs channel s with channel 16+s.
@@ -50,7 +55,7 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int slot = t * 32 + r;
-        const int idx = slot < p.N ? src[slot] : -1;
+        const int idx = __shfl(my_src, slot, 64);
         const float* qp = p.q + (tok0 + (idx >= 0 ? idx : 0)) * p.ldq + coff + 16 * h;
         const float* kp = idx >= 0 ? p.k + (tok0 + idx) * p.ldk + coff + 16 * h
                                    : p.k_pad + (size_t)b * p.k_pad_bs + coff + 16 * h;
@@ -60,6 +65,24 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
             kv[t][c] = *(const f32x4*)(kp + 4 * c);     // key slots >= N: masked by bias = -1e30
         }
     }
+
+    // ---- V^T rows (A operand of O^T = V^T P^T: channel on the lane, one key per k-step = accumulator register (kt, e)): requested
+    //      now, consumed after the softmax
+    float vv0[2][16], vv1[2][16];
+    auto load_v = [&](const float* v, const float* v_pad, float (&vv)[2][16]) __attribute__((always_inline)) {
+        const float* vpad = v_pad + (size_t)b * p.v_pad_bs + coff + r;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key0 = kt * 32 + (e & 3) + 8 * (e >> 2);                   // half 0's key; half 1 takes key0 + 4
+                const int i0 = __builtin_amdgcn_readlane(my_src, key0), i1 = __builtin_amdgcn_readlane(my_src, key0 + 4);
+                const int idx = h ? i1 : i0;
+                const float a = idx >= 0 ? v[(tok0 + idx) * p.ldv + coff + r] : *vpad;
+                vv[kt][e] = (key0 + 4 * h) < p.N ? a : 0.0f;
+            }
+    };
+    load_v(p.v0, p.v0_pad, vv0);
 
     // ---- S^T tiles [key tile kt][query tile qt], initialised with bias (+ shift mask), pre-scaled
     //      by log2(e) so that P = exp2(S' - max').
@@ -104,6 +127,8 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
                     st[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[kt][c][e], qv[qt][c][e] * p.scale_log2e,
                                                                       st[kt][qt], 0, 0, 0);
 
+    if constexpr (DUAL) load_v(p.v1, p.v1_pad, vv1);      // second value stream: requested once the Q / K registers are free, lands under the softmax
+
     // ---- softmax over keys: 32 in-lane values + the partner half (lane ^ 32) ------------------
     float inv[2];
 #pragma unroll
@@ -129,33 +154,23 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
 
     // ---- O^T[d][q] = sum_key V^T[d][key] P^T[key][q]; k-step (kt, reg) covers keys
     //      kt*32 + (reg&3) + 8*(reg>>2) + 4*half, exactly the rows the accumulator register holds.
-    auto pv = [&](const float* v, const float* v_pad, float* out) {
+    auto pv = [&](const float (&vv)[2][16], float* out) {
         f32x16 o[2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[qt][e] = 0.0f;
-        const float* vpad = v_pad + (size_t)b * p.v_pad_bs + coff + r;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            float vv[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const int idx = key < p.N ? src[key] : -1;
-                vv[e] = key < p.N ? (idx >= 0 ? v[(tok0 + idx) * p.ldv + coff + r] : *vpad) : 0.0f;
-            }
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int e = 0; e < 16; ++e)
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt)
-                    o[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[e], st[kt][qt][e], o[qt], 0, 0, 0);
-        }
+                    o[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[kt][e], st[kt][qt][e], o[qt], 0, 0, 0);
         // o[qt][e]: query = qt*32 + r (lane), channel d = (e&3) + 8*(e>>2) + 4*h  -> 4 x 16-B stores
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            const int slot = qt * 32 + r;
-            const int idx = slot < p.N ? src[slot] : -1;
+            const int idx = __shfl(my_src, qt * 32 + r, 64);
             if (idx < 0) continue;
             float* op = out + (tok0 + idx) * p.ldo + coff + 4 * h;
 #pragma unroll
@@ -167,8 +182,8 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
             }
         }
     };
-    pv(p.v0, p.v0_pad, p.out0);
-    if (DUAL) pv(p.v1, p.v1_pad, p.out1);
+    pv(vv0, p.out0);
+    if constexpr (DUAL) pv(vv1, p.out1);
 }
 
 }  // namespace
