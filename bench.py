@@ -420,8 +420,8 @@ def train_bench(device, steps=10, warmup=3, B=8, S=256, max_layers=4, roofline=T
         dom = max(cand, key=lambda k: prof[k][1])
         n, ms = prof[dom]
         ach = counts[dom]["flops"] / (ms * 1e-3) / 1e12
-        names = {"conv3x3": "gemm_f32_kernel<.., CONV> (VGG-19 + decoder forward convolutions)", "conv_dgrad": "gemm_f32_kernel<.., CONV> data gradient (VGG-19 + decoder)",
-                 "conv_wgrad": "gemm_f32_t_kernel<.., GATHER> (decoder weight gradients)", "linear": "gemm_f32_kernel (projections, MLPs)",
+        names = {"conv3x3": "gemm_f32_dma_kernel<.., CONV> (VGG-19 + decoder forward convolutions)", "conv_dgrad": "gemm_f32_dma_kernel<.., CONV> data gradient (VGG-19 + decoder)",
+                 "conv_wgrad": "gemm_f32_t_kernel<.., GATHER> (decoder weight gradients)", "linear": "gemm_f32_dma_kernel (projections, MLPs)",
                  "linear_bwd": "gemm_f32_t_kernel (Linear data / weight gradients)"}
         res["roofline"] = {"kernel": names.get(dom, dom), "family": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS["fp32"],
                            "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS["fp32"], 4), "traffic": train_traffic(dom)[0],
