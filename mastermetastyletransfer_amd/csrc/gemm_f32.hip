@@ -545,6 +545,12 @@ int dispatch(const GemmArgs& p, hipStream_t s) {
     const bool dma_ok = (p.K % BK) == 0 && (!CONV || (p.Cin % BK == 0 && p.Cin <= 512)) &&
                         (((uintptr_t)p.a | (uintptr_t)p.w) & 15) == 0 && (CONV || (p.lda % 4) == 0);
     if (gemm_variant() == 1 && dma_ok) {
+        // a short contraction into a narrow output (K <= 128, N <= 128: the Swin stage-1 proj) is all prologue and epilogue on 128x128 tiles:
+        // 64x64 tiles (3-deep ring, three to five workgroups per CU) take 135 us against 154 at M = 262 144; wider or deeper shapes lose
+        // 4-8 % on them (measured), so only there.  MASTER_GEMM_F32_SHORTK=0 switches it off.
+        static int shortk = -1;
+        if (shortk < 0) { const char* e = getenv("MASTER_GEMM_F32_SHORTK"); shortk = e ? atoi(e) : 1; }
+        if (shortk && !CONV && p.K <= 128 && p.N > 32 && p.N <= 128) return launch_dma<64, 64, 32, 32, CONV, 3>(p, s);
         if (few_tiles) {
             if (gemm_small64()) return launch_dma<64, 64, 32, 32, CONV, 3>(p, s);
             return launch_dma<64, 128, 32, 64, CONV, 2>(p, s);
