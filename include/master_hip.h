@@ -41,6 +41,11 @@ enum master_status {
 };
 
 enum master_dtype { MASTER_F32 = 0, MASTER_BF16 = 1 };
+/* OR-ed into the `dtype` argument of master_linear_wgrad / master_colsum / master_layernorm_bwd: the parameter gradient is ADDED to
+ * the output buffer (dw / out / dgb) instead of overwriting it - the gradient of a tensor used several times in one graph (the k
+ * StyleTransformer layers share their weights, style_transformer.py:1239) is summed by the kernel's own slab reduce instead of by one
+ * autograd add launch per use.  Needs the workspace (at least one output-sized slab). */
+enum master_flags { MASTER_ACCUMULATE = 0x100 };
 enum master_act { MASTER_ACT_NONE = 0, MASTER_ACT_GELU = 1 /* exact erf */, MASTER_ACT_RELU = 2 };
 
 int master_version(void);

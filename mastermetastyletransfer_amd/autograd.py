@@ -32,6 +32,74 @@ def _ws(nfloats: int, dev) -> Optional[Tensor]:
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------
+# Gradients of tensors used several times in one graph (the k StyleTransformer layers share their weights, style_transformer.py:1239;
+# the StyleEncoder's shared block runs 2k times): autograd would sum them with one add launch per use and tensor (~240 of a step's
+# launches).  Instead the forward counts the uses of every such tensor inside the current scope (train_forward.style_transformer),
+# every backward call but the last ACCUMULATES its contribution into one buffer inside the kernel's own slab reduce
+# (MASTER_ACCUMULATE) and returns None to autograd, and the last call returns the buffer.  Outside a scope, or when a backward meets
+# a graph the registry was not counted for (two forwards before a backward, a second backward through a retained graph), every call
+# returns its own fresh gradient as before.
+# ---------------------------------------------------------------------------------------------------------------------------------------
+ACCUMULATE = 0x100            # include/master_hip.h: MASTER_ACCUMULATE
+
+
+class _SharedGrads:
+    def __init__(self):
+        self.counting = None              # token of the scope whose forward is being recorded (None: not counting)
+        self.graph = None                 # token of the scope the counts in `uses` belong to
+        self.uses = {}                    # id(tensor) -> [remaining uses, buffer or None]
+        self._checked = None
+
+    def begin(self) -> object:
+        self.counting = self.graph = object()
+        self.uses = {}
+        return self.counting
+
+    def end(self, token) -> None:
+        if self.counting is token:
+            self.counting = None          # counting stops; the counts stay for the backward of this graph
+
+    def note(self, *ts) -> object:
+        """forward: count one use of every tensor that wants a gradient; returns the scope token to keep in ctx (None outside a scope)"""
+        if self.counting is None:
+            return None
+        for t in ts:
+            if t is not None and t.requires_grad:
+                self.uses.setdefault(id(t), [0, None])[0] += 1
+        return self.counting
+
+    def deliver(self, token, t, compute):
+        """backward: compute(out, accumulate) -> gradient tensor (added into `out` when accumulate).  Returns what the autograd Function
+        should return for `t`: None for every use but the last, then the buffer holding the sum."""
+        e = self.uses.get(id(t)) if (token is not None and token is self.graph) else None
+        if e is None or (e[0] <= 1 and e[1] is None):
+            if e is not None:
+                self.uses.pop(id(t), None)
+            return compute(None, False)
+        if self._checked is not token:    # once per backward pass: a use that never ran backward would strand its sum - fail loudly
+            self._checked = token
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: self._verify(token))
+        e[1] = compute(None, False) if e[1] is None else compute(e[1], True)
+        e[0] -= 1
+        if e[0] == 0:
+            self.uses.pop(id(t), None)
+            return e[1]
+        return None
+
+    def _verify(self, token) -> None:
+        self._checked = None
+        if token is self.graph:
+            stranded = [k for k, e in self.uses.items() if e[1] is not None]
+            self.uses = {}
+            if stranded:
+                raise ops.MasterHipError(f"{len(stranded)} shared parameter gradient(s) were accumulated but never delivered: a counted use "
+                                         "did not take part in this backward pass (a branch of the forward that does not reach the loss)")
+
+
+shared_grads = _SharedGrads()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
 # raw launches (device guard: the autograd engine may call backward from another thread / with another current device)
 # ---------------------------------------------------------------------------------------------------------------------------------------
 @ops._on_device
@@ -58,27 +126,27 @@ def linear_dgrad(g: Tensor, w: Tensor, gelu_pre: Optional[Tensor] = None) -> Ten
 
 
 @ops._on_device
-def linear_wgrad(g: Tensor, a: Tensor) -> Tensor:
+def linear_wgrad(g: Tensor, a: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
     M, N = g.shape
     K = a.shape[1]
     lib = load_library()
-    dw = torch.empty((N, K), dtype=F, device=g.device)
+    dw = out if out is not None else torch.empty((N, K), dtype=F, device=g.device)
     nws = lib.master_gemm_workspace_floats(N, K)
     ws = _ws(nws, g.device)
     if ops._COUNT_ON:
         ops._count("linear_bwd", flops=2.0 * M * N * K, bytes=4.0 * (M * N + M * K + N * K))
-    _check(lib.master_linear_wgrad(_p(g), _p(a), _p(dw), M, N, K, g.stride(0), a.stride(0), _p(ws), ws.numel(), F32, _stream()),
-           "master_linear_wgrad")
+    _check(lib.master_linear_wgrad(_p(g), _p(a), _p(dw), M, N, K, g.stride(0), a.stride(0), _p(ws), ws.numel(),
+                                   F32 | (ACCUMULATE if accumulate else 0), _stream()), "master_linear_wgrad")
     return dw
 
 
 @ops._on_device
-def colsum(x: Tensor) -> Tensor:
+def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
     M, N = x.shape
     lib = load_library()
-    out = torch.empty((N,), dtype=F, device=x.device)
+    out = out if out is not None else torch.empty((N,), dtype=F, device=x.device)
     ws = _ws(lib.master_colsum_workspace_floats(M, N), x.device)
-    _check(lib.master_colsum(_p(x), _p(out), _p(ws), M, N, x.stride(0), F32, _stream()), "master_colsum")
+    _check(lib.master_colsum(_p(x), _p(out), _p(ws), M, N, x.stride(0), F32 | (ACCUMULATE if accumulate else 0), _stream()), "master_colsum")
     return out
 
 
@@ -90,14 +158,16 @@ def reduce_slabs(part: Tensor, n: int, splits: int) -> Tensor:
 
 
 @ops._on_device
-def layernorm_bwd(x: Tensor, gamma: Tensor, g: Tensor, eps: float) -> Tuple[Tensor, Tensor, Tensor]:
+def layernorm_bwd(x: Tensor, gamma: Tensor, g: Tensor, eps: float, dgb: Optional[Tensor] = None, accumulate: bool = False):
+    """-> (dx, dgb [2,C] = dgamma | dbeta); with `dgb` given and accumulate the parameter gradients are added to it"""
     M, C = x.shape
     lib = load_library()
     dx = torch.empty_like(x)
-    dgb = torch.empty((2, C), dtype=F, device=x.device)
+    dgb = dgb if dgb is not None else torch.empty((2, C), dtype=F, device=x.device)
     ws = _ws(lib.master_layernorm_bwd_workspace_floats(M, C), x.device)
-    _check(lib.master_layernorm_bwd(_p(x), _p(gamma), _p(g), _p(dx), _p(dgb), _p(ws), M, C, eps, F32, _stream()), "master_layernorm_bwd")
-    return dx, dgb[0], dgb[1]
+    _check(lib.master_layernorm_bwd(_p(x), _p(gamma), _p(g), _p(dx), _p(dgb), _p(ws), M, C, eps, F32 | (ACCUMULATE if accumulate else 0),
+                                    _stream()), "master_layernorm_bwd")
+    return dx, dgb
 
 
 @ops._on_device
@@ -127,17 +197,18 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, a: Tensor, w: Tensor, bias: Optional[Tensor]):
         a, w = _f32c(a), _f32c(w)
         out, _ = linear_act_fwd(a, w, bias, ops.ACT_NONE, False)
-        ctx.save_for_backward(a, w)
+        ctx.save_for_backward(a, w, bias)
         ctx.has_bias = bias is not None
+        ctx.shared = shared_grads.note(w, bias)
         return out
 
     @staticmethod
     def backward(ctx, g: Tensor):
-        a, w = ctx.saved_tensors
+        a, w, bias = ctx.saved_tensors
         g = _f32c(g)
         da = linear_dgrad(g, w) if ctx.needs_input_grad[0] else None
-        dw = linear_wgrad(g, a) if ctx.needs_input_grad[1] else None
-        db = colsum(g) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        dw = shared_grads.deliver(ctx.shared, w, lambda o, acc: linear_wgrad(g, a, o, acc)) if ctx.needs_input_grad[1] else None
+        db = shared_grads.deliver(ctx.shared, bias, lambda o, acc: colsum(g, o, acc)) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return da, dw, db
 
 
@@ -148,13 +219,21 @@ class LayerNormFn(torch.autograd.Function):
         y = ops.layernorm(x, gamma.detach(), beta.detach(), eps)
         ctx.save_for_backward(x, gamma)
         ctx.eps = eps
+        ctx.shared = shared_grads.note(gamma)              # gamma and beta travel together: one [2,C] buffer, counted on gamma
         return y
 
     @staticmethod
     def backward(ctx, g: Tensor):
         x, gamma = ctx.saved_tensors
-        dx, dg, db = layernorm_bwd(x, gamma.detach(), _f32c(g), ctx.eps)
-        return dx, dg, db, None
+        box = {}
+
+        def run(o, acc):
+            box["dx"], dgb = layernorm_bwd(x, gamma.detach(), _f32c(g), ctx.eps, o, acc)
+            return dgb
+        dgb = shared_grads.deliver(ctx.shared, gamma, run)
+        if dgb is None:
+            return box["dx"], None, None, None
+        return box["dx"], dgb[0], dgb[1], None
 
 
 class MLPFn(torch.autograd.Function):
@@ -167,25 +246,35 @@ class MLPFn(torch.autograd.Function):
         xn = ops.layernorm(x, ln_g.detach(), ln_b.detach(), eps) if ln_g is not None else x
         h, pre = linear_act_fwd(xn, w1, b1, ops.ACT_GELU, True)
         y, _ = linear_act_fwd(h, w2, b2, ops.ACT_NONE, False)
-        ctx.save_for_backward(x, xn, pre, h, w1, w2, ln_g)
+        ctx.save_for_backward(x, xn, pre, h, w1, w2, ln_g, b1, b2)
         ctx.eps = eps
+        ctx.shared = shared_grads.note(w1, b1, w2, b2, ln_g)
         return y
 
     @staticmethod
     def backward(ctx, g: Tensor):
-        x, xn, pre, h, w1, w2, ln_g = ctx.saved_tensors
+        x, xn, pre, h, w1, w2, ln_g, b1, b2 = ctx.saved_tensors
         g = _f32c(g)
         need = ctx.needs_input_grad
-        dw2 = linear_wgrad(g, h) if need[3] else None
-        db2 = colsum(g) if need[4] else None
+        sg, tok = shared_grads, ctx.shared
+        dw2 = sg.deliver(tok, w2, lambda o, acc: linear_wgrad(g, h, o, acc)) if need[3] else None
+        db2 = sg.deliver(tok, b2, lambda o, acc: colsum(g, o, acc)) if need[4] else None
         dpre = linear_dgrad(g, w2, gelu_pre=pre)                        # (g . W2) * gelu'(pre)
-        dw1 = linear_wgrad(dpre, xn) if need[1] else None
-        db1 = colsum(dpre) if need[2] else None
+        dw1 = sg.deliver(tok, w1, lambda o, acc: linear_wgrad(dpre, xn, o, acc)) if need[1] else None
+        db1 = sg.deliver(tok, b1, lambda o, acc: colsum(dpre, o, acc)) if need[2] else None
         dx = dg = dbeta = None
         if need[0] or (ln_g is not None and (need[5] or need[6])):
             dxn = linear_dgrad(dpre, w1)
             if ln_g is not None:
-                dx, dg, dbeta = layernorm_bwd(x, ln_g.detach(), dxn, ctx.eps)
+                box = {}
+
+                def run(o, acc):
+                    box["dx"], dgb = layernorm_bwd(x, ln_g.detach(), dxn, ctx.eps, o, acc)
+                    return dgb
+                dgb = sg.deliver(tok, ln_g, run)
+                dx = box["dx"]
+                if dgb is not None:
+                    dg, dbeta = dgb[0], dgb[1]
             else:
                 dx = dxn
         return dx, dw1, db1, dw2, db2, dg, dbeta, None

@@ -18,11 +18,11 @@ int window_attn_proj_bf16(const bf16_t*, const bf16_t*, const bf16_t*, int, int,
 int gemm_f32_conv3x3_dgrad(const float*, const float*, float*, const float*, const float*, int, int, int, int, int, int, hipStream_t);
 size_t gemm_f32_t_workspace(int, int);
 int gemm_f32_dgrad(const float*, const float*, float*, const float*, int, int, int, int, int, int, hipStream_t);
-int gemm_f32_wgrad(const float*, const float*, float*, int, int, int, int, int, float*, size_t, hipStream_t);
+int gemm_f32_wgrad(const float*, const float*, float*, int, int, int, int, int, float*, size_t, hipStream_t, int accumulate = 0);
 int gemm_f32_conv3x3_wgrad(const float*, const float*, float*, int, int, int, int, int, int, int, int, float*, size_t, hipStream_t);
-int reduce_slabs_launch(const float*, float*, size_t, size_t, int, hipStream_t);
+int reduce_slabs_launch(const float*, float*, size_t, size_t, int, hipStream_t, int accumulate = 0);
 int colsum_slabs(int, int);
-int colsum_launch(const float*, const float*, float*, float*, int, int, int, hipStream_t);
+int colsum_launch(const float*, const float*, float*, float*, int, int, int, hipStream_t, int accumulate = 0);
 template <typename T> int channel_affine_launch(const void*, const float*, const float*, void*, int, int, hipStream_t);
 template <typename T> int softmax_rows_launch(const void*, void*, int, int, int, float, hipStream_t);
 int softmax_rows_bwd_launch(const float*, const float*, float*, int, int, int, float, hipStream_t);
@@ -41,7 +41,7 @@ int loss_tap_slices(int);
 template <typename T> int loss_tap_bwd_launch(const void*, const float*, const float*, const float*, const float*, float*, void*, int, int, int,
                                               float, float, int, int, hipStream_t);
 int layernorm_bwd_blocks(int);
-int layernorm_bwd_launch(const float*, const float*, const float*, float*, float*, float*, int, int, float, hipStream_t);
+int layernorm_bwd_launch(const float*, const float*, const float*, float*, float*, float*, int, int, float, hipStream_t, int accumulate = 0);
 int instnorm_bwd_launch(const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, float, hipStream_t);
 int window_attn_bwd_f32(const float*, const float*, const float*, const float*, int, int, int, const float*, const float*, const float*, int,
                         int, const float*, const int32_t*, const uint8_t*, const int32_t*, const float*, const float*, int, float*, float*,
@@ -169,23 +169,25 @@ size_t master_gemm_workspace_floats(int rows, int cols) { return gemm_f32_t_work
 
 int master_linear_wgrad(const void* g, const void* a, void* dw, int M, int N, int K, int ldg, int lda, void* ws, size_t ws_floats, int dtype,
                         master_stream_t stream) {
+    const int accumulate = (dtype & MASTER_ACCUMULATE) != 0; dtype &= ~MASTER_ACCUMULATE;
     F32_ONLY("linear_wgrad");
     REQUIRE(g && a && dw, "linear_wgrad: null operand");
     REQUIRE(M > 0 && N > 0 && K > 0 && K % 4 == 0 && ldg >= N && lda >= K && lda % 4 == 0, "linear_wgrad: bad dims M=%d N=%d K=%d", M, N, K);
     REQUIRE(al16(a) && al16(dw) && (ws == nullptr || al16(ws)), "linear_wgrad: a/dw/ws must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_LINEAR_BWD, s);
-    return gemm_f32_wgrad((const float*)g, (const float*)a, (float*)dw, M, N, K, ldg, lda, (float*)ws, ws_floats, s);
+    return gemm_f32_wgrad((const float*)g, (const float*)a, (float*)dw, M, N, K, ldg, lda, (float*)ws, ws_floats, s, accumulate);
 }
 
 size_t master_colsum_workspace_floats(int M, int N) { return (size_t)colsum_slabs(M, N) * (size_t)N; }
 int master_colsum(const void* x, void* out, void* ws, int M, int N, int ld, int dtype, master_stream_t stream) {
+    const int accumulate = (dtype & MASTER_ACCUMULATE) != 0; dtype &= ~MASTER_ACCUMULATE;
     F32_ONLY("colsum");
     REQUIRE(x && out && M > 0 && N > 0 && N % 4 == 0 && ld >= N && ld % 4 == 0 && al16(x), "colsum: bad arguments (M=%d N=%d ld=%d)", M, N, ld);
-    REQUIRE(ws || colsum_slabs(M, N) == 1, "colsum: workspace required");
+    REQUIRE(ws || (colsum_slabs(M, N) == 1 && !accumulate), "colsum: workspace required");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_TRAIN_MISC, s);
-    return colsum_launch((const float*)x, nullptr, (float*)out, (float*)ws, M, N, ld, s);
+    return colsum_launch((const float*)x, nullptr, (float*)out, (float*)ws, M, N, ld, s, accumulate);
 }
 
 int master_colsum_prod(const void* x, const void* y, void* out, void* ws, int M, int N, int ld, int dtype, master_stream_t stream) {
@@ -229,11 +231,12 @@ int master_reduce_slabs(const float* part, float* out, size_t n, size_t slab, in
 size_t master_layernorm_bwd_workspace_floats(int M, int C) { return (size_t)layernorm_bwd_blocks(M) * 2 * (size_t)C; }
 int master_layernorm_bwd(const void* x, const float* gamma, const void* g, void* dx, float* dgb, float* ws, int M, int C, float eps, int dtype,
                          master_stream_t stream) {
+    const int accumulate = (dtype & MASTER_ACCUMULATE) != 0; dtype &= ~MASTER_ACCUMULATE;
     F32_ONLY("layernorm_bwd");
     REQUIRE(x && gamma && g && dx && dgb && ws && M > 0, "layernorm_bwd: null operand");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_LAYERNORM, s);
-    return layernorm_bwd_launch((const float*)x, gamma, (const float*)g, (float*)dx, dgb, ws, M, C, eps, s);
+    return layernorm_bwd_launch((const float*)x, gamma, (const float*)g, (float*)dx, dgb, ws, M, C, eps, s, accumulate);
 }
 
 int master_instnorm_bwd(const void* x, const void* g, const void* pad_row_in, const void* g_pad, void* dx, void* dpad, int B, int T, int C,

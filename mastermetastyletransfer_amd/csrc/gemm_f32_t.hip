@@ -15,7 +15,7 @@
 #include "common.h"
 #include <stdlib.h>
 
-int reduce_slabs_launch(const float* part, float* out, size_t n, size_t slab, int splits, hipStream_t s);   // train_misc.hip
+int reduce_slabs_launch(const float* part, float* out, size_t n, size_t slab, int splits, hipStream_t s, int accumulate = 0);   // train_misc.hip
 
 namespace {
 
@@ -272,7 +272,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_t_kernel(
 }
 
 template <int BM, int BN, int WM, int WN, bool AT, bool GATHER>
-int launch_t(TArgs p, float* final_out, float* ws, size_t ws_floats, int want_splits, hipStream_t s) {
+int launch_t(TArgs p, float* final_out, float* ws, size_t ws_floats, int want_splits, hipStream_t s, int accumulate = 0) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     constexpr int A_ELEMS = AT ? BK * (BM + PADT) : BM * LDK;
     constexpr int W_ELEMS = BK * (BN + PADT);
@@ -291,12 +291,15 @@ int launch_t(TArgs p, float* final_out, float* ws, size_t ws_floats, int want_sp
     }
     p.chunks_per_split = (nk + splits - 1) / splits;
     splits = (nk + p.chunks_per_split - 1) / p.chunks_per_split;
-    if (splits > 1) { p.out = ws; p.slab = slab; } else { p.out = final_out; p.slab = 0; }
+    // accumulate (final_out += result): always through the workspace and the slab reduce, which adds to final_out
+    const bool via_ws = splits > 1 || accumulate;
+    if (accumulate && (ws == nullptr || ws_floats < slab)) { master_set_error("gemm_f32_t: accumulating needs a workspace of at least one slab"); return MASTER_ERR_INVALID; }
+    if (via_ws) { p.out = ws; p.slab = slab; } else { p.out = final_out; p.slab = 0; }
     const size_t lds = (size_t)2 * (A_ELEMS + W_ELEMS) * sizeof(float);
     static LdsLimit lds_limit;
     lds_limit.ensure((const void*)gemm_f32_t_kernel<BM, BN, WM, WN, AT, GATHER>, (int)lds);
     hipLaunchKernelGGL((gemm_f32_t_kernel<BM, BN, WM, WN, AT, GATHER>), dim3(tiles, splits), dim3(NT), lds, s, p);
-    if (splits > 1) return reduce_slabs_launch(ws, final_out, (size_t)p.M * p.ldo, slab, splits, s);
+    if (via_ws) return reduce_slabs_launch(ws, final_out, (size_t)p.M * p.ldo, slab, splits, s, accumulate);
     return master_check_launch("gemm_f32_t");
 }
 
@@ -330,10 +333,10 @@ int gemm_f32_dgrad(const float* g, const float* w, float* out, const float* aux,
 
 // dW[Nc,Kc] = G[M,Nc]^T . X[M,Kc]      (dense output, ldo = Kc)
 int gemm_f32_wgrad(const float* g, const float* x, float* out, int M, int Nc, int Kc, int ldg, int ldx, float* ws, size_t ws_floats,
-                   hipStream_t s) {
+                   hipStream_t s, int accumulate) {
     TArgs p{g, x, out, Nc, Kc, M, ldg, ldx, Kc, 0, 0, nullptr, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (Nc > 64) return launch_t<128, 128, 64, 64, true, false>(p, out, ws, ws_floats, 0, s);
-    return launch_t<32, 256, 32, 64, true, false>(p, out, ws, ws_floats, 0, s);
+    if (Nc > 64) return launch_t<128, 128, 64, 64, true, false>(p, out, ws, ws_floats, 0, s, accumulate);
+    return launch_t<32, 256, 32, 64, true, false>(p, out, ws, ws_floats, 0, s, accumulate);
 }
 
 // dWpacked[Cout][3][3][Cin] = sum over the B*Hout*Wout output pixels of G[pix][Cout] (x) gather(X)[pix][tap][Cin]

@@ -3,7 +3,7 @@
 // bias-only rows of the zero-padded map).  Statistics are recomputed from x (two-pass, like the forward); HBM-bound.
 #include "common.h"
 
-int reduce_slabs_launch(const float* part, float* out, size_t n, size_t slab, int splits, hipStream_t s);
+int reduce_slabs_launch(const float* part, float* out, size_t n, size_t slab, int splits, hipStream_t s, int accumulate = 0);
 
 namespace {
 
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restri
 
 int layernorm_bwd_blocks(int M) { int b = (M + 15) / 16; return b > 512 ? 512 : (b < 1 ? 1 : b); }
 // ws: layernorm_bwd_blocks(M) * 2 * C floats; dgb: [2][C] = dgamma | dbeta
-int layernorm_bwd_launch(const float* x, const float* gamma, const float* g, float* dx, float* dgb, float* ws, int M, int C, float eps, hipStream_t s) {
+int layernorm_bwd_launch(const float* x, const float* gamma, const float* g, float* dx, float* dgb, float* ws, int M, int C, float eps, hipStream_t s, int accumulate) {
     if (C % 4 != 0 || C > 1024) { master_set_error("layernorm_bwd: C %% 4 == 0 and C <= 1024 (C=%d)", C); return MASTER_ERR_INVALID; }
     const int blocks = layernorm_bwd_blocks(M);
     const size_t lds = (size_t)8 * C * sizeof(float);
@@ -183,7 +183,7 @@ int layernorm_bwd_launch(const float* x, const float* gamma, const float* g, flo
     if (ch == 1) hipLaunchKernelGGL((layernorm_bwd_kernel<1>), dim3(blocks), dim3(256), lds, s, x, gamma, g, dx, ws, M, C, eps);
     else if (ch == 2) hipLaunchKernelGGL((layernorm_bwd_kernel<2>), dim3(blocks), dim3(256), lds, s, x, gamma, g, dx, ws, M, C, eps);
     else hipLaunchKernelGGL((layernorm_bwd_kernel<4>), dim3(blocks), dim3(256), lds, s, x, gamma, g, dx, ws, M, C, eps);
-    return reduce_slabs_launch(ws, dgb, (size_t)2 * C, (size_t)2 * C, blocks, s);
+    return reduce_slabs_launch(ws, dgb, (size_t)2 * C, (size_t)2 * C, blocks, s, accumulate);
 }
 int instnorm_bwd_launch(const float* x, const float* g, const float* pad_in, const float* g_pad, float* dx, float* dpad, int B, int Tn, int C,
                         int n_pad, float eps, hipStream_t s) {

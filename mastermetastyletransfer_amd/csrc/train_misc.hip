@@ -4,7 +4,7 @@
 // Every reduction adds partial sums in a fixed order: results are bitwise reproducible.
 #include "common.h"
 
-int reduce_slabs_launch(const float* part, float* out, size_t n, size_t slab, int splits, hipStream_t s);
+int reduce_slabs_launch(const float* part, float* out, size_t n, size_t slab, int splits, hipStream_t s, int accumulate = 0);
 
 namespace {
 
@@ -30,7 +30,7 @@ template <> struct El<bf16_t> {
 //      wave are 64 consecutive floats), 8 independent partial sums per thread keep the loads in flight; the four wave partials are
 //      added in a fixed order through LDS.  (r02: one thread per output walking 512 slabs serially took 41 us per bias gradient.) -------
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, size_t slab,
-                                                           int splits) {
+                                                           int splits, int accumulate) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const size_t i = (size_t)blockIdx.x * 64 + lane;
@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
     }
     red[wv][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     __syncthreads();
-    if (wv == 0 && i < n) out[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    // accumulate: out += (r03) - the gradient of a tensor used several times in one graph (the k StyleTransformer layers share their
+    // weights) is summed here instead of by one autograd add launch per use
+    if (wv == 0 && i < n) out[i] = (accumulate ? out[i] : 0.0f) + ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
 }
 
 // ---- column sums: part[slab][n] = sum over the slab's rows of x[m][n]   (bias gradients; N % 4 == 0).  tpr = min(N/4, 64) threads
@@ -354,8 +356,8 @@ inline unsigned blocks_for(size_t n, unsigned cap = 0x7fffffffu) { size_t b = (n
 
 }  // namespace
 
-int reduce_slabs_launch(const float* part, float* out, size_t n, size_t slab, int splits, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, out, n, slab, splits);
+int reduce_slabs_launch(const float* part, float* out, size_t n, size_t slab, int splits, hipStream_t s, int accumulate) {
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, out, n, slab, splits, accumulate);
     return master_check_launch("reduce_slabs");
 }
 
@@ -367,10 +369,11 @@ int colsum_slabs(int M, int N) {                      // row slabs such that the
     return slabs < 1 ? 1 : slabs;
 }
 // ws: colsum_slabs(M, N) * N floats
-int colsum_launch(const float* x, const float* y, float* out, float* ws, int M, int N, int ld, hipStream_t s) {
+int colsum_launch(const float* x, const float* y, float* out, float* ws, int M, int N, int ld, hipStream_t s, int accumulate) {
     const int slabs = colsum_slabs(M, N), rps = (M + slabs - 1) / slabs, tpr = colsum_tpr(N);
-    hipLaunchKernelGGL(colsum_kernel, dim3((N / 4 + tpr - 1) / tpr, slabs), dim3(256), 0, s, x, y, slabs == 1 ? out : ws, M, N, ld, rps, tpr);
-    if (slabs > 1) return reduce_slabs_launch(ws, out, (size_t)N, (size_t)N, slabs, s);
+    const bool direct = slabs == 1 && !accumulate;            // accumulate: always through the slab reduce, which adds to out
+    hipLaunchKernelGGL(colsum_kernel, dim3((N / 4 + tpr - 1) / tpr, slabs), dim3(256), 0, s, x, y, direct ? out : ws, M, N, ld, rps, tpr);
+    if (!direct) return reduce_slabs_launch(ws, out, (size_t)N, (size_t)N, slabs, s, accumulate);
     return master_check_launch("colsum");
 }
 int relu_mask_launch(const float* g, const float* relu_out, float* gm, int B, int HW, int C, int Cp, int g_nchw, hipStream_t s) {

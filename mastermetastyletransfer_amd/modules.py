@@ -826,6 +826,8 @@ class SwinEncoder(nn.Sequential):
         if self.training:
             from . import train_forward as TF
             blocks = [b for b in list(self[1]) + list(self[3]) if b.stochastic_depth_prob > 0.0]
+            if len({int(img.shape[0]) for img in imgs}) == 1:          # all masks of this call in two launches instead of two per mask
+                TF.sd_masks.prefetch([b.stochastic_depth_prob for _ in imgs for b in blocks for _ in range(2)], int(imgs[0].shape[0]), imgs[0].device)
             per_call = [[(TF.sd_masks.draw(int(img.shape[0]), b.stochastic_depth_prob, img.device),
                           TF.sd_masks.draw(int(img.shape[0]), b.stochastic_depth_prob, img.device)) for b in blocks] for img in imgs]
             for j, b in enumerate(blocks):

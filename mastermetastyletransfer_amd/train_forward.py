@@ -45,11 +45,31 @@ class StochasticDepthMasks:
             if not self._explicit:
                 raise RuntimeError("StochasticDepthMasks: the explicit mask list is exhausted")
             return self._explicit.pop(0).to(device=device, dtype=torch.float32).contiguous()
+        q = self.__dict__.get("_queue")
+        if q:
+            (qB, qp, qdev), row = q[0]
+            if qB == B and qp == p and qdev == device:
+                q.pop(0)
+                return row
+            q.clear()                                    # the caller left the announced order: fall back to one draw per call
         keep = 1.0 - p
         noise = torch.empty((B,), dtype=torch.float32, device=device).bernoulli_(keep, generator=self.generator)
         if keep > 0.0:
             noise.div_(keep)
         return noise
+
+    def prefetch(self, ps: Sequence[float], B: int, device) -> None:
+        """Draw the masks of the next len(ps) draw(B, ps[i], device) calls in TWO launches (one Bernoulli over a [n, B] matrix of keep
+        probabilities, one division) instead of two per mask: a train step draws 34-50 masks of 8 floats each.  Same distribution as
+        torchvision's per-call `empty([B]).bernoulli_(1 - p).div_(1 - p)`; the device random stream is consumed in one block instead of
+        n (no CPU / reference stream is reproducible on the device either way - parity tests install explicit masks)."""
+        if self._explicit is not None or not ps:
+            return
+        keep = torch.tensor([1.0 - float(p) for p in ps], dtype=torch.float32).clamp_(min=0.0)
+        keep = keep.to(device, non_blocking=True)[:, None].expand(len(ps), B)
+        noise = torch.bernoulli(keep, generator=self.generator)
+        noise = noise / keep.clamp(min=1e-30)            # p = 1 rows are all zero either way
+        self.__dict__["_queue"] = [((B, float(p), device), noise[i]) for i, p in enumerate(ps)]
 
 
 sd_masks = StochasticDepthMasks()          # the process-wide source (one model per process; parity tests install explicit masks here)
@@ -285,10 +305,28 @@ def style_decoder(dec, fcs: Tensor, key: Tensor, scale: Tensor, shift: Tensor, B
     return _residual(_mlp(dec.last_MLP, query), query, p, dec.training, sd, B, T)                     # :1125
 
 
+def _mask_order(st, k: int) -> List[float]:
+    """StochasticDepth probabilities of one StyleTransformer call in draw order (only the residuals that draw: training and p > 0)"""
+    enc, dec = st.encoder, st.decoder
+    eb, db = enc.shared_MHA_without_MLP, dec.MHA_self_attn
+    pe_blk = eb.stochastic_depth_prob if eb.training else 0.0
+    pe = enc.encoder_stochastic_depth_prob if enc.training else 0.0
+    pd_blk = db.stochastic_depth_prob if db.training else 0.0
+    pd = dec.decoder_stochastic_depth_prob if dec.training else 0.0
+    key = [pe_blk, pe]
+    scale_shift = [pe_blk, pe, pe_blk, pe]
+    per_layer = (key + scale_shift) if enc.if_use_processed_Key_in_Scale_and_Shift_calculation else (scale_shift + key)
+    per_layer = per_layer + [pd_blk] + ([] if db.exclude_MLP_after else [pd_blk]) + [pd]
+    return [p for p in per_layer * k if p > 0.0]
+
+
 def style_transformer(st, fc: Tensor, fs: Tensor, k: int, B, H, W, sd: StochasticDepthMasks) -> Tensor:
     global _MEMO
+    from .autograd import shared_grads
     outer, _MEMO = _MEMO, {}
+    scope = shared_grads.begin() if (outer is None and torch.is_grad_enabled()) else None
     try:
+        sd.prefetch(_mask_order(st, k), B, fc.device)
         scale = shift = fs                                                                            # :1235-1236
         for _ in range(k):
             fs, scale, shift = style_encoder(st.encoder, fs, scale, shift, B, H, W, sd)
@@ -296,6 +334,8 @@ def style_transformer(st, fc: Tensor, fs: Tensor, k: int, B, H, W, sd: Stochasti
         return fc
     finally:
         _MEMO = outer
+        if scope is not None:
+            shared_grads.end(scope)
 
 
 def image_decoder(dec, x_nhwc: Tensor) -> Tensor:
