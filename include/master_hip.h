@@ -132,6 +132,16 @@ int master_window_attn_proj_fwd(const void* q, const void* k, const void* v, int
                                 const uint8_t* region, const void* wproj, const float* bproj, const void* res, int ldr, void* out,
                                 int ldo, int B, int T, int heads, int nW, int N, float scale, int dtype, master_stream_t stream);
 
+/* n (1..3) independent Linear layers of one shape class in ONE launch:  out_i[M, N_i] = LN?(x_i) . w_i^T + bias_i
+ * (same M and K; N_i % 128 == 0; no residual operands; x, w, bias, out, N, ldx, ldo are HOST arrays of n entries; bias_i may be NULL).
+ * Replaces the groups of projections that feed one attention call from different inputs: Wk . Key | Wv_scale . Scale | Wv_shift . Shift
+ * of the sigma/mu attention (style_transformer.py:515-517) and Wq|Wk . Key + Wv . Scale of the StyleEncoder's Scale / Shift call
+ * (:114-116 with q = k) - each a one-tile-per-CU launch on its own at bs = 32.  MASTER_BF16, K in {128, 256}; MASTER_ERR_UNSUPPORTED
+ * otherwise (callers then use master_linear_fwd per problem). */
+int master_linear_group_fwd(int n, const void* const* x, const void* const* w, const void* const* bias, void* const* out, const int* N,
+                            const int* ldx, const int* ldo, const float* ln_gamma, const float* ln_beta, int M, int K, float eps,
+                            int dtype, master_stream_t stream);
+
 /* Whole attention half of a (Style)SwinTransformerBlock with q = k = v in ONE launch:
  *     out = x + proj( window_attention( qkv( LayerNorm?(x) ) ) )
  * x, out: token matrices [B*T, C]; wqkv [3C, C] = rows of Wq | Wk | Wv (torchvision's fused qkv.weight), bqkv [3C] fp32;

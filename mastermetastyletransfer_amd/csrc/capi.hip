@@ -15,6 +15,8 @@ int gemm_f32_linear(const float*, const float*, const float*, const float*, cons
 int window_attn_proj_bf16(const bf16_t*, const bf16_t*, const bf16_t*, int, int, int, const bf16_t*, const bf16_t*, int, int, const float*,
                           const int32_t*, const uint8_t*, const bf16_t*, const float*, const bf16_t*, int, bf16_t*, int, int, int, int, int,
                           int, float, hipStream_t);
+int linear_ts_group_bf16(int, const bf16_t* const*, const bf16_t* const*, const float* const*, bf16_t* const*, const int*, const int*, const int*,
+                         const float*, const float*, int, int, float, hipStream_t);
 int gemm_f32_conv3x3_dgrad(const float*, const float*, float*, const float*, const float*, int, int, int, int, int, int, hipStream_t);
 size_t gemm_f32_t_workspace(int, int);
 int gemm_f32_dgrad(const float*, const float*, float*, const float*, int, int, int, int, int, int, hipStream_t);
@@ -439,6 +441,25 @@ int master_linear_ln_fwd(const void* x, const float* ln_gamma, const float* ln_b
     const int rc = linear_ts_bf16((const bf16_t*)x, ln_gamma, ln_beta, (const bf16_t*)w, (const float*)bias, (const bf16_t*)r1,
                                   (const bf16_t*)r2, (bf16_t*)out, M, N, K, ldx, ldr, ldo, eps, s);
     if (rc == MASTER_ERR_UNSUPPORTED) master_set_error("linear_ln: shape M=%d N=%d K=%d not covered by the fused kernel", M, N, K);
+    return rc;
+}
+
+int master_linear_group_fwd(int n, const void* const* x, const void* const* w, const void* const* bias, void* const* out, const int* N,
+                            const int* ldx, const int* ldo, const float* ln_gamma, const float* ln_beta, int M, int K, float eps, int dtype,
+                            master_stream_t stream) {
+    REQUIRE(n >= 1 && n <= 3 && x && w && bias && out && N && ldx && ldo, "linear_group: 1..3 problems, non-null tables");
+    REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), "linear_group: ln_gamma and ln_beta come together");
+    REQUIRE(M > 0 && K > 0, "linear_group: bad dims");
+    if (dtype != MASTER_BF16) { master_set_error("linear_group: bf16 only (the fp32 mode launches master_linear_fwd per problem)"); return MASTER_ERR_UNSUPPORTED; }
+    for (int i = 0; i < n; ++i) {
+        REQUIRE(x[i] && w[i] && out[i] && N[i] > 0 && ldx[i] >= K && ldo[i] >= N[i], "linear_group: problem %d: null operand or bad leading dimension", i);
+        REQUIRE(al16(x[i]) && al16(w[i]) && ldx[i] % 8 == 0 && ldo[i] % 4 == 0, "linear_group: problem %d: alignment", i);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_LINEAR, s);
+    const int rc = linear_ts_group_bf16(n, (const bf16_t* const*)x, (const bf16_t* const*)w, (const float* const*)bias, (bf16_t* const*)out, N, ldx,
+                                        ldo, ln_gamma, ln_beta, M, K, eps, s);
+    if (rc == MASTER_ERR_UNSUPPORTED) master_set_error("linear_group: shapes (K=%d) not covered by the token-stationary kernel", K);
     return rc;
 }
 

@@ -29,6 +29,12 @@ struct LinArgs {
     int mH, mW, mC;              // PatchMerging gather: x is NHWC [B, mH, mW, mC] and row m = the 2x2 neighbourhood (K = 4 mC); 0 = off
 };
 
+// up to three independent problems of one shape class (same M, K; N per problem) in ONE launch: blockIdx.y picks the problem
+// (r03: the K | V_scale | V_shift projections that feed the sigma/mu attention, and q|k + v of the StyleEncoder's Scale / Shift
+// call - each a 13-us one-tile-per-CU launch on its own)
+constexpr int MAXG = 3;
+struct LinGroup { LinArgs g[MAXG]; };
+
 union Frag { u32x4 u; bf16x8_t b; };
 
 constexpr int SLOT = 32768, RING = 3, AHEAD = 2;
@@ -39,8 +45,16 @@ constexpr int STAGE = 32768;     // epilogue staging: 8 waves x [32 tokens][32 c
 #define LGKM_WAIT(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 // NW = 8 waves (K <= 256), or 4 (K = 512: the X row alone is 128 registers, which leaves no room for two waves per SIMD)
-template <int K, bool RES, int NW>
-__global__ __launch_bounds__(NW * 64) void linear_ts_bf16_kernel(LinArgs p) {
+template <bool GROUP> struct KArgs { typedef LinArgs type; };
+template <> struct KArgs<true> { typedef LinGroup type; };
+__device__ __forceinline__ const LinArgs& pick(const LinArgs& a) { return a; }
+__device__ __forceinline__ const LinArgs& pick(const LinGroup& a) { return a.g[blockIdx.y]; }
+
+// GROUP: the kernel argument is a LinGroup and blockIdx.y picks the problem (kept out of the single-problem instantiations: indexing
+// the argument block costs the residual variants enough registers to spill)
+template <int K, bool RES, int NW, bool GROUP>
+__global__ __launch_bounds__(NW * 64) void linear_ts_bf16_kernel(typename KArgs<GROUP>::type karg) {
+    const LinArgs& p = pick(karg);
     constexpr int NTHREADS = NW * 64;
     constexpr int DMA_PER_STEP = 32 / NW;       // one-KB LDS-DMA pieces per wave per 32-KB step
     constexpr int TPW = 16 / NW;                // 32-column tiles per wave per 128-column chunk (4 or 2)
@@ -253,9 +267,21 @@ int launch(const LinArgs& p, hipStream_t s) {
     constexpr int NW = K <= 256 ? 8 : 4;
     const size_t lds = (size_t)RING * SLOT + STAGE + (size_t)(p.N + 2 * K) * sizeof(float);
     static LdsLimit lds_limit;
-    lds_limit.ensure((const void*)linear_ts_bf16_kernel<K, RES, NW>, (int)((int)lds));
-    hipLaunchKernelGGL((linear_ts_bf16_kernel<K, RES, NW>), dim3((p.M + 127) / 128), dim3(NW * 64), lds, s, p);
+    lds_limit.ensure((const void*)linear_ts_bf16_kernel<K, RES, NW, false>, (int)((int)lds));
+    hipLaunchKernelGGL((linear_ts_bf16_kernel<K, RES, NW, false>), dim3((p.M + 127) / 128), dim3(NW * 64), lds, s, p);
     return master_check_launch("linear_ts_bf16");
+}
+
+template <int K>
+int launch_group(const LinGroup& grp, int n, hipStream_t s) {
+    constexpr int NW = 8;
+    int nmax = 0;
+    for (int i = 0; i < n; ++i) nmax = grp.g[i].N > nmax ? grp.g[i].N : nmax;
+    const size_t lds = (size_t)RING * SLOT + STAGE + (size_t)(nmax + 2 * K) * sizeof(float);
+    static LdsLimit lds_limit;
+    lds_limit.ensure((const void*)linear_ts_bf16_kernel<K, false, NW, true>, (int)((int)lds));
+    hipLaunchKernelGGL((linear_ts_bf16_kernel<K, false, NW, true>), dim3((grp.g[0].M + 127) / 128, n), dim3(NW * 64), lds, s, grp);
+    return master_check_launch("linear_ts_bf16 (group)");
 }
 
 }  // namespace
@@ -271,4 +297,17 @@ int linear_ts_bf16(const bf16_t* x, const float* ln_g, const float* ln_b, const 
     if (K == 128) return res ? launch<128, true>(p, s) : launch<128, false>(p, s);
     if (K == 256) return res ? launch<256, true>(p, s) : launch<256, false>(p, s);
     return res ? launch<512, true>(p, s) : launch<512, false>(p, s);
+}
+
+// n (<= 3) problems out_i[M, N_i] = LN?(x_i) . W_i^T + bias_i in one launch; same M and K, no residual operands.
+// MASTER_ERR_UNSUPPORTED outside the token-stationary kernel's shapes (the caller then launches them one by one).
+int linear_ts_group_bf16(int n, const bf16_t* const* x, const bf16_t* const* w, const float* const* bias, bf16_t* const* out, const int* N,
+                         const int* ldx, const int* ldo, const float* ln_g, const float* ln_b, int M, int K, float eps, hipStream_t s) {
+    if (n < 1 || n > MAXG || (K != 128 && K != 256)) return MASTER_ERR_UNSUPPORTED;
+    LinGroup grp{};
+    for (int i = 0; i < n; ++i) {
+        if (N[i] % 128 != 0 || N[i] > 1024) return MASTER_ERR_UNSUPPORTED;
+        grp.g[i] = LinArgs{x[i], ln_g, ln_b, w[i], bias[i], nullptr, nullptr, out[i], M, N[i], ldx[i], 0, ldo[i], eps, 0, 0, 0};
+    }
+    return K == 128 ? launch_group<128>(grp, n, s) : launch_group<256>(grp, n, s);
 }

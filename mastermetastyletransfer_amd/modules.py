@@ -206,22 +206,31 @@ class ShiftedWindowAttention(_WindowAttentionBase):
                     memo.append((t, o))
                     return o
                 xq, xk, xvs = ln(xq), ln(xk), [ln(v) for v in xvs]
-            if xq is xk:
-                qk = ops.linear(xq, self._w("qk", self.Wq.weight, self.Wk.weight), self._b("qk", self.Wq.bias, self.Wk.bias))
-                q, k = qk[:, :C], qk[:, C:]
-            else:
-                q = ops.linear(xq, self._w("q", self.Wq.weight), self._b("q", self.Wq.bias))
-                k = ops.linear(xk, self._w("k", self.Wk.weight), self._b("k", self.Wk.bias))
-            vs, uniq, seen = [], [], []
+            uniq, seen = [], []
             for v in xvs:
                 for i, s in enumerate(seen):
                     if s is v:
                         uniq.append(i)
                         break
                 else:
+                    uniq.append(len(seen))
                     seen.append(v)
-                    uniq.append(len(vs))
-                    vs.append(ops.linear(v, self._w("v", self.Wv.weight), self._b("v", self.Wv.bias)))
+            wv, bv = self._w("v", self.Wv.weight), self._b("v", self.Wv.bias)
+            # the projections of this call read different inputs but are independent: one grouped launch (q|k + v, or q, k, v) when
+            # there are at most three of them
+            if xq is xk:
+                probs = [(xq, self._w("qk", self.Wq.weight, self.Wk.weight), self._b("qk", self.Wq.bias, self.Wk.bias))]
+            else:
+                probs = [(xq, self._w("q", self.Wq.weight), self._b("q", self.Wq.bias)), (xk, self._w("k", self.Wk.weight), self._b("k", self.Wk.bias))]
+            probs += [(v, wv, bv) for v in seen]
+            if len(probs) <= 3:
+                outs_ = ops.linear_group([p_[0] for p_ in probs], [p_[1] for p_ in probs], [p_[2] for p_ in probs])
+            else:
+                outs_ = [ops.linear(*p_) for p_ in probs]
+            if xq is xk:
+                q, k, vs = outs_[0][:, :C], outs_[0][:, C:], outs_[1:]
+            else:
+                q, k, vs = outs_[0], outs_[1], outs_[2:]
         if len(vs) > 2:
             raise NotImplementedError("at most two value streams per attention call")
         kp, vp = self._row("k", self.Wk.bias), self._row("v", self.Wv.bias)
@@ -357,7 +366,10 @@ class ShiftedWindowAttention_for_decoder_last_MHA(_WindowAttentionBase):
         if not self.use_Key_instance_norm_after_linear_transformation:
             xk, _ = ops.instnorm(xk, B, T)                                          # :470-472
             xk = aff(xk, nk, "ink")
-        k = ops.linear(xk, self._w("k", self.Wk.weight), self._b("k", self.Wk.bias))
+        # Wk . Key | Wv_scale . Scale | Wv_shift . Shift  (:515-517): three inputs, three weights, one grouped launch
+        k, vs, vsh = ops.linear_group([xk, xs, xsh],
+                                      [self._w("k", self.Wk.weight), self._w("vs", self.Wv_scale.weight), self._w("vsh", self.Wv_shift.weight)],
+                                      [self._b("k", self.Wk.bias), self._b("vs", self.Wv_scale.bias), self._b("vsh", self.Wv_shift.bias)])
         k_pad = self._row("k", self.Wk.bias)
         if self.use_Key_instance_norm_after_linear_transformation:
             # :520-530  statistics over the zero-padded pH x pW map: its padded slots hold Wk.bias
@@ -366,8 +378,6 @@ class ShiftedWindowAttention_for_decoder_last_MHA(_WindowAttentionBase):
             k = aff(k, nk, "ink")
             if k_pad_b is not None:
                 k_pad = k_pad_b if nk is None else aff(k_pad_b.contiguous(), nk, "ink")
-        vs = ops.linear(xs, self._w("vs", self.Wv_scale.weight), self._b("vs", self.Wv_scale.bias))
-        vsh = ops.linear(xsh, self._w("vsh", self.Wv_shift.weight), self._b("vsh", self.Wv_shift.bias))
         o_s, o_sh = self._core(q, k, [vs, vsh], k_pad, [self._row("vs", self.Wv_scale.bias), self._row("vsh", self.Wv_shift.bias)], B, H, W)
         pw, pb = self._w("proj", self.proj.weight), self._b("proj", self.proj.bias)
         mu = ops.linear(o_sh, pw, pb)                                               # :594-595

@@ -23,7 +23,7 @@ K_FAMILIES = ("linear", "conv3x3", "window_attn", "layernorm", "instnorm", "patc
 EXPORTS = (
     "master_version", "master_last_error_string", "master_linear_fwd", "master_conv3x3_reflect_fwd",
     "master_window_attn_fwd", "master_layernorm_fwd", "master_instnorm_fwd", "master_patch_embed_fwd",
-    "master_patch_merge_ln_fwd", "master_patch_merge_linear_fwd", "master_resize_plan", "master_preprocess_fwd", "master_postprocess_fwd", "master_image_to_nhwc_fwd", "master_conv3x3_zero_fwd", "master_maxpool2x2_fwd", "master_channel_stats_fwd", "master_stats_slices", "master_instnorm_distance_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_linear_ln_fwd", "master_attn_block_fwd", "master_window_attn_proj_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
+    "master_patch_merge_ln_fwd", "master_patch_merge_linear_fwd", "master_resize_plan", "master_preprocess_fwd", "master_postprocess_fwd", "master_image_to_nhwc_fwd", "master_conv3x3_zero_fwd", "master_maxpool2x2_fwd", "master_channel_stats_fwd", "master_stats_slices", "master_instnorm_distance_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_linear_ln_fwd", "master_attn_block_fwd", "master_window_attn_proj_fwd", "master_linear_group_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
     # train step
     "master_linear_act_fwd", "master_linear_dgrad", "master_linear_wgrad", "master_gemm_workspace_floats", "master_colsum",
     "master_colsum_workspace_floats", "master_reduce_slabs", "master_layernorm_bwd", "master_layernorm_bwd_workspace_floats",
@@ -99,6 +99,7 @@ def load_library() -> ctypes.CDLL:
     lib.master_linear_ln_fwd.argtypes = [vp] * 8 + [ci] * 6 + [cf, ci, vp]
     lib.master_attn_block_fwd.argtypes = [vp] * 11 + [ci] * 6 + [cf, cf, ci, vp]
     lib.master_decoder_tail_fwd.argtypes = [vp] * 6 + [ci] * 4 + [vp]
+    lib.master_linear_group_fwd.argtypes = [ci] + [vp] * 9 + [ci, ci, cf, ci, vp]
     lib.master_window_attn_proj_fwd.argtypes = [vp] * 3 + [ci] * 3 + [vp] * 2 + [ci] * 2 + [vp] * 6 + [ci, vp, ci] + [ci] * 5 + [cf, ci, vp]
     lib.master_prof_read.argtypes = [ci, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]
     # ---- train step ----
@@ -236,6 +237,30 @@ def linear_ln(x: torch.Tensor, ln_gamma: torch.Tensor, ln_beta: torch.Tensor, w:
                                                     _dt(x), _stream()), "master_linear_ln_fwd")
         return out
     return linear(layernorm(x, ln_gamma, ln_beta, eps), w, bias, r2=r2)
+
+
+@_on_device
+def linear_group(xs: Sequence[torch.Tensor], ws: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]]) -> list:
+    """[x_i @ w_i.T + bias_i] for up to three problems with the same M and K in ONE launch (bf16, token-stationary kernel); falls back to
+    one linear() per problem when the shapes are outside it."""
+    n = len(xs)
+    M, K = xs[0].shape
+    grouped = (1 < n <= 3 and xs[0].dtype == torch.bfloat16 and K in (128, 256) and os.environ.get("MASTER_LINEAR_GROUP", "1") != "0"
+               and all(x.shape == (M, K) and x.stride(1) == 1 and x.dtype == torch.bfloat16 for x in xs)
+               and all(w.shape[1] == K and w.shape[0] % 128 == 0 and w.shape[0] <= 1024 and w.is_contiguous() for w in ws))
+    if not grouped:
+        return [linear(x, w, b) for x, w, b in zip(xs, ws, biases)]
+    _dev(*xs, *ws)
+    outs = [torch.empty((M, w.shape[0]), dtype=xs[0].dtype, device=xs[0].device) for w in ws]
+    arr = lambda ts: (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
+    ints = lambda vs: (ctypes.c_int * n)(*vs)
+    if _COUNT_ON:
+        for x, w in zip(xs, ws):
+            _count("linear", flops=2.0 * M * w.shape[0] * K, bytes=x.element_size() * (M * K + w.numel() + M * w.shape[0]))
+    _check(load_library().master_linear_group_fwd(n, arr(xs), arr(ws), arr(biases), arr(outs), ints([w.shape[0] for w in ws]),
+                                                   ints([x.stride(0) for x in xs]), ints([o.stride(0) for o in outs]), None, None, M, K,
+                                                   1e-5, _dt(xs[0]), _stream()), "master_linear_group_fwd")
+    return outs
 
 
 def mlp_fused_supported(x: torch.Tensor, hidden: int) -> bool:
