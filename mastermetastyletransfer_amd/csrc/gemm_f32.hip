@@ -468,52 +468,73 @@ int launch(const GemmArgs& p, hipStream_t s) {
 // (COUT x 288 floats) sit in LDS and are read as wave-wide broadcasts.  Same reflect / upsample / zero-pad index rules as the gather
 // above; fp32 FMA chains (exact products, a different summation order than the MFMA's: ~1e-6).
 // ---------------------------------------------------------------------------------------------------------------------------------
+// Tile form: a workgroup owns a 16 x 16 block of output pixels; the (16 + 2) x (16 + 2) source pixels it needs (after reflect / upsample
+// index math; zero rows for out-of-image taps of a zero-padded convolution) are copied ONCE into LDS with coalesced 16-byte loads -
+// pixel rows padded to Cin + 4 floats, so that the 16 lanes of a ds_read_b128 group (16 neighbouring pixels) hit 16 distinct bank
+// groups - and every thread then reads its nine taps from LDS instead of 72 strided 16-byte global loads (267 us as a direct
+// global-memory convolution: the texture path, not HBM, bounded it).
 template <int COUT>
 __global__ __launch_bounds__(256) void conv3x3_small_cout_kernel(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];            // [COUT][9][Cin]
-    const int K = 9 * p.Cin;
-    for (int i = threadIdx.x; i < COUT * K; i += 256) wl[i] = p.w[i];
-    __syncthreads();
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= p.M) return;
-    const int hw = p.Hout * p.Wout;
-    const int b = m / hw, pix = m - b * hw, y = pix / p.Wout, x = pix - y * p.Wout;
+    extern __shared__ __attribute__((aligned(16))) float sm[];            // halo tile [18][18][Cin + 4]
+    const int K = 9 * p.Cin, PS = p.Cin + 4;
+    float* tile = sm;
+    const int tiles_x = (p.Wout + 15) >> 4, tiles_y = (p.Hout + 15) >> 4;
+    const int b = blockIdx.x / (tiles_x * tiles_y), t = blockIdx.x - b * (tiles_x * tiles_y);
+    const int y0 = (t / tiles_x) << 4, x0 = (t % tiles_x) << 4;
     const int Hs = p.Hin << p.up, Ws = p.Win << p.up;
+    const int c4n = p.Cin >> 2;                                           // 16-byte chunks per pixel
+    for (int i = threadIdx.x; i < 18 * 18 * c4n; i += 256) {
+        const int pix = i / c4n, c4 = i - pix * c4n;
+        const int yy = y0 + pix / 18 - 1, xx = x0 + pix % 18 - 1;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const bool outside = (unsigned)yy >= (unsigned)Hs || (unsigned)xx >= (unsigned)Ws;
+        if (!(p.zero_pad && outside) && yy >= -1 && xx >= -1 && yy <= Hs && xx <= Ws) {
+            const int sy = reflect1(yy, Hs) >> p.up, sx = reflect1(xx, Ws) >> p.up;
+            if ((unsigned)sy < (unsigned)p.Hin && (unsigned)sx < (unsigned)p.Win)
+                v = *(const f32x4*)(p.a + ((size_t)(b * p.Hin + sy) * p.Win + sx) * p.Cin + c4 * 4);
+        }
+        *(f32x4*)(tile + pix * PS + c4 * 4) = v;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
+    const int y = y0 + ly, x = x0 + lx;
     float acc[COUT];
 #pragma unroll
     for (int co = 0; co < COUT; ++co) acc[co] = p.bias ? p.bias[co] : 0.0f;
+#pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-        if (p.zero_pad && ((unsigned)yy >= (unsigned)Hs || (unsigned)xx >= (unsigned)Ws)) continue;
-        const int sy = reflect1(yy, Hs) >> p.up, sx = reflect1(xx, Ws) >> p.up;
-        const float* src = p.a + ((size_t)(b * p.Hin + sy) * p.Win + sx) * p.Cin;
-        const float* wt = wl + tap * p.Cin;
+        const float* src = tile + ((ly + tap / 3) * 18 + lx + tap % 3) * PS;
+        const float* wt = p.w + tap * p.Cin;                              // wave-uniform addresses: scalar loads, the weight is an SGPR operand of the FMA
+#pragma unroll 8
         for (int c = 0; c < p.Cin; c += 4) {
             const f32x4 xv = *(const f32x4*)(src + c);
 #pragma unroll
             for (int co = 0; co < COUT; ++co) {
-                const f32x4 wv = *(const f32x4*)(wt + co * K + c);       // same address in every lane: LDS broadcast
+                const f32x4 wv = *(const f32x4*)(wt + co * K + c);
                 acc[co] = fmaf(xv[0], wv[0], acc[co]); acc[co] = fmaf(xv[1], wv[1], acc[co]);
                 acc[co] = fmaf(xv[2], wv[2], acc[co]); acc[co] = fmaf(xv[3], wv[3], acc[co]);
             }
         }
     }
+    if (y >= p.Hout || x >= p.Wout) return;
+    const int hw = p.Hout * p.Wout, pix = y * p.Wout + x;
 #pragma unroll
     for (int co = 0; co < COUT; ++co) {
         float v = acc[co];
         if (p.act == MASTER_ACT_GELU) v = gelu_erf(v);
         else if (p.act == MASTER_ACT_RELU) v = fmaxf(v, 0.0f);
         if (p.out_nchw) p.out[((size_t)b * COUT + co) * hw + pix] = v;
-        else p.out[(size_t)m * p.ldo + co] = v;
+        else p.out[((size_t)b * hw + pix) * p.ldo + co] = v;
     }
 }
 
 template <int COUT>
 int launch_small_cout(const GemmArgs& p, hipStream_t s) {
-    const size_t lds = (size_t)COUT * 9 * p.Cin * sizeof(float);
+    const size_t lds = (size_t)18 * 18 * (p.Cin + 4) * sizeof(float);
+    const int B = p.M / (p.Hout * p.Wout);
     static LdsLimit lds_limit;
     lds_limit.ensure((const void*)conv3x3_small_cout_kernel<COUT>, (int)lds);
-    hipLaunchKernelGGL(conv3x3_small_cout_kernel<COUT>, dim3((p.M + 255) / 256), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(conv3x3_small_cout_kernel<COUT>, dim3(B * ((p.Hout + 15) / 16) * ((p.Wout + 15) / 16)), dim3(256), lds, s, p);
     return master_check_launch("conv3x3_small_cout");
 }
 
@@ -533,7 +554,7 @@ static int gemm_small64() {
 template <bool CONV>
 int dispatch(const GemmArgs& p, hipStream_t s) {
     if (CONV && p.N <= 4 && p.N >= 1 && gemm_variant() == 1 && !p.r1 && !p.r2 && !p.aux && !p.mask_relu && p.off == 0 && (p.Cin & 3) == 0 &&
-        p.Cin <= 1024 && (((uintptr_t)p.a) & 15) == 0) {
+        p.Cin <= 96 && (((uintptr_t)p.a) & 15) == 0) {
         switch (p.N) {
             case 1: return launch_small_cout<1>(p, s);
             case 2: return launch_small_cout<2>(p, s);
