@@ -65,7 +65,11 @@ def test_linear_epilogues_and_strides(cuda):
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,up,relu,nchw", [(2, 8, 8, 256, 128, False, True, False), (1, 8, 8, 128, 128, True, True, False),
                                                           (2, 5, 7, 64, 64, True, True, False), (1, 16, 16, 64, 32, False, True, False),
-                                                          (2, 12, 10, 32, 3, False, False, True), (1, 2, 2, 32, 32, False, False, False)])
+                                                          (2, 12, 10, 32, 3, False, False, True), (1, 2, 2, 32, 32, False, False, False),
+                                                          # <= 4 output channels: the direct convolution (16 x 16 pixel tiles with a halo in LDS): partial
+                                                          # tiles, upsample folded into the tile gather, NHWC and NCHW outputs, 1..4 channels
+                                                          (1, 40, 24, 32, 3, True, True, False), (2, 17, 33, 64, 4, False, True, True),
+                                                          (1, 16, 16, 32, 1, False, False, False), (3, 5, 3, 96, 2, True, False, True)])
 def test_conv3x3_reflect(cuda, B, H, W, Cin, Cout, up, relu, nchw):
     from mastermetastyletransfer_amd import ops
     g = torch.Generator().manual_seed(H * 31 + Cout)
@@ -78,6 +82,19 @@ def test_conv3x3_reflect(cuda, B, H, W, Cin, Cout, up, relu, nchw):
     out = ops.conv3x3_reflect(x.permute(0, 2, 3, 1).contiguous().to(cuda), w.permute(0, 2, 3, 1).contiguous().to(cuda),
                               b.to(cuda), up, relu, out_nchw=nchw)
     assert_close(out if nchw else out.permute(0, 3, 1, 2), ref, "conv3x3", 1e-4)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 20, 12, 32, 3), (1, 16, 48, 64, 4), (1, 9, 9, 64, 128)])
+def test_conv3x3_zero_padding(cuda, B, H, W, Cin, Cout):
+    """nn.Conv2d(padding=1) + ReLU (the VGG-19 layers of the loss network) incl. the <= 4-channel direct form with zero rows for
+    out-of-image taps"""
+    from mastermetastyletransfer_amd import ops
+    g = torch.Generator().manual_seed(H * 13 + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    out = ops.conv3x3_zero(x.permute(0, 2, 3, 1).contiguous().to(cuda), w.permute(0, 2, 3, 1).contiguous().to(cuda), b.to(cuda), relu=True)
+    assert_close(out.permute(0, 3, 1, 2), F.relu(F.conv2d(x, w, b, padding=1)), "conv3x3 zero pad", 1e-4)
 
 
 @pytest.mark.parametrize("M,C", [(100, 128), (33, 256), (7, 512), (5, 1024), (64, 64)])
