@@ -200,14 +200,17 @@ __global__ __launch_bounds__(256) void instnorm_reg_kernel(const T* __restrict__
     }
 }
 
-template <typename T>
+// STRIP = channels per workgroup (32, or 16 when 32-channel strips would leave CUs idle: the 64x64 maps of 512x512 images at batch 16
+// make 128 strips of 32 on 256 CUs - r03: 151 us per launch of the fp32 mode's BASELINE config 5)
+template <typename T, int STRIP>
 __global__ __launch_bounds__(256) void instnorm_kernel(const T* __restrict__ x, T* __restrict__ out,
                                                        const T* __restrict__ pad_in, T* __restrict__ pad_out, int Tn,
                                                        int C, int n_pad, float eps, int repeat) {
-    __shared__ f32x4 red[32][8];
-    const int strips = C >> 5;
-    const int b = blockIdx.x / strips, c0 = (blockIdx.x % strips) * 32;
-    const int cq = threadIdx.x & 7, tg = threadIdx.x >> 3;
+    constexpr int CQ = STRIP / 4, TG = 256 / CQ;                         // 4-channel vectors per strip, token groups
+    __shared__ f32x4 red[TG][CQ];
+    const int strips = C / STRIP;
+    const int b = blockIdx.x / strips, c0 = (blockIdx.x % strips) * STRIP;
+    const int cq = threadIdx.x % CQ, tg = threadIdx.x / CQ;
     const T* xb = x + (size_t)b * Tn * C + c0 + cq * 4;
     T* ob = out + (size_t)b * Tn * C + c0 + cq * 4;
     f32x4 pr = {0.f, 0.f, 0.f, 0.f};
@@ -218,19 +221,19 @@ __global__ __launch_bounds__(256) void instnorm_kernel(const T* __restrict__ x, 
         red[tg][cq] = v;
         __syncthreads();
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < 32; ++i) s += red[i][cq];
+        for (int i = 0; i < TG; ++i) s += red[i][cq];
         __syncthreads();
         return s;
     };
 
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int t = tg; t < Tn; t += 32) acc += Vec4<T>::load(xb + (size_t)t * C);
+    for (int t = tg; t < Tn; t += TG) acc += Vec4<T>::load(xb + (size_t)t * C);
     f32x4 mean = block_sum(acc);
 #pragma unroll
     for (int e = 0; e < 4; ++e) mean[e] = (mean[e] + (float)n_pad * pr[e]) / cnt;
 
     acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int t = tg; t < Tn; t += 32) {
+    for (int t = tg; t < Tn; t += TG) {
         const f32x4 d = Vec4<T>::load(xb + (size_t)t * C) - mean;
         acc += d * d;
     }
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256) void instnorm_kernel(const T* __restrict__ x, 
         rstd[e] = rsqrtf(vr + eps);
         if (repeat == 2) rstd[e] *= rsqrtf(vr * rstd[e] * rstd[e] + eps);
     }
-    for (int t = tg; t < Tn; t += 32)
+    for (int t = tg; t < Tn; t += TG)
         Vec4<T>::store(ob + (size_t)t * C, (Vec4<T>::load(xb + (size_t)t * C) - mean) * rstd);
     if (n_pad > 0 && pad_out && tg == 0)
         Vec4<T>::store(pad_out + (size_t)b * C + c0 + cq * 4, (pr - mean) * rstd);
@@ -442,8 +445,11 @@ int instnorm_launch(const void* x, void* out, const void* pad_in, void* pad_out,
     else if (Tn <= TG * 32 && sizeof(T) == 4)      // fp32: 32 rows x 4 values per thread
         hipLaunchKernelGGL((instnorm_reg_kernel<T, 32>), dim3(B * (C / 32)), dim3(256), 0, s, (const T*)x, (T*)out,
                            (const T*)pad_in, (T*)pad_out, Tn, C, n_pad, eps, repeat);
+    else if (B * (C / 32) < 256 && C % 16 == 0)          // fewer 32-channel strips than CUs: 16-channel strips double the workgroups
+        hipLaunchKernelGGL((instnorm_kernel<T, 16>), dim3(B * (C / 16)), dim3(256), 0, s, (const T*)x, (T*)out,
+                           (const T*)pad_in, (T*)pad_out, Tn, C, n_pad, eps, repeat);
     else
-        hipLaunchKernelGGL((instnorm_kernel<T>), dim3(B * (C / 32)), dim3(256), 0, s, (const T*)x, (T*)out,
+        hipLaunchKernelGGL((instnorm_kernel<T, 32>), dim3(B * (C / 32)), dim3(256), 0, s, (const T*)x, (T*)out,
                            (const T*)pad_in, (T*)pad_out, Tn, C, n_pad, eps, repeat);
     return master_check_launch("instnorm");
 }

@@ -105,7 +105,8 @@ def test_layernorm(cuda, M, C):
     assert_close(ops.layernorm(x.to(cuda), w.to(cuda), b.to(cuda)), F.layer_norm(x, (C,), w, b, 1e-5), "layernorm", 1e-5)
 
 
-@pytest.mark.parametrize("B,T,C,n_pad", [(2, 81, 64, 0), (3, 1024, 256, 0), (2, 81, 64, 115), (1, 1024, 256, 201)])
+@pytest.mark.parametrize("B,T,C,n_pad", [(2, 81, 64, 0), (3, 1024, 256, 0), (2, 81, 64, 115), (1, 1024, 256, 201),
+                                          (2, 4096, 256, 0), (1, 4096, 256, 804), (40, 2000, 256, 0)])   # streaming form: 16- and 32-channel strips
 def test_instnorm(cuda, B, T, C, n_pad):
     from mastermetastyletransfer_amd import ops
     g = torch.Generator().manual_seed(T + n_pad)
