@@ -136,7 +136,10 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
             const int slot = 4 * I + (lane >> 4);
             int idx = src[slot];
             idx = idx < 0 ? 0 : idx;                                       // padded slots are zeroed in the LN phase
-            const bf16_t* sp = p.x + ((size_t)b * p.T + idx) * C + (lane & 15) * 8;
+            // r03: source-swizzled like the working tile (LDS position c of a row holds source chunk c ^ (slot & 15)): the residual reads
+            // of the epilogue (32 lanes = 32 rows, one 8-byte piece each) were a 32-way bank conflict on the linear tile (rows are
+            // 256 B = all 64 banks apart), 12.8 % of the kernel's wave cycles in SQ_LDS_BANK_CONFLICT; now 2-way
+            const bf16_t* sp = p.x + ((size_t)b * p.T + idx) * C + ((lane & 15) ^ (slot & 15)) * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
                                              (__attribute__((address_space(3))) void*)(lds + XRAW + buf * 64 * ROWB + I * 1024), 16, 0, 0);
         }
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
             float v[32];
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
-                const u32x4 u = *(const u32x4*)(raw + lrow * ROWB + lq * 64 + c4 * 16);
+                const u32x4 u = *(const u32x4*)(raw + lrow * ROWB + (((lq * 4 + c4) ^ (lrow & 15)) << 4));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[c4 * 8 + 2 * e] = __uint_as_float(u[e] << 16); v[c4 * 8 + 2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); }
             }
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(256, 1) void attn_block_c128_kernel(BlockArgs p) {
             const size_t off = (tok0 + idx) * C + wave * 32 + 4 * h;
             u32x2 res[4];                                                  // residual = the raw row still sitting in LDS
 #pragma unroll
-            for (int g = 0; g < 4; ++g) res[g] = *(const u32x2*)(raw + slot * ROWB + (wave * 32 + 4 * h + 8 * g) * 2);
+            for (int g = 0; g < 4; ++g) res[g] = *(const u32x2*)(raw + slot * ROWB + (((wave * 4 + g) ^ (slot & 15)) << 4) + 8 * h);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 u32x2 o;
