@@ -41,6 +41,13 @@ constexpr int SLOT = 32768, RING = 3, AHEAD = 2;
 constexpr int STAGE = 32768;     // epilogue staging: 8 waves x [32 tokens][32 channels] fp32
 
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#ifdef LIN_CLOCK_PROBE   // diagnostic build only (profiles/probes/linear_probe.hip): s_memtime sections of wave 0
+#define LPROBE_MARK() do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); probe_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define LPROBE_ADD(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); probe_sec[i] += t_ - probe_last; probe_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define LPROBE_MARK() do {} while (0)
+#define LPROBE_ADD(i) do {} while (0)
+#endif
 #define LDS_READ128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:" #imm : "=v"(dst) : "v"(addr))
 #define LGKM_WAIT(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
@@ -55,6 +62,11 @@ __device__ __forceinline__ const LinArgs& pick(const LinGroup& a) { return a.g[b
 template <int K, bool RES, int NW, bool GROUP>
 __global__ __launch_bounds__(NW * 64) void linear_ts_bf16_kernel(typename KArgs<GROUP>::type karg) {
     const LinArgs& p = pick(karg);
+#ifdef LIN_CLOCK_PROBE
+    unsigned long long probe_sec[6] = {0, 0, 0, 0, 0, 0}, probe_last = 0;
+    const unsigned long long probe_t0 = __builtin_amdgcn_s_memtime();
+    LPROBE_MARK();
+#endif
     constexpr int NTHREADS = NW * 64;
     constexpr int DMA_PER_STEP = 32 / NW;       // one-KB LDS-DMA pieces per wave per 32-KB step
     constexpr int TPW = 16 / NW;                // 32-column tiles per wave per 128-column chunk (4 or 2)
@@ -88,8 +100,26 @@ __global__ __launch_bounds__(NW * 64) void linear_ts_bf16_kernel(typename KArgs<
                                              (__attribute__((address_space(3))) void*)(slot + i * 1024), 16, 0, 0);
         }
     };
+    // K <= 256 (r03): the X tile itself comes in by LDS-DMA - whole rows per piece, each row once per workgroup - into ring slots 1 (and 2),
+    // which the weight stream does not need yet, and the fragments are read back from LDS.  The r02 form loaded the fragments straight
+    // from global memory: 16 instructions per wave, each touching 32 rows (lane = token), and both waves of a band loaded the same rows:
+    // the prologue was 43 % of the kernel (profiles/r03_linear_probe_mi355x.txt).
+    const bool XDMA = K <= 256 && p.mC == 0;
     int t_issue = 0;
-    for (; t_issue < AHEAD && t_issue < T; ++t_issue) issue(t_issue);
+    for (; t_issue < (XDMA ? 1 : AHEAD) && t_issue < T; ++t_issue) issue(t_issue);
+    if (XDMA) {
+        constexpr int RPP = 1024 / (K * 2), XPW = (128 / RPP) / NW;     // rows per 1-KB piece, pieces per wave
+        unsigned char* xs = lds + SLOT;
+#pragma unroll
+        for (int i = 0; i < XPW; ++i) {
+            const int I = wave * XPW + i;
+            const int row = I * RPP + lane / (64 / RPP), pos = lane % (64 / RPP);
+            int mm = blockIdx.x * 128 + row; mm = mm < p.M ? mm : p.M - 1;
+            const bf16_t* src = p.x + (size_t)mm * p.ldx + ((pos ^ (row & 15)) << 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(xs + I * 1024), 16, 0, 0);
+        }
+    }
 
     for (int i = tid; i < p.N; i += NTHREADS) bs[i] = p.bias ? p.bias[i] : 0.f;
     if (p.ln_g) for (int i = tid; i < K; i += NTHREADS) { lng[i] = p.ln_g[i]; lnb[i] = p.ln_b[i]; }
@@ -126,12 +156,22 @@ __global__ __launch_bounds__(NW * 64) void linear_ts_bf16_kernel(typename KArgs<
                 xf[s].u = *(const u32x4*)(px + ((size_t)(q & 1) * p.mW + (q >> 1)) * p.mC + c);
             }
         } else {
-            const bf16_t* xp = p.x + (size_t)mc * p.ldx + 8 * h;
+            if (XDMA) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's X pieces (and weight step 0, residual values) have landed
+                __builtin_amdgcn_s_barrier();
+                const int row = band * 32 + r;
+                const unsigned char* xr = lds + SLOT + row * (K * 2);
 #pragma unroll
-            for (int s = 0; s < KS; ++s) xf[s].u = *(const u32x4*)(xp + 16 * s);
+                for (int s = 0; s < KS; ++s) xf[s].u = *(const u32x4*)(xr + (((2 * s + h) ^ (row & 15)) << 4));
+            } else {
+                const bf16_t* xp = p.x + (size_t)mc * p.ldx + 8 * h;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) xf[s].u = *(const u32x4*)(xp + 16 * s);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();                                        // parameter vectors visible; with XDMA: every wave has its X fragments, slots 1.. are free
+        if (XDMA) for (; t_issue < AHEAD && t_issue < T; ++t_issue) issue(t_issue);
         if (p.ln_g) {
             float sum = 0.f;
 #pragma unroll
@@ -169,6 +209,7 @@ __global__ __launch_bounds__(NW * 64) void linear_ts_bf16_kernel(typename KArgs<
         }
     }
 
+    LPROBE_ADD(0);                                                       // prologue: first DMA issue, parameter vectors, residual + X loads, LayerNorm
     int t_cons = 0;
     auto begin_step = [&]() __attribute__((always_inline)) {
         // conservative count: stores of the previous chunk's epilogue are younger than every DMA, so "at most 4
@@ -177,7 +218,9 @@ __global__ __launch_bounds__(NW * 64) void linear_ts_bf16_kernel(typename KArgs<
         if (ahead >= 1) { if (DMA_PER_STEP == 8) WAIT_VMCNT(8); else WAIT_VMCNT(4); } else WAIT_VMCNT(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        LPROBE_ADD(1);                                                   // wait for the step's weights + barrier
         if (t_issue < T) { issue(t_issue); ++t_issue; }
+        LPROBE_ADD(2);                                                   // DMA issue of a later step
         const unsigned char* slot = lds + (t_cons % RING) * SLOT;
         ++t_cons;
         return slot;
@@ -256,10 +299,19 @@ __global__ __launch_bounds__(NW * 64) void linear_ts_bf16_kernel(typename KArgs<
 
     for (int nc = 0; nc < nch; ++nc) {
         zero_acc();
+        LPROBE_MARK();
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) step(begin_step(), kb);
+        for (int kb = 0; kb < KB; ++kb) { step(begin_step(), kb); LPROBE_ADD(3); }
         epilogue(nc);
+        LPROBE_ADD(4);
     }
+#ifdef LIN_CLOCK_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 && g_probe) {
+        g_probe[blockIdx.x * 8] = __builtin_amdgcn_s_memtime() - probe_t0;
+        for (int i = 0; i < 5; ++i) g_probe[blockIdx.x * 8 + 1 + i] = probe_sec[i];
+    }
+#endif
 }
 
 template <int K, bool RES>
