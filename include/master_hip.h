@@ -42,7 +42,7 @@ enum master_status {
 
 enum master_dtype { MASTER_F32 = 0, MASTER_BF16 = 1 };
 /* OR-ed into the `dtype` argument of master_linear_wgrad / master_colsum / master_layernorm_bwd: the parameter gradient is ADDED to
- * the output buffer (dw / out / dgb) instead of overwriting it - the gradient of a tensor used several times in one graph (the k
+ * the output buffer (dw and dbias / out / dgb) instead of overwriting it - the gradient of a tensor used several times in one graph (the k
  * StyleTransformer layers share their weights, style_transformer.py:1239) is summed by the kernel's own slab reduce instead of by one
  * autograd add launch per use.  Needs the workspace (at least one output-sized slab). */
 enum master_flags { MASTER_ACCUMULATE = 0x100 };
@@ -246,10 +246,12 @@ int master_linear_act_fwd(const void* a, const void* w, const void* bias, void* 
 int master_linear_dgrad(const void* g, const void* w, void* da, const void* gelu_pre, int M, int N, int K, int ldg, int ldda,
                         int ld_pre, int dtype, master_stream_t stream);
 
-/* Weight gradient of out = a . w^T:  dw[N,K] = g[M,N]^T . a[M,K] (dense, row stride K).  The contraction over the M tokens is split
- * across workgroups; ws holds the partial tiles: master_gemm_workspace_floats(N, K) floats are always enough. */
+/* Weight gradient of out = a . w^T + bias:  dw[N,K] = g[M,N]^T . a[M,K] (dense, row stride K) and, when dbias != NULL, the bias gradient
+ * dbias[N] = sum_m g[m][n] from the same pass over g (what autograd's Linear backward returns for weight and bias; MASTER_ACCUMULATE adds to
+ * both).  The contraction over the M tokens is split across workgroups; ws holds the partial tiles and row sums:
+ * master_gemm_workspace_floats(N, K) floats are always enough. */
 size_t master_gemm_workspace_floats(int rows, int cols);
-int master_linear_wgrad(const void* g, const void* a, void* dw, int M, int N, int K, int ldg, int lda, void* ws, size_t ws_floats,
+int master_linear_wgrad(const void* g, const void* a, void* dw, void* dbias, int M, int N, int K, int ldg, int lda, void* ws, size_t ws_floats,
                         int dtype, master_stream_t stream);
 
 /* out[n] = sum_m x[m][n]  (bias gradients).  N % 4 == 0; ws: master_colsum_workspace_floats(M, N) floats. */
@@ -310,8 +312,9 @@ int master_conv3x3_dgrad(const void* g, const void* wf, void* out, const void* r
 
 /* Weight gradient of the 3x3 convolutions of master_conv3x3_reflect_fwd / master_conv3x3_zero_fwd:
  * dw[Cout][3][3][Cin] = sum over output pixels of g[pix][Cout] (row stride ldg) x the gathered input patch (x: NHWC [B,Hin,Win,Cin],
- * same reflect / zero padding and upsample gather as the forward).  ws: master_gemm_workspace_floats(Cout, 9*Cin). */
-int master_conv3x3_wgrad(const void* g, const void* x, void* dw, int B, int Hin, int Win, int Cin, int Cout, int ldg, int upsample,
+ * same reflect / zero padding and upsample gather as the forward); dbias[Cout] = sum over the pixels of g (the bias gradient) when
+ * dbias != NULL.  ws: master_gemm_workspace_floats(Cout, 9*Cin). */
+int master_conv3x3_wgrad(const void* g, const void* x, void* dw, void* dbias, int B, int Hin, int Win, int Cin, int Cout, int ldg, int upsample,
                          int zero_pad, void* ws, size_t ws_floats, int dtype, master_stream_t stream);
 
 /* gm[b,p,c] = (c < C and (relu_out == NULL or relu_out[b,p,c] > 0)) ? g[b,p,c] : 0 for c < Cp: ReLU backward + channel padding.
@@ -341,14 +344,25 @@ int master_mul_add_fwd(const void* q, const void* sigma, const void* mu, void* o
 int master_mul_add_bwd(const void* g, const void* q, const void* sigma, void* dq, void* dsigma, size_t n, int dtype,
                        master_stream_t stream);
 
+/* The scalar arithmetic of one tap of the perceptual loss (codes/loss.py:112-130 content term, :272-322 style term), from the
+ * [3B,C] statistics of master_channel_stats_fwd (rows: content | style | output images) and the per-workgroup partial sums of
+ * master_instnorm_distance_fwd (n_partial of them):
+ *     losses[0] (+)= sum(dist_partial) / (B*C*HW)
+ *     losses[1] (+)= mean_{i,c} f(mean_style - mean_out) + mean_{i,c} f(std_style - std_out)     f = |.| or, squared_style, (.)^2; unbiased std
+ * ("first": overwrite instead of add - no memset needed), and the per-(image, channel) coefficients of the style term's gradient for a
+ * unit upstream gradient: coefA = d/d mean_out / HW, coefB = d/d std_out / ((HW-1) std_out) (0 where std_out = 0). */
+int master_loss_terms_fwd(const float* mean, const float* var, const float* dist_partial, int n_partial, float* losses, float* coefA, float* coefB,
+                          int B, int HW, int C, int squared_style, int first, master_stream_t stream);
+
 /* Perceptual-loss tap backward (codes/loss.py:112-130, 272-322).  x: features [3B,HW,C] of [content | style | output]; mean, var
- * [3B,C] from master_channel_stats_fwd.  dx [B,HW,C] = gradient w.r.t. the OUTPUT image's features of
- *     wc * sum |IN(x_i) - IN(x_2B+i)| (squared: (.)^2)  +  sum_p ( coefA[i,c] + coefB[i,c] * (x_2B+i - mean) )
- * (the second term carries the style loss through mean and std; coefficients [B,C] computed by the caller from the statistics);
+ * [3B,C] from master_channel_stats_fwd; coefA, coefB [B,C] from master_loss_terms_fwd.  g_content, g_style: DEVICE pointers to the upstream
+ * gradients of the two loss scalars (NULL = 0).  dx [B,HW,C] = gradient w.r.t. the OUTPUT image's features of
+ *     g_content / (B*C*HW) * sum |IN(x_i) - IN(x_2B+i)| (squared: (.)^2)  +  g_style * sum_p ( coefA[i,c] + coefB[i,c] * (x_2B+i - mean) );
  * relu_gate: zero the result where x_2B+i <= 0.  ws: master_loss_tap_workspace_floats(B, HW, C) floats. */
 size_t master_loss_tap_workspace_floats(int B, int HW, int C);
 int master_loss_tap_bwd(const void* x, const float* mean, const float* var, const float* coefA, const float* coefB, float* ws, void* dx,
-                        int B, int HW, int C, float eps, float wc, int squared, int relu_gate, int dtype, master_stream_t stream);
+                        int B, int HW, int C, float eps, const float* g_content, const float* g_style, int squared, int relu_gate, int dtype,
+                        master_stream_t stream);
 
 /* Multi-tensor optimizer steps.  table: DEVICE array of ntensors records {float* param; const float* grad; float* exp_avg;
  * float* exp_avg_sq; int64 numel; int64 first_block} (6 x 8 bytes), first_block = running sum of ceil(numel / master_adam_chunk()),

@@ -86,6 +86,34 @@ class _SharedGrads:
             return e[1]
         return None
 
+    def deliver_pair(self, token, w, b, compute):
+        """weight and bias of one Linear (counted together by `note`, so always at the same use):
+        compute(out_w, out_b, accumulate, want_w, want_b) -> (dw, db), one launch for both.  Returns (dw, db) as `deliver` would for each."""
+        live = token is not None and token is self.graph
+        ew, eb = (self.uses.get(id(w)), self.uses.get(id(b))) if live else (None, None)
+        if ew is None or eb is None or ew[0] != eb[0] or (ew[1] is None) != (eb[1] is None):
+            # not counted as a pair (a bias that is also used elsewhere, e.g. as an attention pad row): separate launches
+            if ew is None and eb is None:
+                return compute(None, None, False, True, True)
+            dw = self.deliver(token, w, lambda o, acc: compute(o, None, acc, True, False)[0])
+            db = self.deliver(token, b, lambda o, acc: compute(None, o, acc, False, True)[1])
+            return dw, db
+        if ew[0] <= 1 and ew[1] is None:
+            self.uses.pop(id(w), None); self.uses.pop(id(b), None)
+            return compute(None, None, False, True, True)
+        if self._checked is not token:
+            self._checked = token
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: self._verify(token))
+        if ew[1] is None:
+            ew[1], eb[1] = compute(None, None, False, True, True)
+        else:
+            compute(ew[1], eb[1], True, True, True)
+        ew[0] -= 1; eb[0] -= 1
+        if ew[0] == 0:
+            self.uses.pop(id(w), None); self.uses.pop(id(b), None)
+            return ew[1], eb[1]
+        return None, None
+
     def _verify(self, token) -> None:
         self._checked = None
         if token is self.graph:
@@ -126,18 +154,24 @@ def linear_dgrad(g: Tensor, w: Tensor, gelu_pre: Optional[Tensor] = None) -> Ten
 
 
 @ops._on_device
-def linear_wgrad(g: Tensor, a: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+def linear_wgrad(g: Tensor, a: Optional[Tensor], out: Optional[Tensor] = None, accumulate: bool = False, dbias: Optional[Tensor] = None,
+                 want_bias: bool = False, want_weight: bool = True):
+    """-> (dw [N,K] = g^T . a, db [N] = column sums of g or None): one GEMM launch + one slab reduce for both (the bias gradient rides
+    along in the workgroups of the weight gradient's first column tile).  want_weight False: the bias gradient alone (master_colsum)."""
     M, N = g.shape
+    if not want_weight:
+        return None, colsum(g, dbias, accumulate)
     K = a.shape[1]
     lib = load_library()
     dw = out if out is not None else torch.empty((N, K), dtype=F, device=g.device)
+    db = dbias if dbias is not None else (torch.empty((N,), dtype=F, device=g.device) if want_bias else None)
     nws = lib.master_gemm_workspace_floats(N, K)
     ws = _ws(nws, g.device)
     if ops._COUNT_ON:
         ops._count("linear_bwd", flops=2.0 * M * N * K, bytes=4.0 * (M * N + M * K + N * K))
-    _check(lib.master_linear_wgrad(_p(g), _p(a), _p(dw), M, N, K, g.stride(0), a.stride(0), _p(ws), ws.numel(),
+    _check(lib.master_linear_wgrad(_p(g), _p(a), _p(dw), _p(db), M, N, K, g.stride(0), a.stride(0), _p(ws), ws.numel(),
                                    F32 | (ACCUMULATE if accumulate else 0), _stream()), "master_linear_wgrad")
-    return dw
+    return dw, db
 
 
 @ops._on_device
@@ -190,6 +224,16 @@ def rowscale_add(x: Tensor, res: Optional[Tensor], scale: Tensor, B: int, T: int
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # Linear / MLP / norms / elementwise
 # ---------------------------------------------------------------------------------------------------------------------------------------
+def _weight_bias_grads(token, g: Tensor, a: Tensor, w: Tensor, bias: Optional[Tensor], need_w: bool, need_b: bool):
+    """(dw, db) of out = a . w^T + bias for the upstream gradient g, through the shared-gradient registry"""
+    sg = shared_grads
+    if need_w and need_b:
+        return sg.deliver_pair(token, w, bias, lambda ow, ob, acc, ww, wb: linear_wgrad(g, a, ow, acc, dbias=ob, want_bias=wb, want_weight=ww))
+    dw = sg.deliver(token, w, lambda o, acc: linear_wgrad(g, a, o, acc)[0]) if need_w else None
+    db = sg.deliver(token, bias, lambda o, acc: colsum(g, o, acc)) if need_b else None
+    return dw, db
+
+
 class LinearFn(torch.autograd.Function):
     """a [M,K] @ w[N,K]^T + bias   (nn.Linear: Wq/Wk/Wv/proj, style_transformer.py:114-116,156)"""
 
@@ -207,8 +251,7 @@ class LinearFn(torch.autograd.Function):
         a, w, bias = ctx.saved_tensors
         g = _f32c(g)
         da = linear_dgrad(g, w) if ctx.needs_input_grad[0] else None
-        dw = shared_grads.deliver(ctx.shared, w, lambda o, acc: linear_wgrad(g, a, o, acc)) if ctx.needs_input_grad[1] else None
-        db = shared_grads.deliver(ctx.shared, bias, lambda o, acc: colsum(g, o, acc)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        dw, db = _weight_bias_grads(ctx.shared, g, a, w, bias if ctx.has_bias else None, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
         return da, dw, db
 
 
@@ -257,11 +300,9 @@ class MLPFn(torch.autograd.Function):
         g = _f32c(g)
         need = ctx.needs_input_grad
         sg, tok = shared_grads, ctx.shared
-        dw2 = sg.deliver(tok, w2, lambda o, acc: linear_wgrad(g, h, o, acc)) if need[3] else None
-        db2 = sg.deliver(tok, b2, lambda o, acc: colsum(g, o, acc)) if need[4] else None
+        dw2, db2 = _weight_bias_grads(tok, g, h, w2, b2, need[3], need[4])
         dpre = linear_dgrad(g, w2, gelu_pre=pre)                        # (g . W2) * gelu'(pre)
-        dw1 = sg.deliver(tok, w1, lambda o, acc: linear_wgrad(dpre, xn, o, acc)) if need[1] else None
-        db1 = sg.deliver(tok, b1, lambda o, acc: colsum(dpre, o, acc)) if need[2] else None
+        dw1, db1 = _weight_bias_grads(tok, dpre, xn, w1, b1, need[1], need[2])
         dx = dg = dbeta = None
         if need[0] or (ln_g is not None and (need[5] or need[6])):
             dxn = linear_dgrad(dpre, w1)
@@ -502,15 +543,20 @@ def conv_backward(g: Tensor, y_relu: Optional[Tensor], x: Tensor, weight: Tensor
     else:
         gm = torch.empty((B, H, W, Cp), dtype=F, device=dev)
         _check(lib.master_relu_mask(_p(g), _p(y_relu), _p(gm), B, H * W, Cout, Cp, int(g_nchw), F32, _stream()), "master_relu_mask")
-    db = colsum(gm.view(B * H * W, Cp))[:Cout] if need_db else None
+    db = None
+    if need_db and not need_dw:
+        db = colsum(gm.view(B * H * W, Cp))[:Cout]
     dw = None
     if need_dw:
         dwp = torch.empty((Cp, 3, 3, Cin), dtype=F, device=dev)
+        dbp = torch.empty((Cp,), dtype=F, device=dev) if need_db else None            # the bias gradient rides along in the same launch
         ws = _ws(lib.master_gemm_workspace_floats(Cp, 9 * Cin), dev)
         if ops._COUNT_ON:
             ops._count("conv_wgrad", flops=2.0 * B * H * W * Cout * 9 * Cin, bytes=4.0 * (B * H * W * Cout + x.numel() + Cout * 9 * Cin))
-        _check(lib.master_conv3x3_wgrad(_p(gm), _p(x), _p(dwp), B, Hin, Win, Cin, Cp, Cp, up, 0 if reflect else 1, _p(ws), ws.numel(), F32,
+        _check(lib.master_conv3x3_wgrad(_p(gm), _p(x), _p(dwp), _p(dbp), B, Hin, Win, Cin, Cp, Cp, up, 0 if reflect else 1, _p(ws), ws.numel(), F32,
                                         _stream()), "master_conv3x3_wgrad")
+        if dbp is not None:
+            db = dbp[:Cout]
         dw = dwp[:Cout].permute(0, 3, 1, 2).contiguous()                               # [Cout,3,3,Cin] -> [Cout,Cin,3,3]
     dx = None
     if need_dx:
@@ -590,20 +636,21 @@ class PerceptualLossFn(torch.autograd.Function):
                 h = ops.maxpool2x2(h)
             elif i in VGG19_TAPS:
                 taps.append(h)
-        content_loss = torch.zeros((), dtype=F, device=dev)
-        style_loss = torch.zeros((), dtype=F, device=dev)
+        # the [B,C] arithmetic of both terms and the style term's gradient coefficients: one single-workgroup launch per tap
+        # (master_loss_terms_fwd) - as torch elementwise operators it was ~30 launches per tap, forward and backward each
+        losses = torch.empty((2,), dtype=F, device=dev)
         stats = []
-        for f in taps:
+        lib = load_library()
+        for t, f in enumerate(taps):
             N, H, W, C = f.shape
             mean, var = ops.channel_stats(f)
-            stats.append((mean, var))
-            content_loss = content_loss + ops.instnorm_distance(f, mean, var, B, 2 * B, squared_c, EPS_IN)
-            std = torch.sqrt(var * (float(H * W) / float(H * W - 1)))
-            dm, ds = mean[B:2 * B] - mean[2 * B:], std[B:2 * B] - std[2 * B:]
-            if squared_s:
-                style_loss = style_loss + torch.mean(torch.square(dm)) + torch.mean(torch.square(ds))
-            else:
-                style_loss = style_loss + torch.mean(torch.abs(dm)) + torch.mean(torch.abs(ds))
+            part = ops.instnorm_distance(f, mean, var, B, 2 * B, squared_c, EPS_IN, partials_only=True)
+            coefA = torch.empty((B, C), dtype=F, device=dev)
+            coefB = torch.empty((B, C), dtype=F, device=dev)
+            _check(lib.master_loss_terms_fwd(_p(mean), _p(var), _p(part), part.numel(), _p(losses), _p(coefA), _p(coefB), B, H * W, C,
+                                             int(squared_s), int(t == 0), _stream()), "master_loss_terms_fwd")
+            stats.append((mean, var, coefA, coefB))
+        content_loss, style_loss = losses[0], losses[1]
         ctx.B, ctx.flags, ctx.vgg = B, (squared_c, squared_s), vgg
         ctx.acts, ctx.taps, ctx.stats = acts, taps, stats
         return content_loss, style_loss
@@ -617,29 +664,18 @@ class PerceptualLossFn(torch.autograd.Function):
         dev = taps[0].device
         dt = taps[0].dtype
         DT = ops._dt(taps[0])
-        gc = float(g_content) if g_content is not None else 0.0           # scalars: one host read each (the step ends in a sync anyway)
-        gs = float(g_style) if g_style is not None else 0.0
+        # upstream gradients of the two scalars stay on the device (a float() here drained the queue at the start of every backward)
+        gc = g_content.to(F).contiguous() if g_content is not None else None
+        gs = g_style.to(F).contiguous() if g_style is not None else None
         with torch.cuda.device(dev):
             # ---- loss gradient at the four taps, for the output images [2B, 3B) ------------------------------------------------------
             tap_grads = []
-            for t, (f, (mean, var)) in enumerate(zip(taps, stats)):
+            for t, (f, (mean, var, coefA, coefB)) in enumerate(zip(taps, stats)):
                 N, H, W, C = f.shape
                 HW = H * W
-                n1 = float(HW) / float(HW - 1)
-                std = torch.sqrt(var * n1)
-                dm, ds = mean[B:2 * B] - mean[2 * B:], std[B:2 * B] - std[2 * B:]
-                cnt = float(B * C)
-                if squared_s:
-                    dmu, dsg = -2.0 * dm / cnt, -2.0 * ds / cnt
-                else:
-                    dmu, dsg = -torch.sign(dm) / cnt, -torch.sign(ds) / cnt
-                so = std[2 * B:]
-                coefA = (gs * dmu / float(HW)).contiguous()
-                coefB = torch.where(so > 0, gs * dsg / (float(HW - 1) * so), torch.zeros_like(so)).contiguous()   # torch: std' = 0 at std = 0
                 dx = torch.empty((B, H, W, C), dtype=dt, device=dev)
                 ws = _ws(lib.master_loss_tap_workspace_floats(B, HW, C), dev)
-                wc = gc / float(B * C * HW)
-                _check(lib.master_loss_tap_bwd(_p(f), _p(mean), _p(var), _p(coefA), _p(coefB), _p(ws), _p(dx), B, HW, C, EPS_IN, wc,
+                _check(lib.master_loss_tap_bwd(_p(f), _p(mean), _p(var), _p(coefA), _p(coefB), _p(ws), _p(dx), B, HW, C, EPS_IN, _p(gc), _p(gs),
                                                int(squared_c), int(t == 3), DT, _stream()), "master_loss_tap_bwd")
                 tap_grads.append(dx)
             # ---- VGG-19 backward on the output images --------------------------------------------------------------------------------

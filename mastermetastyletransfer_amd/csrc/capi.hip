@@ -20,8 +20,8 @@ int linear_ts_group_bf16(int, const bf16_t* const*, const bf16_t* const*, const 
 int gemm_f32_conv3x3_dgrad(const float*, const float*, float*, const float*, const float*, int, int, int, int, int, int, hipStream_t);
 size_t gemm_f32_t_workspace(int, int);
 int gemm_f32_dgrad(const float*, const float*, float*, const float*, int, int, int, int, int, int, hipStream_t);
-int gemm_f32_wgrad(const float*, const float*, float*, int, int, int, int, int, float*, size_t, hipStream_t, int accumulate = 0);
-int gemm_f32_conv3x3_wgrad(const float*, const float*, float*, int, int, int, int, int, int, int, int, float*, size_t, hipStream_t);
+int gemm_f32_wgrad(const float*, const float*, float*, float*, int, int, int, int, int, float*, size_t, hipStream_t, int accumulate = 0);
+int gemm_f32_conv3x3_wgrad(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, float*, size_t, hipStream_t);
 int reduce_slabs_launch(const float*, float*, size_t, size_t, int, hipStream_t, int accumulate = 0);
 int colsum_slabs(int, int);
 int colsum_launch(const float*, const float*, float*, float*, int, int, int, hipStream_t, int accumulate = 0);
@@ -40,8 +40,9 @@ int adam_chunk();
 int adam_launch(const void*, int, long long, float, float, float, float, float, int, hipStream_t);
 int lerp_launch(const void*, int, long long, float, hipStream_t);
 int loss_tap_slices(int);
+int loss_terms_launch(const float*, const float*, const float*, int, float*, float*, float*, int, int, int, int, int, hipStream_t);
 template <typename T> int loss_tap_bwd_launch(const void*, const float*, const float*, const float*, const float*, float*, void*, int, int, int,
-                                              float, float, int, int, hipStream_t);
+                                              float, float, const float*, const float*, int, int, hipStream_t);
 int layernorm_bwd_blocks(int);
 int layernorm_bwd_launch(const float*, const float*, const float*, float*, float*, float*, int, int, float, hipStream_t, int accumulate = 0);
 int instnorm_bwd_launch(const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, float, hipStream_t);
@@ -169,8 +170,8 @@ int master_linear_dgrad(const void* g, const void* w, void* da, const void* gelu
 
 size_t master_gemm_workspace_floats(int rows, int cols) { return gemm_f32_t_workspace(rows, cols); }
 
-int master_linear_wgrad(const void* g, const void* a, void* dw, int M, int N, int K, int ldg, int lda, void* ws, size_t ws_floats, int dtype,
-                        master_stream_t stream) {
+int master_linear_wgrad(const void* g, const void* a, void* dw, void* dbias, int M, int N, int K, int ldg, int lda, void* ws, size_t ws_floats,
+                        int dtype, master_stream_t stream) {
     const int accumulate = (dtype & MASTER_ACCUMULATE) != 0; dtype &= ~MASTER_ACCUMULATE;
     F32_ONLY("linear_wgrad");
     REQUIRE(g && a && dw, "linear_wgrad: null operand");
@@ -178,7 +179,7 @@ int master_linear_wgrad(const void* g, const void* a, void* dw, int M, int N, in
     REQUIRE(al16(a) && al16(dw) && (ws == nullptr || al16(ws)), "linear_wgrad: a/dw/ws must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_LINEAR_BWD, s);
-    return gemm_f32_wgrad((const float*)g, (const float*)a, (float*)dw, M, N, K, ldg, lda, (float*)ws, ws_floats, s, accumulate);
+    return gemm_f32_wgrad((const float*)g, (const float*)a, (float*)dw, (float*)dbias, M, N, K, ldg, lda, (float*)ws, ws_floats, s, accumulate);
 }
 
 size_t master_colsum_workspace_floats(int M, int N) { return (size_t)colsum_slabs(M, N) * (size_t)N; }
@@ -293,7 +294,7 @@ int master_conv3x3_dgrad(const void* g, const void* wf, void* out, const void* r
                                   full, s);
 }
 
-int master_conv3x3_wgrad(const void* g, const void* x, void* dw, int B, int Hin, int Win, int Cin, int Cout, int ldg, int upsample,
+int master_conv3x3_wgrad(const void* g, const void* x, void* dw, void* dbias, int B, int Hin, int Win, int Cin, int Cout, int ldg, int upsample,
                          int zero_pad, void* ws, size_t ws_floats, int dtype, master_stream_t stream) {
     F32_ONLY("conv3x3_wgrad");
     REQUIRE(g && x && dw, "conv3x3_wgrad: null operand");
@@ -302,8 +303,8 @@ int master_conv3x3_wgrad(const void* g, const void* x, void* dw, int B, int Hin,
     REQUIRE(al16(x) && al16(dw) && (ws == nullptr || al16(ws)), "conv3x3_wgrad: x/dw/ws must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_CONV_WGRAD, s);
-    return gemm_f32_conv3x3_wgrad((const float*)g, (const float*)x, (float*)dw, B, Hin, Win, Cin, Cout, ldg, upsample, zero_pad, (float*)ws,
-                                  ws_floats, s);
+    return gemm_f32_conv3x3_wgrad((const float*)g, (const float*)x, (float*)dw, (float*)dbias, B, Hin, Win, Cin, Cout, ldg, upsample, zero_pad,
+                                  (float*)ws, ws_floats, s);
 }
 
 int master_relu_mask(const void* g, const void* relu_out, void* gm, int B, int HW, int C, int Cp, int g_nchw, int dtype, master_stream_t stream) {
@@ -364,13 +365,24 @@ int master_mul_add_bwd(const void* g, const void* q, const void* sigma, void* dq
 
 size_t master_loss_tap_workspace_floats(int B, int HW, int C) { return (size_t)B * (size_t)(loss_tap_slices(HW) + 1) * 2 * (size_t)C; }
 int master_loss_tap_bwd(const void* x, const float* mean, const float* var, const float* coefA, const float* coefB, float* ws, void* dx, int B,
-                        int HW, int C, float eps, float wc, int squared, int relu_gate, int dtype, master_stream_t stream) {
+                        int HW, int C, float eps, const float* g_content, const float* g_style, int squared, int relu_gate, int dtype,
+                        master_stream_t stream) {
     REQUIRE(x && mean && var && coefA && coefB && ws && dx && B > 0 && HW > 0, "loss_tap_bwd: null operand");
     REQUIRE(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0, "loss_tap_bwd: C/4 must divide 256 (C=%d)", C);
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_TRAIN_MISC, s);
-    return dtype == MASTER_F32 ? loss_tap_bwd_launch<float>(x, mean, var, coefA, coefB, ws, dx, B, HW, C, eps, wc, squared, relu_gate, s)
-                               : loss_tap_bwd_launch<bf16_t>(x, mean, var, coefA, coefB, ws, dx, B, HW, C, eps, wc, squared, relu_gate, s);
+    const float wc_unit = 1.0f / ((float)B * (float)C * (float)HW);
+    return dtype == MASTER_F32 ? loss_tap_bwd_launch<float>(x, mean, var, coefA, coefB, ws, dx, B, HW, C, eps, wc_unit, g_content, g_style, squared, relu_gate, s)
+                               : loss_tap_bwd_launch<bf16_t>(x, mean, var, coefA, coefB, ws, dx, B, HW, C, eps, wc_unit, g_content, g_style, squared, relu_gate, s);
+}
+
+int master_loss_terms_fwd(const float* mean, const float* var, const float* dist_partial, int n_partial, float* losses, float* coefA, float* coefB,
+                          int B, int HW, int C, int squared_style, int first, master_stream_t stream) {
+    REQUIRE(mean && var && losses && coefA && coefB && (dist_partial || n_partial == 0), "loss_terms_fwd: null operand");
+    REQUIRE(B > 0 && C > 0 && HW > 1 && n_partial >= 0, "loss_terms_fwd: bad dims B=%d HW=%d C=%d", B, HW, C);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_TRAIN_MISC, s);
+    return loss_terms_launch(mean, var, dist_partial, n_partial, losses, coefA, coefB, B, HW, C, squared_style, first, s);
 }
 
 int master_adam_chunk(void) { return adam_chunk(); }

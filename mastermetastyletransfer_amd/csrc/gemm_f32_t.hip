@@ -12,10 +12,17 @@
 // Weight gradients contract over all tokens / pixels of the batch (8 192 ... 524 288) into a small output, so the contraction is split
 // over blockIdx.y: every split writes its partial tile to a workspace slab and reduce_slabs_kernel (train_misc.hip) adds the slabs in a fixed order
 // (deterministic, no atomics).
+//
+// Bias gradients ride along (r03): the weight-gradient forms already stream G through the workgroups, so the workgroups of the first
+// column tile also add up the G values they stage (one VALU add per 16-byte load, next to the MFMAs) and write  rowsum[m] = sum over the
+// split's contraction rows of G[k][m]  - the column sums of G, i.e. the bias gradient - to a second slab that the same reduce launch
+// folds.  This replaced one colsum launch + one reduce launch per Linear / convolution with a bias (88 + 88 launches of a train step).
 #include "common.h"
 #include <stdlib.h>
 
 int reduce_slabs_launch(const float* part, float* out, size_t n, size_t slab, int splits, hipStream_t s, int accumulate = 0);   // train_misc.hip
+int reduce_slabs2_launch(const float* part, float* out, size_t n, size_t slab, const float* part2, float* out2, size_t n2, size_t slab2, int splits,
+                         hipStream_t s, int accumulate);                                                                           // train_misc.hip
 
 namespace {
 
@@ -33,6 +40,8 @@ struct TArgs {
     const float* aux; int ld_aux;
     // conv weight gradient: w = x NHWC [B,Hin,Win,Cin]; contraction index = output pixel of the Hout x Wout map; column n = tap*Cin + ci
     int Hin, Win, Cin, Hout, Wout, up, zero_pad;
+    // contraction-major A only: rowsum[blockIdx.y * rowsum_slab + m] = sum over this split's contraction rows of a[k][m]  (NULL: not wanted)
+    float* rowsum; size_t rowsum_slab;
 };
 
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
@@ -88,6 +97,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_t_kernel(
     }
 
     f32x4 a_st[ACH], w_st[WCH];
+    // bias gradient: thread c = tid + i NT stages contraction row c / (BM/4), columns (c % (BM/4)) * 4 .. +3 of every chunk; NT is a multiple
+    // of BM/4, so all of a thread's pieces are the same four columns: one running f32x4, added where the staged values are consumed
+    // (stage_store) - next to the load it would put a wait for the global loads in front of the MFMAs they are meant to hide under
+    static_assert(!AT || NT % (BM / 4) == 0, "a thread's A pieces must share their columns");
+    f32x4 a_sum = {0.f, 0.f, 0.f, 0.f};
+    const bool do_rowsum = AT && p.rowsum != nullptr && nt == 0;               // workgroup-uniform
     auto stage_load = [&](int kt) {
         const int k0 = kt * BK;
         if (AT) {
@@ -142,6 +157,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_t_kernel(
             for (int i = 0; i < ACH; ++i) {
                 const int c = tid + i * NT;
                 if (c < BK * BM / 4) *(f32x4*)(As + buf * A_ELEMS + (c / (BM / 4)) * LDA_T + (c % (BM / 4)) * 4) = a_st[i];
+                if (do_rowsum) a_sum += a_st[i];                               // zeros where c or the row is out of range; every chunk passes here once
             }
         } else {
             const int kc = (tid & 7) * 4;
@@ -197,6 +213,20 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_t_kernel(
             if (kt + 1 < kt1) stage_store(buf ^ 1);
             __syncthreads();
         }
+    }
+
+    if (AT && do_rowsum) {
+        constexpr int GROUPS = NT / (BM / 4);                                  // threads holding partial sums of the same four columns
+        float* red = smem;                                                     // [GROUPS][BM]; the main loop's last barrier has passed
+        *(f32x4*)(red + (tid / (BM / 4)) * BM + (tid % (BM / 4)) * 4) = a_sum;
+        __syncthreads();
+        if (tid < BM && m0 + tid < p.M) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < GROUPS; ++q) t += red[q * BM + tid];
+            p.rowsum[(size_t)blockIdx.y * p.rowsum_slab + m0 + tid] = t;
+        }
+        // the epilogue's own first barrier orders these reads before the tile goes into the same memory
     }
 
     // ---- epilogue --------------------------------------------------------------------------------------------------------------------
@@ -272,12 +302,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_t_kernel(
 }
 
 template <int BM, int BN, int WM, int WN, bool AT, bool GATHER>
-int launch_t(TArgs p, float* final_out, float* ws, size_t ws_floats, int want_splits, hipStream_t s, int accumulate = 0) {
+int launch_t(TArgs p, float* final_out, float* ws, size_t ws_floats, int want_splits, hipStream_t s, int accumulate = 0, float* rowsum_out = nullptr) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     constexpr int A_ELEMS = AT ? BK * (BM + PADT) : BM * LDK;
     constexpr int W_ELEMS = BK * (BN + PADT);
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const int nk = (p.K + BK - 1) / BK;
+    if (rowsum_out && !AT) { master_set_error("gemm_f32_t: row sums need the contraction-major A form"); return MASTER_ERR_INVALID; }
     int splits = want_splits;
     if (splits <= 0) {                                       // two workgroups per CU
         splits = (512 + tiles - 1) / tiles;
@@ -285,21 +316,26 @@ int launch_t(TArgs p, float* final_out, float* ws, size_t ws_floats, int want_sp
     }
     if (splits < 1) splits = 1;
     const size_t slab = ((size_t)p.M * p.ldo + 3) & ~(size_t)3;
-    if (splits > 1 && (ws == nullptr || ws_floats < slab * splits)) {
-        splits = ws ? (int)(ws_floats / slab) : 1;
+    const size_t rs_slab = rowsum_out ? (((size_t)p.M + 3) & ~(size_t)3) : 0;        // the row-sum slabs follow the output slabs in ws
+    if (splits > 1 && (ws == nullptr || ws_floats < (slab + rs_slab) * splits)) {
+        splits = ws ? (int)(ws_floats / (slab + rs_slab)) : 1;
         if (splits < 1) splits = 1;
     }
     p.chunks_per_split = (nk + splits - 1) / splits;
     splits = (nk + p.chunks_per_split - 1) / p.chunks_per_split;
     // accumulate (final_out += result): always through the workspace and the slab reduce, which adds to final_out
     const bool via_ws = splits > 1 || accumulate;
-    if (accumulate && (ws == nullptr || ws_floats < slab)) { master_set_error("gemm_f32_t: accumulating needs a workspace of at least one slab"); return MASTER_ERR_INVALID; }
-    if (via_ws) { p.out = ws; p.slab = slab; } else { p.out = final_out; p.slab = 0; }
+    if (accumulate && (ws == nullptr || ws_floats < slab + rs_slab)) { master_set_error("gemm_f32_t: accumulating needs a workspace of at least one slab"); return MASTER_ERR_INVALID; }
+    if (via_ws) { p.out = ws; p.slab = slab; p.rowsum = rowsum_out ? ws + slab * splits : nullptr; p.rowsum_slab = rs_slab; }
+    else { p.out = final_out; p.slab = 0; p.rowsum = rowsum_out; p.rowsum_slab = 0; }
     const size_t lds = (size_t)2 * (A_ELEMS + W_ELEMS) * sizeof(float);
     static LdsLimit lds_limit;
     lds_limit.ensure((const void*)gemm_f32_t_kernel<BM, BN, WM, WN, AT, GATHER>, (int)lds);
     hipLaunchKernelGGL((gemm_f32_t_kernel<BM, BN, WM, WN, AT, GATHER>), dim3(tiles, splits), dim3(NT), lds, s, p);
-    if (via_ws) return reduce_slabs_launch(ws, final_out, (size_t)p.M * p.ldo, slab, splits, s, accumulate);
+    if (via_ws) {
+        if (rowsum_out) return reduce_slabs2_launch(ws, final_out, (size_t)p.M * p.ldo, slab, p.rowsum, rowsum_out, (size_t)p.M, rs_slab, splits, s, accumulate);
+        return reduce_slabs_launch(ws, final_out, (size_t)p.M * p.ldo, slab, splits, s, accumulate);
+    }
     return master_check_launch("gemm_f32_t");
 }
 
@@ -307,7 +343,7 @@ int launch_t(TArgs p, float* final_out, float* ws, size_t ws_floats, int want_sp
 
 // number of floats of workspace that lets a weight-gradient GEMM use its preferred split count
 size_t gemm_f32_t_workspace(int M, int N) {
-    const size_t slab = ((size_t)M * N + 3) & ~(size_t)3;
+    const size_t slab = (((size_t)M * N + 3) & ~(size_t)3) + (((size_t)M + 3) & ~(size_t)3);     // output tile slab + the bias-gradient (row sum) slab
     size_t n = slab * 512, cap = (size_t)8 << 20;            // up to 512 splits, at most 32 MB - but never fewer than 8 slabs
     if (n > cap) n = cap;
     return n < slab * 8 ? slab * 8 : n;
@@ -316,7 +352,7 @@ size_t gemm_f32_t_workspace(int M, int N) {
 // dX[M,Kc] = G[M,Nc] . W[Nc,Kc] (* gelu'(aux) when aux != NULL)
 int gemm_f32_dgrad(const float* g, const float* w, float* out, const float* aux, int M, int Nc, int Kc, int ldg, int ldo, int ld_aux,
                    hipStream_t s) {
-    TArgs p{g, w, out, M, Kc, Nc, ldg, Kc, ldo, 0, 0, aux, ld_aux, 0, 0, 0, 0, 0, 0, 0};
+    TArgs p{g, w, out, M, Kc, Nc, ldg, Kc, ldo, 0, 0, aux, ld_aux, 0, 0, 0, 0, 0, 0, 0, nullptr, 0};
     if (Kc > 64) {
         // fewer than one 128x128 tile per CU (the StyleTransformer's 8 192-token matrices): 64-row tiles double the workgroups
         // (r03: 64x64 tiles, four workgroups per CU, for the 8 192-token matrices: 512+ workgroups instead of 256 one-per-CU ones)
@@ -331,20 +367,20 @@ int gemm_f32_dgrad(const float* g, const float* w, float* out, const float* aux,
     return launch_t<128, 64, 64, 32, false, false>(p, out, nullptr, 0, 1, s);
 }
 
-// dW[Nc,Kc] = G[M,Nc]^T . X[M,Kc]      (dense output, ldo = Kc)
-int gemm_f32_wgrad(const float* g, const float* x, float* out, int M, int Nc, int Kc, int ldg, int ldx, float* ws, size_t ws_floats,
+// dW[Nc,Kc] = G[M,Nc]^T . X[M,Kc]      (dense output, ldo = Kc);  dbias[Nc] = column sums of G when dbias != NULL
+int gemm_f32_wgrad(const float* g, const float* x, float* out, float* dbias, int M, int Nc, int Kc, int ldg, int ldx, float* ws, size_t ws_floats,
                    hipStream_t s, int accumulate) {
-    TArgs p{g, x, out, Nc, Kc, M, ldg, ldx, Kc, 0, 0, nullptr, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (Nc > 64) return launch_t<128, 128, 64, 64, true, false>(p, out, ws, ws_floats, 0, s, accumulate);
-    return launch_t<32, 256, 32, 64, true, false>(p, out, ws, ws_floats, 0, s, accumulate);
+    TArgs p{g, x, out, Nc, Kc, M, ldg, ldx, Kc, 0, 0, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, nullptr, 0};
+    if (Nc > 64) return launch_t<128, 128, 64, 64, true, false>(p, out, ws, ws_floats, 0, s, accumulate, dbias);
+    return launch_t<32, 256, 32, 64, true, false>(p, out, ws, ws_floats, 0, s, accumulate, dbias);
 }
 
-// dWpacked[Cout][3][3][Cin] = sum over the B*Hout*Wout output pixels of G[pix][Cout] (x) gather(X)[pix][tap][Cin]
-int gemm_f32_conv3x3_wgrad(const float* g, const float* x, float* out, int B, int Hin, int Win, int Cin, int Cout, int ldg, int up,
+// dWpacked[Cout][3][3][Cin] = sum over the B*Hout*Wout output pixels of G[pix][Cout] (x) gather(X)[pix][tap][Cin];  dbias[Cout] = column sums of G
+int gemm_f32_conv3x3_wgrad(const float* g, const float* x, float* out, float* dbias, int B, int Hin, int Win, int Cin, int Cout, int ldg, int up,
                            int zero_pad, float* ws, size_t ws_floats, hipStream_t s) {
     const int Hout = Hin << up, Wout = Win << up;
-    TArgs p{g, x, out, Cout, 9 * Cin, B * Hout * Wout, ldg, 0, 9 * Cin, 0, 0, nullptr, 0, Hin, Win, Cin, Hout, Wout, up, zero_pad};
-    if (Cout > 64) return launch_t<128, 128, 64, 64, true, true>(p, out, ws, ws_floats, 0, s);
-    if (Cout > 32) return launch_t<64, 128, 32, 64, true, true>(p, out, ws, ws_floats, 0, s);
-    return launch_t<32, 256, 32, 64, true, true>(p, out, ws, ws_floats, 0, s);
+    TArgs p{g, x, out, Cout, 9 * Cin, B * Hout * Wout, ldg, 0, 9 * Cin, 0, 0, nullptr, 0, Hin, Win, Cin, Hout, Wout, up, zero_pad, nullptr, 0};
+    if (Cout > 64) return launch_t<128, 128, 64, 64, true, true>(p, out, ws, ws_floats, 0, s, 0, dbias);
+    if (Cout > 32) return launch_t<64, 128, 32, 64, true, true>(p, out, ws, ws_floats, 0, s, 0, dbias);
+    return launch_t<32, 256, 32, 64, true, true>(p, out, ws, ws_floats, 0, s, 0, dbias);
 }

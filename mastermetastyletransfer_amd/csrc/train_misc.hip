@@ -30,10 +30,15 @@ template <> struct El<bf16_t> {
 //      wave are 64 consecutive floats), 8 independent partial sums per thread keep the loads in flight; the four wave partials are
 //      added in a fixed order through LDS.  (r02: one thread per output walking 512 slabs serially took 41 us per bias gradient.) -------
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, size_t slab,
-                                                           int splits, int accumulate) {
+                                                           int splits, int accumulate, const float* __restrict__ part2, float* __restrict__ out2,
+                                                           size_t n2, size_t slab2, unsigned blocks1) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const size_t i = (size_t)blockIdx.x * 64 + lane;
+    size_t i = (size_t)blockIdx.x * 64 + lane;
+    if (blockIdx.x >= blocks1) {                   // second segment (r03: the bias gradient next to its weight gradient, one launch for both)
+        part = part2; out = out2; n = n2; slab = slab2;
+        i = (size_t)(blockIdx.x - blocks1) * 64 + lane;
+    }
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (i < n) {
         int k = wv;
@@ -234,9 +239,13 @@ constexpr int SLICE_ROWS = 256;
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void loss_tap_bwd_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ var,
                                                            const float* __restrict__ coefA, const float* __restrict__ coefB, float* __restrict__ partial,
-                                                           const float* __restrict__ sums, T* __restrict__ dx, int B, int HW, int C, float eps, float wc, int squared,
+                                                           const float* __restrict__ sums, T* __restrict__ dx, int B, int HW, int C, float eps, float wc_unit,
+                                                           const float* __restrict__ g_content, const float* __restrict__ g_style, int squared,
                                                            int relu_gate, int nslice) {
     extern __shared__ float red[];                              // MODE 0: [2][RPB][C]
+    // upstream gradients of the two loss scalars, read on the device (r03: float(g) on the host drained the whole queue at the start of
+    // every backward pass); a NULL pointer = that loss does not reach the objective
+    const float wc = wc_unit * (g_content ? *g_content : 0.f), gs = g_style ? *g_style : 0.f;
     const int TPR = C / 4, RPB = 256 / TPR;
     const int tc = threadIdx.x % TPR, tr = threadIdx.x / TPR, i = blockIdx.y, j = 2 * B + i, sl = blockIdx.x;
     const int r0 = sl * SLICE_ROWS, r1 = min(r0 + SLICE_ROWS, HW);
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(256) void loss_tap_bwd_kernel(const T* __restrict__
         s1[e] = 0.f; s2[e] = 0.f;
         if (MODE == 1) {                                           // sums[i][2][C]: the slice partials added up by loss_tap_finalize_kernel
             s1[e] = sums[((size_t)i * 2 + 0) * C + c]; s2[e] = sums[((size_t)i * 2 + 1) * C + c];
-            ca[e] = coefA[(size_t)i * C + c]; cb[e] = coefB[(size_t)i * C + c];
+            ca[e] = gs * coefA[(size_t)i * C + c]; cb[e] = gs * coefB[(size_t)i * C + c];
         }
     }
     if (tr < RPB)
@@ -280,6 +289,46 @@ __global__ __launch_bounds__(256) void loss_tap_bwd_kernel(const T* __restrict__
             for (int k = 0; k < RPB; ++k) t += red[(which * RPB + k) * C + cc];
             partial[(((size_t)i * nslice + sl) * 2 + which) * C + cc] = t;
         }
+    }
+}
+
+// ---- the scalar arithmetic of one tap of the perceptual loss (codes/loss.py:112-130 content term, :272-322 style term), one workgroup:
+//   losses[0] (+)= sum(dist_partial) / (B*C*HW)                                  (the |IN - IN| partials of master_instnorm_distance_fwd)
+//   losses[1] (+)= mean_{i,c} f(mean_s - mean_o) + mean_{i,c} f(std_s - std_o)    f = |.| or (.)^2, std unbiased
+//   coefA[i,c] = d style / d mean_o / HW,  coefB[i,c] = d style / d std_o / ((HW-1) std_o)  (0 where std_o = 0: torch's sqrt'(0) guard
+//   of the reference's backward) - what master_loss_tap_bwd adds per position, for a unit upstream gradient.
+// r03: this was ~30 torch elementwise launches per tap and pass on [B,C] tensors.  Sums in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void loss_terms_kernel(const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ dist_partial,
+                                                         int n_partial, float* __restrict__ losses, float* __restrict__ coefA, float* __restrict__ coefB,
+                                                         int B, int HW, int C, int squared_s, int first) {
+    __shared__ float red[2][256];
+    const int tid = threadIdx.x, n = B * C;
+    const float n1 = (float)HW / (float)(HW - 1), cnt = (float)n;
+    float st = 0.f, ct = 0.f;
+    for (int i = tid; i < n; i += 256) {
+        const float ms = mean[n + i], mo = mean[2 * n + i];
+        const float ss = sqrtf(var[n + i] * n1), so = sqrtf(var[2 * n + i] * n1);
+        const float dm = ms - mo, ds = ss - so;
+        float dmu, dsg;
+        if (squared_s) { st += dm * dm + ds * ds; dmu = -2.f * dm / cnt; dsg = -2.f * ds / cnt; }
+        else {
+            st += fabsf(dm) + fabsf(ds);
+            dmu = (dm > 0.f ? -1.f : (dm < 0.f ? 1.f : 0.f)) / cnt; dsg = (ds > 0.f ? -1.f : (ds < 0.f ? 1.f : 0.f)) / cnt;
+        }
+        coefA[i] = dmu / (float)HW;
+        coefB[i] = so > 0.f ? dsg / ((float)(HW - 1) * so) : 0.f;
+    }
+    for (int i = tid; i < n_partial; i += 256) ct += dist_partial[i];
+    red[0][tid] = st; red[1][tid] = ct;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) { red[0][tid] += red[0][tid + w]; red[1][tid] += red[1][tid + w]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float c_term = red[1][0] / ((float)n * (float)HW), s_term = red[0][0] / cnt;
+        losses[0] = (first ? 0.f : losses[0]) + c_term;
+        losses[1] = (first ? 0.f : losses[1]) + s_term;
     }
 }
 
@@ -357,7 +406,16 @@ inline unsigned blocks_for(size_t n, unsigned cap = 0x7fffffffu) { size_t b = (n
 }  // namespace
 
 int reduce_slabs_launch(const float* part, float* out, size_t n, size_t slab, int splits, hipStream_t s, int accumulate) {
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, out, n, slab, splits, accumulate);
+    const unsigned b1 = (unsigned)((n + 63) / 64);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(b1), dim3(256), 0, s, part, out, n, slab, splits, accumulate, (const float*)nullptr, (float*)nullptr,
+                       (size_t)0, (size_t)0, b1);
+    return master_check_launch("reduce_slabs");
+}
+// two reductions with the same split count in one launch: out[i] (+)= sum_k part[k*slab + i], out2[j] (+)= sum_k part2[k*slab2 + j]
+int reduce_slabs2_launch(const float* part, float* out, size_t n, size_t slab, const float* part2, float* out2, size_t n2, size_t slab2, int splits,
+                         hipStream_t s, int accumulate) {
+    const unsigned b1 = (unsigned)((n + 63) / 64), b2 = (unsigned)((n2 + 63) / 64);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(b1 + b2), dim3(256), 0, s, part, out, n, slab, splits, accumulate, part2, out2, n2, slab2, b1);
     return master_check_launch("reduce_slabs");
 }
 
@@ -428,20 +486,26 @@ int loss_tap_slices(int HW) { return (HW + SLICE_ROWS - 1) / SLICE_ROWS; }
 // partial: B * (slices + 1) * 2 * C floats of workspace (slice partials, then their sums); dx: [B, HW, C]
 template <typename T>
 int loss_tap_bwd_launch(const void* xv, const float* mean, const float* var, const float* coefA, const float* coefB, float* partial, void* dxv,
-                        int B, int HW, int C, float eps, float wc, int squared, int relu_gate, hipStream_t s) {
+                        int B, int HW, int C, float eps, float wc_unit, const float* g_content, const float* g_style, int squared, int relu_gate,
+                        hipStream_t s) {
     const T* x = (const T*)xv; T* dx = (T*)dxv;
     const int ns = loss_tap_slices(HW);
     float* sums = partial + (size_t)B * ns * 2 * C;
     const size_t lds = (size_t)2 * (256 / (C / 4)) * C * sizeof(float);
     hipLaunchKernelGGL((loss_tap_bwd_kernel<T, 0>), dim3(ns, B), dim3(256), lds, s, x, mean, var, coefA, coefB, partial, (const float*)nullptr, dx, B, HW,
-                       C, eps, wc, squared, relu_gate, ns);
+                       C, eps, wc_unit, g_content, g_style, squared, relu_gate, ns);
     hipLaunchKernelGGL(loss_tap_finalize_kernel, dim3((B * 2 * C + 255) / 256), dim3(256), 0, s, (const float*)partial, sums, HW, C, ns, B * 2 * C);
     hipLaunchKernelGGL((loss_tap_bwd_kernel<T, 1>), dim3(ns, B), dim3(256), 0, s, x, mean, var, coefA, coefB, partial, (const float*)sums, dx, B, HW, C,
-                       eps, wc, squared, relu_gate, ns);
+                       eps, wc_unit, g_content, g_style, squared, relu_gate, ns);
     return master_check_launch("loss_tap_bwd");
 }
-template int loss_tap_bwd_launch<float>(const void*, const float*, const float*, const float*, const float*, float*, void*, int, int, int, float, float, int, int, hipStream_t);
-template int loss_tap_bwd_launch<bf16_t>(const void*, const float*, const float*, const float*, const float*, float*, void*, int, int, int, float, float, int, int, hipStream_t);
+template int loss_tap_bwd_launch<float>(const void*, const float*, const float*, const float*, const float*, float*, void*, int, int, int, float, float, const float*, const float*, int, int, hipStream_t);
+template int loss_tap_bwd_launch<bf16_t>(const void*, const float*, const float*, const float*, const float*, float*, void*, int, int, int, float, float, const float*, const float*, int, int, hipStream_t);
+int loss_terms_launch(const float* mean, const float* var, const float* dist_partial, int n_partial, float* losses, float* coefA, float* coefB, int B,
+                      int HW, int C, int squared_s, int first, hipStream_t s) {
+    hipLaunchKernelGGL(loss_terms_kernel, dim3(1), dim3(256), 0, s, mean, var, dist_partial, n_partial, losses, coefA, coefB, B, HW, C, squared_s, first);
+    return master_check_launch("loss_terms");
+}
 template <typename T> int channel_affine_launch(const void* x, const float* gamma, const float* beta, void* out, int M, int C, hipStream_t s) {
     const size_t total4 = (size_t)M * (C / 4);
     hipLaunchKernelGGL((channel_affine_kernel<T>), dim3(blocks_for(total4, 2048)), dim3(256), 0, s, (const T*)x, gamma, beta, (T*)out, C / 4, total4);

@@ -29,7 +29,7 @@ EXPORTS = (
     "master_colsum_workspace_floats", "master_reduce_slabs", "master_layernorm_bwd", "master_layernorm_bwd_workspace_floats",
     "master_instnorm_bwd", "master_window_attn_bwd", "master_conv3x3_dgrad", "master_conv3x3_wgrad", "master_relu_mask",
     "master_fold_reflect", "master_maxpool2x2_bwd", "master_nhwc_to_image", "master_rowscale_add", "master_mul_add_fwd",
-    "master_mul_add_bwd", "master_colsum_prod", "master_channel_affine_fwd", "master_softmax_rows_fwd", "master_softmax_rows_bwd", "master_loss_tap_bwd", "master_loss_tap_workspace_floats", "master_adam_chunk", "master_adam_step", "master_lerp",
+    "master_mul_add_bwd", "master_colsum_prod", "master_channel_affine_fwd", "master_softmax_rows_fwd", "master_softmax_rows_bwd", "master_loss_tap_bwd", "master_loss_tap_workspace_floats", "master_loss_terms_fwd", "master_adam_chunk", "master_adam_step", "master_lerp",
 )
 
 _lib = None
@@ -107,7 +107,7 @@ def load_library() -> ctypes.CDLL:
     lib.master_linear_act_fwd.argtypes = [vp] * 5 + [ci] * 7 + [vp]
     lib.master_linear_dgrad.argtypes = [vp] * 4 + [ci] * 7 + [vp]
     lib.master_gemm_workspace_floats.argtypes = [ci, ci]; lib.master_gemm_workspace_floats.restype = cz
-    lib.master_linear_wgrad.argtypes = [vp] * 3 + [ci] * 5 + [vp, cz, ci, vp]
+    lib.master_linear_wgrad.argtypes = [vp] * 4 + [ci] * 5 + [vp, cz, ci, vp]
     lib.master_colsum_workspace_floats.argtypes = [ci, ci]; lib.master_colsum_workspace_floats.restype = cz
     lib.master_colsum.argtypes = [vp] * 3 + [ci] * 4 + [vp]
     lib.master_reduce_slabs.argtypes = [vp, vp, cz, cz, ci, vp]
@@ -121,7 +121,7 @@ def load_library() -> ctypes.CDLL:
     lib.master_window_attn_bwd.argtypes = ([vp] * 4 + [ci] * 3 + [vp] * 3 + [ci] * 2 + [vp] * 4 + [vp] * 2 + [ci] + [vp] * 4 + [ci] * 3
                                            + [vp] * 4 + [ci] * 6 + [cf, ci, vp])
     lib.master_conv3x3_dgrad.argtypes = [vp] * 5 + [ci] * 7 + [vp]
-    lib.master_conv3x3_wgrad.argtypes = [vp] * 3 + [ci] * 8 + [vp, cz, ci, vp]
+    lib.master_conv3x3_wgrad.argtypes = [vp] * 4 + [ci] * 8 + [vp, cz, ci, vp]
     lib.master_relu_mask.argtypes = [vp] * 3 + [ci] * 6 + [vp]
     lib.master_fold_reflect.argtypes = [vp] * 2 + [ci] * 6 + [vp]
     lib.master_maxpool2x2_bwd.argtypes = [vp] * 3 + [ci] * 5 + [vp]
@@ -130,7 +130,8 @@ def load_library() -> ctypes.CDLL:
     lib.master_mul_add_fwd.argtypes = [vp] * 4 + [cz, ci, vp]
     lib.master_mul_add_bwd.argtypes = [vp] * 5 + [cz, ci, vp]
     lib.master_loss_tap_workspace_floats.argtypes = [ci, ci, ci]; lib.master_loss_tap_workspace_floats.restype = cz
-    lib.master_loss_tap_bwd.argtypes = [vp] * 7 + [ci] * 3 + [cf, cf, ci, ci, ci, vp]
+    lib.master_loss_tap_bwd.argtypes = [vp] * 7 + [ci] * 3 + [cf, vp, vp, ci, ci, ci, vp]
+    lib.master_loss_terms_fwd.argtypes = [vp] * 3 + [ci] + [vp] * 3 + [ci] * 5 + [vp]
     lib.master_adam_step.argtypes = [vp, ci, cll] + [cf] * 5 + [ci, vp]
     lib.master_lerp.argtypes = [vp, ci, cll, cf, vp]
     _lib = lib
@@ -561,14 +562,15 @@ def channel_stats(x: torch.Tensor):
 
 @_on_device
 def instnorm_distance(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, pairs: int, pair_offset: int, squared: bool,
-                      eps: float = 1e-5) -> torch.Tensor:
-    """mean over pairs, channels and positions of |IN(x[i]) - IN(x[i + pair_offset])| (or its square): a 0-d fp32 tensor"""
+                      eps: float = 1e-5, partials_only: bool = False) -> torch.Tensor:
+    """mean over pairs, channels and positions of |IN(x[i]) - IN(x[i + pair_offset])| (or its square): a 0-d fp32 tensor
+    (partials_only: the per-workgroup partial sums, for master_loss_terms_fwd to fold)"""
     _dev(x)
     N, H, W, C = x.shape
     partial = torch.empty((pairs * load_library().master_stats_slices(H * W),), dtype=torch.float32, device=x.device)
     _check(load_library().master_instnorm_distance_fwd(_p(x), _p(mean), _p(var), _p(partial), pairs, pair_offset, H * W, C, eps, int(squared),
                                                        _dt(x), _stream()), "master_instnorm_distance_fwd")
-    return partial.sum() / float(pairs * C * H * W)
+    return partial if partials_only else partial.sum() / float(pairs * C * H * W)
 
 
 _RESIZE_PLANS = {}
