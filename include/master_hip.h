@@ -276,6 +276,10 @@ int master_softmax_rows_bwd(const void* p, const void* g, void* dx, int M, int N
 
 /* out[i] = sum_{k < splits} part[k * slab + i], i < n  (fixed order).  Used to add up per-window / per-workgroup partial gradients. */
 int master_reduce_slabs(const float* part, float* out, size_t n, size_t slab, int splits, master_stream_t stream);
+/* Up to four such reductions in ONE launch, each with its own split count; accumulate != 0: out[i] += the sum (a gradient that several
+ * uses of one tensor contribute to).  The backward of one attention call reduces its bias-tile slabs and its pad-row gradients this way. */
+typedef struct master_reduce_seg { const float* part; float* out; size_t n; size_t slab; int splits; int accumulate; } master_reduce_seg;
+int master_reduce_segments(const master_reduce_seg* segs, int count, master_stream_t stream);
 
 /* nn.LayerNorm backward: dx[M,C]; dgb[2][C] = dgamma | dbeta.  ws: master_layernorm_bwd_workspace_floats(M, C) floats. */
 size_t master_layernorm_bwd_workspace_floats(int M, int C);

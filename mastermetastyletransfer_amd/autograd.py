@@ -86,6 +86,27 @@ class _SharedGrads:
             return e[1]
         return None
 
+    def slot(self, token, t, alloc):
+        """backward, for a launch that writes several gradients at once: -> (buffer to write, accumulate into it?, what to return to
+        autograd for `t`: None for every use but the last).  `alloc()` makes the buffer at the first use."""
+        e = self.uses.get(id(t)) if (token is not None and token is self.graph) else None
+        if e is None or (e[0] <= 1 and e[1] is None):
+            if e is not None:
+                self.uses.pop(id(t), None)
+            out = alloc()
+            return out, False, out
+        if self._checked is not token:
+            self._checked = token
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: self._verify(token))
+        acc = e[1] is not None
+        if not acc:
+            e[1] = alloc()
+        e[0] -= 1
+        if e[0] == 0:
+            self.uses.pop(id(t), None)
+            return e[1], acc, e[1]
+        return e[1], acc, None
+
     def deliver_pair(self, token, w, b, compute):
         """weight and bias of one Linear (counted together by `note`, so always at the same use):
         compute(out_w, out_b, accumulate, want_w, want_b) -> (dw, db), one launch for both.  Returns (dw, db) as `deliver` would for each."""
@@ -189,6 +210,20 @@ def reduce_slabs(part: Tensor, n: int, splits: int) -> Tensor:
     out = torch.empty((n,), dtype=F, device=part.device)
     _check(load_library().master_reduce_slabs(_p(part), _p(out), n, n, splits, _stream()), "master_reduce_slabs")
     return out
+
+
+class _ReduceSeg(ctypes.Structure):            # include/master_hip.h: master_reduce_seg
+    _fields_ = [("part", ctypes.c_void_p), ("out", ctypes.c_void_p), ("n", ctypes.c_size_t), ("slab", ctypes.c_size_t),
+                ("splits", ctypes.c_int), ("accumulate", ctypes.c_int)]
+
+
+@ops._on_device
+def reduce_segments(segs: Sequence[Tuple[Tensor, Tensor, int, int, int, bool]]) -> None:
+    """[(part, out, n, slab, splits, accumulate)] (<= 4): out[i] (+)= sum_k part[k*slab + i], all in one launch"""
+    arr = (_ReduceSeg * len(segs))()
+    for a, (part, out, n, slab, splits, acc) in zip(arr, segs):
+        a.part, a.out, a.n, a.slab, a.splits, a.accumulate = part.data_ptr(), out.data_ptr(), n, slab, splits, int(acc)
+    _check(load_library().master_reduce_segments(ctypes.cast(arr, ctypes.c_void_p), len(segs), _stream()), "master_reduce_segments")
 
 
 @ops._on_device
@@ -454,6 +489,13 @@ class WindowAttnFn(torch.autograd.Function):
         ctx.save_for_backward(bases[0], bases[1], bases[2], bases[3], kp, v0p, v1p, bias64)
         ctx.meta = (offs, plan, B, T, heads, scale, None)
         ctx.base_ids = [id(t) if t is not None else None for t in (tq, tk, tv0, tv1)]
+        # parameter-like inputs used by several attention calls of one graph (the bias tile and the pad rows = Linear biases of the k
+        # weight-sharing layers): their gradients are summed inside this Function's own reduce launch (shared_grads).  The original
+        # tensors are kept for that (their ids are the registry keys); a v1 pad row that IS the v0 pad row counts once.
+        ctx.pad_src = (k_pad, v0_pad, v1_pad if v1 is not None else None, bias64)
+        ctx.same_v = v1 is not None and v1_pad is v0_pad
+        pads = [t for t in (k_pad, v0_pad, None if ctx.same_v else ctx.pad_src[2]) if t is not None and t.dim() == 1 and plan.n_pad > 0]
+        ctx.shared = shared_grads.note(*pads, bias64)
         return o0, o1
 
     @staticmethod
@@ -478,8 +520,9 @@ class WindowAttnFn(torch.autograd.Function):
         dv1 = bufs[ids[3]][:, ov1:ov1 + C] if dual else None
         n_pad = plan.n_pad
         dkp = torch.empty((B, max(n_pad, 1), C), dtype=F, device=dev) if n_pad > 0 else None
-        dv0p = torch.empty_like(dkp) if n_pad > 0 else None
-        dv1p = torch.empty_like(dkp) if (n_pad > 0 and dual) else None
+        dvp = torch.empty((2 if dual else 1, B, max(n_pad, 1), C), dtype=F, device=dev) if n_pad > 0 else None      # v0 | v1 pad-row gradients, adjacent
+        dv0p = dvp[0] if n_pad > 0 else None
+        dv1p = dvp[1] if (n_pad > 0 and dual) else None
         need_bias = ctx.needs_input_grad[7]
         dbws = torch.empty((B * plan.nW, heads, 64, 64), dtype=F, device=dev) if need_bias else None
         q, k, v0 = bq[:, oq:oq + C], bk[:, ok:ok + C], bv0[:, ov0:ov0 + C]
@@ -506,14 +549,38 @@ class WindowAttnFn(torch.autograd.Function):
             else:
                 seen.add(i); outs.append(bufs[i])
 
-        def pad_grad(rows, like):
+        # ---- pad-row and bias-tile gradients: every reduction of this call in one launch (they were a reduce launch + one torch sum per
+        #      pad row, and autograd then added the uses together) ------------------------------------------------------------------------
+        k_src, v0_src, v1_src, bias_src = ctx.pad_src
+        sg, tok = shared_grads, ctx.shared
+        segs = []
+        need = ctx.needs_input_grad
+
+        def vec_grad(rows, like, src, nrows):
+            """gradient of a [C] pad row = sum of `rows` [nrows, C]; through the registry when the row is shared"""
+            out, acc, ret = sg.slot(tok, src, lambda: torch.empty((C,), dtype=F, device=dev))
+            segs.append((rows, out, C, C, nrows, acc))
+            return ret
+
+        def pad_grad(rows, like, src, nrows):
             if rows is None:
-                return torch.zeros_like(like)
-            return rows.sum((0, 1)) if like.dim() == 1 else rows.sum(1)
-        gkp = pad_grad(dkp, kp) if ctx.needs_input_grad[4] else None
-        gv0p = pad_grad(dv0p, v0p) if ctx.needs_input_grad[5] else None
-        gv1p = pad_grad(dv1p, v1p) if (dual and ctx.needs_input_grad[6]) else None
-        dbias = reduce_slabs(dbws, heads * 4096, B * plan.nW).view(heads, 64, 64) if need_bias else None
+                return None                                     # no padded slots: no gradient through the pad row
+            if like.dim() == 1:
+                return vec_grad(rows, like, src, nrows)
+            return rows.sum(1)                                  # [B,C] pad rows (one per image: the sigma/mu attention's normalised Key row)
+        gkp = pad_grad(dkp, kp, k_src, B * max(n_pad, 1)) if need[4] else None
+        if dual and ctx.same_v and v0p.dim() == 1 and (need[5] or need[6]):
+            gv0p = pad_grad(dvp, v0p, v0_src, 2 * B * max(n_pad, 1)) if n_pad > 0 else None      # one row used for both value streams: one sum over both
+            gv1p = None
+        else:
+            gv0p = pad_grad(dv0p, v0p, v0_src, B * max(n_pad, 1)) if need[5] else None
+            gv1p = pad_grad(dv1p, v1p, v1_src, B * max(n_pad, 1)) if (dual and need[6]) else None
+        dbias = None
+        if need_bias:
+            out, acc, dbias = sg.slot(tok, bias_src, lambda: torch.empty((heads, 64, 64), dtype=F, device=dev))
+            segs.append((dbws, out, heads * 4096, heads * 4096, B * plan.nW, acc))
+        if segs:
+            reduce_segments(segs)
         return (outs[0], outs[1], outs[2], outs[3], gkp, gv0p, gv1p, dbias, None, None, None, None, None, None)
 
 

@@ -23,6 +23,7 @@ int gemm_f32_dgrad(const float*, const float*, float*, const float*, int, int, i
 int gemm_f32_wgrad(const float*, const float*, float*, float*, int, int, int, int, int, float*, size_t, hipStream_t, int accumulate = 0);
 int gemm_f32_conv3x3_wgrad(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, float*, size_t, hipStream_t);
 int reduce_slabs_launch(const float*, float*, size_t, size_t, int, hipStream_t, int accumulate = 0);
+int reduce_segments_launch(const float* const*, float* const*, const size_t*, const size_t*, const int*, const int*, int, hipStream_t);
 int colsum_slabs(int, int);
 int colsum_launch(const float*, const float*, float*, float*, int, int, int, hipStream_t, int accumulate = 0);
 template <typename T> int channel_affine_launch(const void*, const float*, const float*, void*, int, int, hipStream_t);
@@ -229,6 +230,18 @@ int master_reduce_slabs(const float* part, float* out, size_t n, size_t slab, in
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_TRAIN_MISC, s);
     return reduce_slabs_launch(part, out, n, slab, splits, s);
+}
+
+int master_reduce_segments(const master_reduce_seg* segs, int count, master_stream_t stream) {
+    REQUIRE(segs && count >= 1 && count <= 4, "reduce_segments: 1..4 segments");
+    const float* part[4]; float* out[4]; size_t n[4], slab[4]; int splits[4], acc[4];
+    for (int q = 0; q < count; ++q) {
+        REQUIRE(segs[q].part && segs[q].out && segs[q].n > 0 && segs[q].splits >= 1, "reduce_segments: bad segment %d", q);
+        part[q] = segs[q].part; out[q] = segs[q].out; n[q] = segs[q].n; slab[q] = segs[q].slab; splits[q] = segs[q].splits; acc[q] = segs[q].accumulate != 0;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_TRAIN_MISC, s);
+    return reduce_segments_launch(part, out, n, slab, splits, acc, count, s);
 }
 
 size_t master_layernorm_bwd_workspace_floats(int M, int C) { return (size_t)layernorm_bwd_blocks(M) * 2 * (size_t)C; }

@@ -29,16 +29,21 @@ template <> struct El<bf16_t> {
 // ---- slab reduce: out[i] = sum_k part[k*slab + i].  A workgroup owns 64 outputs; its 4 waves take every 4th slab (loads of one
 //      wave are 64 consecutive floats), 8 independent partial sums per thread keep the loads in flight; the four wave partials are
 //      added in a fixed order through LDS.  (r02: one thread per output walking 512 slabs serially took 41 us per bias gradient.) -------
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, size_t slab,
-                                                           int splits, int accumulate, const float* __restrict__ part2, float* __restrict__ out2,
-                                                           size_t n2, size_t slab2, unsigned blocks1) {
+struct ReduceSeg { const float* part; float* out; size_t n, slab; int splits, accumulate; unsigned block0; };
+struct ReduceSegs { ReduceSeg s[4]; int count; };
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(ReduceSegs segs) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    size_t i = (size_t)blockIdx.x * 64 + lane;
-    if (blockIdx.x >= blocks1) {                   // second segment (r03: the bias gradient next to its weight gradient, one launch for both)
-        part = part2; out = out2; n = n2; slab = slab2;
-        i = (size_t)(blockIdx.x - blocks1) * 64 + lane;
-    }
+    // up to four independent reductions in one launch (r03: a weight gradient with its bias gradient; the bias-tile and pad-row gradients of
+    // one attention backward): a workgroup belongs to the last segment whose first block it has reached
+    int which = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q) if (q < segs.count && blockIdx.x >= segs.s[q].block0) which = q;
+    const ReduceSeg sg = segs.s[which];
+    const float* __restrict__ part = sg.part;
+    const size_t n = sg.n, slab = sg.slab;
+    const int splits = sg.splits;
+    const size_t i = (size_t)(blockIdx.x - sg.block0) * 64 + lane;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (i < n) {
         int k = wv;
@@ -51,7 +56,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
     __syncthreads();
     // accumulate: out += (r03) - the gradient of a tensor used several times in one graph (the k StyleTransformer layers share their
     // weights) is summed here instead of by one autograd add launch per use
-    if (wv == 0 && i < n) out[i] = (accumulate ? out[i] : 0.0f) + ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+    if (wv == 0 && i < n) sg.out[i] = (sg.accumulate ? sg.out[i] : 0.0f) + ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
 }
 
 // ---- column sums: part[slab][n] = sum over the slab's rows of x[m][n]   (bias gradients; N % 4 == 0).  tpr = min(N/4, 64) threads
@@ -405,18 +410,29 @@ inline unsigned blocks_for(size_t n, unsigned cap = 0x7fffffffu) { size_t b = (n
 
 }  // namespace
 
-int reduce_slabs_launch(const float* part, float* out, size_t n, size_t slab, int splits, hipStream_t s, int accumulate) {
-    const unsigned b1 = (unsigned)((n + 63) / 64);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(b1), dim3(256), 0, s, part, out, n, slab, splits, accumulate, (const float*)nullptr, (float*)nullptr,
-                       (size_t)0, (size_t)0, b1);
+// segs: { part, out, n, slab, splits, accumulate } x count (<= 4); out[i] (+)= sum_k part[k*slab + i] for each
+int reduce_segments_launch(const float* const* part, float* const* out, const size_t* n, const size_t* slab, const int* splits, const int* accumulate,
+                           int count, hipStream_t s) {
+    ReduceSegs segs{};
+    unsigned blocks = 0;
+    for (int q = 0; q < count; ++q) {
+        segs.s[q] = ReduceSeg{part[q], out[q], n[q], slab[q], splits[q], accumulate[q], blocks};
+        blocks += (unsigned)((n[q] + 63) / 64);
+    }
+    segs.count = count;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, segs);
     return master_check_launch("reduce_slabs");
+}
+int reduce_slabs_launch(const float* part, float* out, size_t n, size_t slab, int splits, hipStream_t s, int accumulate) {
+    return reduce_segments_launch(&part, &out, &n, &slab, &splits, &accumulate, 1, s);
 }
 // two reductions with the same split count in one launch: out[i] (+)= sum_k part[k*slab + i], out2[j] (+)= sum_k part2[k*slab2 + j]
 int reduce_slabs2_launch(const float* part, float* out, size_t n, size_t slab, const float* part2, float* out2, size_t n2, size_t slab2, int splits,
                          hipStream_t s, int accumulate) {
-    const unsigned b1 = (unsigned)((n + 63) / 64), b2 = (unsigned)((n2 + 63) / 64);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(b1 + b2), dim3(256), 0, s, part, out, n, slab, splits, accumulate, part2, out2, n2, slab2, b1);
-    return master_check_launch("reduce_slabs");
+    const float* parts[2] = {part, part2}; float* outs[2] = {out, out2};
+    const size_t ns[2] = {n, n2}, slabs[2] = {slab, slab2};
+    const int sp[2] = {splits, splits}, ac[2] = {accumulate, accumulate};
+    return reduce_segments_launch(parts, outs, ns, slabs, sp, ac, 2, s);
 }
 
 static int colsum_tpr(int N) { return N / 4 >= 64 ? 64 : N / 4; }

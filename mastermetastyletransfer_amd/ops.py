@@ -26,7 +26,7 @@ EXPORTS = (
     "master_patch_merge_ln_fwd", "master_patch_merge_linear_fwd", "master_resize_plan", "master_preprocess_fwd", "master_postprocess_fwd", "master_image_to_nhwc_fwd", "master_conv3x3_zero_fwd", "master_maxpool2x2_fwd", "master_channel_stats_fwd", "master_stats_slices", "master_instnorm_distance_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_linear_ln_fwd", "master_attn_block_fwd", "master_window_attn_proj_fwd", "master_linear_group_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
     # train step
     "master_linear_act_fwd", "master_linear_dgrad", "master_linear_wgrad", "master_gemm_workspace_floats", "master_colsum",
-    "master_colsum_workspace_floats", "master_reduce_slabs", "master_layernorm_bwd", "master_layernorm_bwd_workspace_floats",
+    "master_colsum_workspace_floats", "master_reduce_slabs", "master_reduce_segments", "master_layernorm_bwd", "master_layernorm_bwd_workspace_floats",
     "master_instnorm_bwd", "master_window_attn_bwd", "master_conv3x3_dgrad", "master_conv3x3_wgrad", "master_relu_mask",
     "master_fold_reflect", "master_maxpool2x2_bwd", "master_nhwc_to_image", "master_rowscale_add", "master_mul_add_fwd",
     "master_mul_add_bwd", "master_colsum_prod", "master_channel_affine_fwd", "master_softmax_rows_fwd", "master_softmax_rows_bwd", "master_loss_tap_bwd", "master_loss_tap_workspace_floats", "master_loss_terms_fwd", "master_adam_chunk", "master_adam_step", "master_lerp",
@@ -111,6 +111,7 @@ def load_library() -> ctypes.CDLL:
     lib.master_colsum_workspace_floats.argtypes = [ci, ci]; lib.master_colsum_workspace_floats.restype = cz
     lib.master_colsum.argtypes = [vp] * 3 + [ci] * 4 + [vp]
     lib.master_reduce_slabs.argtypes = [vp, vp, cz, cz, ci, vp]
+    lib.master_reduce_segments.argtypes = [vp, ci, vp]
     lib.master_colsum_prod.argtypes = [vp] * 4 + [ci] * 4 + [vp]
     lib.master_channel_affine_fwd.argtypes = [vp] * 4 + [ci] * 3 + [vp]
     lib.master_softmax_rows_fwd.argtypes = [vp] * 2 + [ci] * 3 + [cf, ci, vp]
