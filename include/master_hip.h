@@ -242,9 +242,10 @@ int master_linear_act_fwd(const void* a, const void* w, const void* bias, void* 
                           int act, int dtype, master_stream_t stream);
 
 /* Data gradient of out = a . w^T:  da[M,K] = g[M,N] . w[N,K]; with gelu_pre != NULL the result is multiplied by gelu'(gelu_pre[M,K])
- * (the backward of the GELU that produced `a`).  N % 32 == 0, K % 4 == 0. */
-int master_linear_dgrad(const void* g, const void* w, void* da, const void* gelu_pre, int M, int N, int K, int ldg, int ldda,
-                        int ld_pre, int dtype, master_stream_t stream);
+ * (the backward of the GELU that produced `a`); with add != NULL, add[M,K] (row stride ld_add) is added last - the gradient reaching `a`
+ * over a skip connection.  N % 32 == 0, K % 4 == 0. */
+int master_linear_dgrad(const void* g, const void* w, void* da, const void* gelu_pre, const void* add, int M, int N, int K, int ldg, int ldda,
+                        int ld_pre, int ld_add, int dtype, master_stream_t stream);
 
 /* Weight gradient of out = a . w^T + bias:  dw[N,K] = g[M,N]^T . a[M,K] (dense, row stride K) and, when dbias != NULL, the bias gradient
  * dbias[N] = sum_m g[m][n] from the same pass over g (what autograd's Linear backward returns for weight and bias; MASTER_ACCUMULATE adds to
@@ -281,9 +282,11 @@ int master_reduce_slabs(const float* part, float* out, size_t n, size_t slab, in
 typedef struct master_reduce_seg { const float* part; float* out; size_t n; size_t slab; int splits; int accumulate; } master_reduce_seg;
 int master_reduce_segments(const master_reduce_seg* segs, int count, master_stream_t stream);
 
-/* nn.LayerNorm backward: dx[M,C]; dgb[2][C] = dgamma | dbeta.  ws: master_layernorm_bwd_workspace_floats(M, C) floats. */
+/* nn.LayerNorm backward: dx[M,C] (+ add[M,C] when add != NULL: the gradient that reaches x over the skip connection around the norm,
+ * style_transformer.py:390-397 - autograd would add it with a separate elementwise launch); dgb[2][C] = dgamma | dbeta.
+ * ws: master_layernorm_bwd_workspace_floats(M, C) floats. */
 size_t master_layernorm_bwd_workspace_floats(int M, int C);
-int master_layernorm_bwd(const void* x, const float* gamma, const void* g, void* dx, float* dgb, float* ws, int M, int C, float eps,
+int master_layernorm_bwd(const void* x, const float* gamma, const void* g, const void* add, void* dx, float* dgb, float* ws, int M, int C, float eps,
                          int dtype, master_stream_t stream);
 
 /* nn.InstanceNorm2d(affine=False) backward on a token-major map (forward: master_instnorm_fwd with repeat = 1).  With n_pad > 0 the
@@ -325,6 +328,17 @@ int master_conv3x3_wgrad(const void* g, const void* x, void* dw, void* dbias, in
  * g is NHWC [B,HW,C] or (g_nchw) NCHW [B,C,HW]; gm is NHWC [B,HW,Cp]. */
 int master_relu_mask(const void* g, const void* relu_out, void* gm, int B, int HW, int C, int Cp, int g_nchw, int dtype,
                      master_stream_t stream);
+
+/* Weight layouts of a trainable 3x3 convolution (decoder.py:24-54) from nn.Conv2d's w [Cout][Cin][3][3], one launch:
+ * wp [Cout][3][3][Cin] (master_conv3x3_reflect_fwd / master_conv3x3_wgrad) and, when wf != NULL, wf [Cin][3][3][Cp] = taps flipped, channels
+ * swapped, Cout zero-padded to Cp (master_conv3x3_dgrad). */
+int master_conv_weight_pack(const float* w, float* wp, float* wf, int Cout, int Cin, int Cp, master_stream_t stream);
+
+/* Relative-position bias tile of one attention module (style_transformer.py:21-28: relative_position_bias_table [entries, heads] gathered by
+ * relative_position_index [N*N] int64) in the [heads,64,64] form the attention kernels read: tile[h][i][j] = table[index[i*N+j]][h] for
+ * i, j < N, 0 for rows i >= N, -1e30 for key slots j >= N.  _bwd: dtable[e][h] = sum of dtile[h][i][j] over the positions with index e. */
+int master_bias_tile_fwd(const float* table, const long long* index, float* tile, int N, int heads, master_stream_t stream);
+int master_bias_tile_bwd(const float* dtile, const long long* index, float* dtable, int N, int heads, int entries, master_stream_t stream);
 
 /* Backward of ReflectionPad(1) (+ nearest x2 upsample): dxp [B,H+2,W+2,C] (gradient on the padded H x W domain) -> out
  * [B, H>>upsample, W>>upsample, C].  C % 4 == 0, H, W >= 2. */

@@ -163,14 +163,15 @@ def linear_act_fwd(a: Tensor, w: Tensor, bias: Optional[Tensor], act: int, want_
 
 
 @ops._on_device
-def linear_dgrad(g: Tensor, w: Tensor, gelu_pre: Optional[Tensor] = None) -> Tensor:
+def linear_dgrad(g: Tensor, w: Tensor, gelu_pre: Optional[Tensor] = None, add: Optional[Tensor] = None) -> Tensor:
+    """g . w (* gelu'(gelu_pre)) (+ add: the gradient arriving over a skip connection, added in the GEMM's epilogue)"""
     M, N = g.shape
     K = w.shape[1]
     da = torch.empty((M, K), dtype=F, device=g.device)
     if ops._COUNT_ON:
-        ops._count("linear_bwd", flops=2.0 * M * N * K, bytes=4.0 * (M * N + N * K + M * K * (1 + (gelu_pre is not None))))
-    _check(load_library().master_linear_dgrad(_p(g), _p(w), _p(da), _p(gelu_pre), M, N, K, g.stride(0), K, K, F32, _stream()),
-           "master_linear_dgrad")
+        ops._count("linear_bwd", flops=2.0 * M * N * K, bytes=4.0 * (M * N + N * K + M * K * (1 + (gelu_pre is not None) + (add is not None))))
+    _check(load_library().master_linear_dgrad(_p(g), _p(w), _p(da), _p(gelu_pre), _p(add), M, N, K, g.stride(0), K, K,
+                                              add.stride(0) if add is not None else 0, F32, _stream()), "master_linear_dgrad")
     return da
 
 
@@ -227,14 +228,15 @@ def reduce_segments(segs: Sequence[Tuple[Tensor, Tensor, int, int, int, bool]]) 
 
 
 @ops._on_device
-def layernorm_bwd(x: Tensor, gamma: Tensor, g: Tensor, eps: float, dgb: Optional[Tensor] = None, accumulate: bool = False):
-    """-> (dx, dgb [2,C] = dgamma | dbeta); with `dgb` given and accumulate the parameter gradients are added to it"""
+def layernorm_bwd(x: Tensor, gamma: Tensor, g: Tensor, eps: float, dgb: Optional[Tensor] = None, accumulate: bool = False,
+                  add: Optional[Tensor] = None):
+    """-> (dx (+ add), dgb [2,C] = dgamma | dbeta); with `dgb` given and accumulate the parameter gradients are added to it"""
     M, C = x.shape
     lib = load_library()
     dx = torch.empty_like(x)
     dgb = dgb if dgb is not None else torch.empty((2, C), dtype=F, device=x.device)
     ws = _ws(lib.master_layernorm_bwd_workspace_floats(M, C), x.device)
-    _check(lib.master_layernorm_bwd(_p(x), _p(gamma), _p(g), _p(dx), _p(dgb), _p(ws), M, C, eps, F32 | (ACCUMULATE if accumulate else 0),
+    _check(lib.master_layernorm_bwd(_p(x), _p(gamma), _p(g), _p(add), _p(dx), _p(dgb), _p(ws), M, C, eps, F32 | (ACCUMULATE if accumulate else 0),
                                     _stream()), "master_layernorm_bwd")
     return dx, dgb
 
@@ -291,27 +293,34 @@ class LinearFn(torch.autograd.Function):
 
 
 class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm.  fork: also return x itself - the caller uses THAT alias for the skip connection around the norm
+    (style_transformer.py:390-397), so x has this Function as its only consumer and the gradient arriving over the skip connection is
+    added inside the backward kernel instead of by one autograd add launch per block."""
+
     @staticmethod
-    def forward(ctx, x: Tensor, gamma: Tensor, beta: Tensor, eps: float):
+    def forward(ctx, x: Tensor, gamma: Tensor, beta: Tensor, eps: float, fork: bool = False):
         x = _f32c(x)
         y = ops.layernorm(x, gamma.detach(), beta.detach(), eps)
         ctx.save_for_backward(x, gamma)
         ctx.eps = eps
         ctx.shared = shared_grads.note(gamma)              # gamma and beta travel together: one [2,C] buffer, counted on gamma
-        return y
+        return (y, x) if fork else y
 
     @staticmethod
-    def backward(ctx, g: Tensor):
+    def backward(ctx, g: Tensor, g_skip: Optional[Tensor] = None):
         x, gamma = ctx.saved_tensors
         box = {}
+        skip = _f32c(g_skip) if g_skip is not None else None
+        if g is None:                                        # only the alias was used
+            return skip, None, None, None, None
 
         def run(o, acc):
-            box["dx"], dgb = layernorm_bwd(x, gamma.detach(), _f32c(g), ctx.eps, o, acc)
+            box["dx"], dgb = layernorm_bwd(x, gamma.detach(), _f32c(g), ctx.eps, o, acc, add=skip)
             return dgb
         dgb = shared_grads.deliver(ctx.shared, gamma, run)
         if dgb is None:
-            return box["dx"], None, None, None
-        return box["dx"], dgb[0], dgb[1], None
+            return box["dx"], None, None, None, None
+        return box["dx"], dgb[0], dgb[1], None, None
 
 
 class MLPFn(torch.autograd.Function):
@@ -319,7 +328,7 @@ class MLPFn(torch.autograd.Function):
     The GELU backward is the epilogue of fc2's data-gradient GEMM (gelu'(pre) on the saved pre-activation)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, ln_g, ln_b, eps: float):
+    def forward(ctx, x, w1, b1, w2, b2, ln_g, ln_b, eps: float, fork: bool = False):
         x, w1, w2 = _f32c(x), _f32c(w1), _f32c(w2)
         xn = ops.layernorm(x, ln_g.detach(), ln_b.detach(), eps) if ln_g is not None else x
         h, pre = linear_act_fwd(xn, w1, b1, ops.ACT_GELU, True)
@@ -327,12 +336,13 @@ class MLPFn(torch.autograd.Function):
         ctx.save_for_backward(x, xn, pre, h, w1, w2, ln_g, b1, b2)
         ctx.eps = eps
         ctx.shared = shared_grads.note(w1, b1, w2, b2, ln_g)
-        return y
+        return (y, x) if fork else y             # fork: x again, for the skip connection around the MLP (see LayerNormFn)
 
     @staticmethod
-    def backward(ctx, g: Tensor):
+    def backward(ctx, g: Tensor, g_skip: Optional[Tensor] = None):
         x, xn, pre, h, w1, w2, ln_g, b1, b2 = ctx.saved_tensors
         g = _f32c(g)
+        skip = _f32c(g_skip) if g_skip is not None else None
         need = ctx.needs_input_grad
         sg, tok = shared_grads, ctx.shared
         dw2, db2 = _weight_bias_grads(tok, g, h, w2, b2, need[3], need[4])
@@ -340,20 +350,22 @@ class MLPFn(torch.autograd.Function):
         dw1, db1 = _weight_bias_grads(tok, dpre, xn, w1, b1, need[1], need[2])
         dx = dg = dbeta = None
         if need[0] or (ln_g is not None and (need[5] or need[6])):
-            dxn = linear_dgrad(dpre, w1)
             if ln_g is not None:
+                dxn = linear_dgrad(dpre, w1)
                 box = {}
 
                 def run(o, acc):
-                    box["dx"], dgb = layernorm_bwd(x, ln_g.detach(), dxn, ctx.eps, o, acc)
+                    box["dx"], dgb = layernorm_bwd(x, ln_g.detach(), dxn, ctx.eps, o, acc, add=skip)
                     return dgb
                 dgb = sg.deliver(tok, ln_g, run)
                 dx = box["dx"]
                 if dgb is not None:
                     dg, dbeta = dgb[0], dgb[1]
             else:
-                dx = dxn
-        return dx, dw1, db1, dw2, db2, dg, dbeta, None
+                dx = linear_dgrad(dpre, w1, add=skip)                   # the skip gradient joins in the GEMM's epilogue
+        elif skip is not None:
+            dx = skip
+        return dx, dw1, db1, dw2, db2, dg, dbeta, None, None
 
 
 class InstNormFn(torch.autograd.Function):
@@ -464,6 +476,34 @@ class MulAddFn(torch.autograd.Function):
         with torch.cuda.device(g.device):
             _check(load_library().master_mul_add_bwd(_p(g), _p(q), _p(sigma), _p(dq), _p(ds), q.numel(), F32, _stream()), "master_mul_add_bwd")
         return dq, ds, g
+
+
+class BiasTileFn(torch.autograd.Function):
+    """relative_position_bias_table [entries, heads] -> the [heads,64,64] bias tile of the attention kernels (style_transformer.py:21-28;
+    rows >= N zero, key slots >= N at -1e30): one launch each way (master_bias_tile_fwd / _bwd)"""
+
+    @staticmethod
+    @ops._on_device
+    def forward(ctx, table: Tensor, index: Tensor, N: int):
+        table = _f32c(table)
+        index = index.reshape(-1).contiguous()
+        assert index.dtype == torch.int64 and index.numel() == N * N
+        heads = table.shape[1]
+        tile = torch.empty((heads, 64, 64), dtype=F, device=table.device)
+        _check(load_library().master_bias_tile_fwd(_p(table), _p(index), _p(tile), N, heads, _stream()), "master_bias_tile_fwd")
+        ctx.save_for_backward(index)
+        ctx.dims = (N, heads, table.shape[0])
+        return tile
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (index,) = ctx.saved_tensors
+        N, heads, entries = ctx.dims
+        g = _f32c(g)
+        dtable = torch.empty((entries, heads), dtype=F, device=g.device)
+        with torch.cuda.device(g.device):
+            _check(load_library().master_bias_tile_bwd(_p(g), _p(index), _p(dtable), N, heads, entries, _stream()), "master_bias_tile_bwd")
+        return dtable, None, None
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------
@@ -594,7 +634,7 @@ def _pad32(c: int) -> int:
 @ops._on_device
 def conv_backward(g: Tensor, y_relu: Optional[Tensor], x: Tensor, weight: Tensor, upsample: bool, reflect: bool, g_nchw: bool,
                   need_dx: bool, need_dw: bool, need_db: bool, dgrad_relu_src: Optional[Tensor] = None, dgrad_add: Optional[Tensor] = None,
-                  premasked: bool = False):
+                  premasked: bool = False, wf: Optional[Tensor] = None):
     """shared by the decoder (reflect) and VGG (zero padding) convolutions.  g: gradient of the conv (+ReLU) output, NHWC or NCHW;
     y_relu: the ReLU output (None: no ReLU or g already masked); x: the conv input NHWC [B,Hin,Win,Cin]; weight [Cout,Cin,3,3].
     Returns (dx NHWC like x, dweight, dbias)."""
@@ -627,10 +667,8 @@ def conv_backward(g: Tensor, y_relu: Optional[Tensor], x: Tensor, weight: Tensor
         dw = dwp[:Cout].permute(0, 3, 1, 2).contiguous()                               # [Cout,3,3,Cin] -> [Cout,Cin,3,3]
     dx = None
     if need_dx:
-        wf = weight.detach().flip(2, 3).permute(1, 2, 3, 0)                            # [Cin][3][3][Cout], taps flipped
-        if Cp != Cout:
-            wf = torch.nn.functional.pad(wf, (0, Cp - Cout))
-        wf = wf.contiguous()
+        if wf is None:                                                                 # [Cin][3][3][Cp], taps flipped (the forward packs it when it can)
+            wf = conv_weight_pack(weight, want_flipped=True)[1]
         if ops._COUNT_ON:
             ops._count("conv_dgrad", flops=2.0 * B * H * W * Cout * 9 * Cin, bytes=4.0 * (B * H * W * (Cout + Cin) + Cout * 9 * Cin))
         if reflect:
@@ -645,22 +683,34 @@ def conv_backward(g: Tensor, y_relu: Optional[Tensor], x: Tensor, weight: Tensor
     return dx, dw, db
 
 
+@ops._on_device
+def conv_weight_pack(weight: Tensor, want_flipped: bool):
+    """nn.Conv2d weight [Cout,Cin,3,3] -> (wp [Cout,3,3,Cin], wf [Cin,3,3,Cp] or None) in one launch (master_conv_weight_pack)"""
+    w = _f32c(weight.detach())
+    Cout, Cin = w.shape[:2]
+    Cp = _pad32(Cout)
+    wp = torch.empty((Cout, 3, 3, Cin), dtype=F, device=w.device)
+    wf = torch.empty((Cin, 3, 3, Cp), dtype=F, device=w.device) if want_flipped else None
+    _check(load_library().master_conv_weight_pack(_p(w), _p(wp), _p(wf), Cout, Cin, Cp, _stream()), "master_conv_weight_pack")
+    return wp, wf
+
+
 class ConvReflectFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, bias: Tensor, upsample: bool, relu: bool, out_nchw: bool):
         x = _f32c(x)
-        wp = weight.detach().permute(0, 2, 3, 1).contiguous()
+        wp, wf = conv_weight_pack(weight, want_flipped=x.requires_grad)          # the data gradient's layout comes out of the same launch
         y = ops.conv3x3_reflect(x, wp, bias.detach().float().contiguous(), upsample=upsample, relu=relu, out_nchw=out_nchw)
-        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.save_for_backward(x, weight, y if relu else None, wf)
         ctx.flags = (upsample, relu, out_nchw)
         return y
 
     @staticmethod
     def backward(ctx, g: Tensor):
-        x, weight, y = ctx.saved_tensors
+        x, weight, y, wf = ctx.saved_tensors
         upsample, relu, out_nchw = ctx.flags
         dx, dw, db = conv_backward(_f32c(g), y, x, weight, upsample, True, out_nchw, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                   ctx.needs_input_grad[2])
+                                   ctx.needs_input_grad[2], wf=wf)
         return dx, dw, db, None, None, None
 
 

@@ -19,7 +19,7 @@ int linear_ts_group_bf16(int, const bf16_t* const*, const bf16_t* const*, const 
                          const float*, const float*, int, int, float, hipStream_t);
 int gemm_f32_conv3x3_dgrad(const float*, const float*, float*, const float*, const float*, int, int, int, int, int, int, hipStream_t);
 size_t gemm_f32_t_workspace(int, int);
-int gemm_f32_dgrad(const float*, const float*, float*, const float*, int, int, int, int, int, int, hipStream_t);
+int gemm_f32_dgrad(const float*, const float*, float*, const float*, const float*, int, int, int, int, int, int, int, hipStream_t);
 int gemm_f32_wgrad(const float*, const float*, float*, float*, int, int, int, int, int, float*, size_t, hipStream_t, int accumulate = 0);
 int gemm_f32_conv3x3_wgrad(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, float*, size_t, hipStream_t);
 int reduce_slabs_launch(const float*, float*, size_t, size_t, int, hipStream_t, int accumulate = 0);
@@ -42,10 +42,13 @@ int adam_launch(const void*, int, long long, float, float, float, float, float, 
 int lerp_launch(const void*, int, long long, float, hipStream_t);
 int loss_tap_slices(int);
 int loss_terms_launch(const float*, const float*, const float*, int, float*, float*, float*, int, int, int, int, int, hipStream_t);
+int conv_weight_pack_launch(const float*, float*, float*, int, int, int, hipStream_t);
+int bias_tile_fwd_launch(const float*, const long long*, float*, int, int, hipStream_t);
+int bias_tile_bwd_launch(const float*, const long long*, float*, int, int, int, hipStream_t);
 template <typename T> int loss_tap_bwd_launch(const void*, const float*, const float*, const float*, const float*, float*, void*, int, int, int,
                                               float, float, const float*, const float*, int, int, hipStream_t);
 int layernorm_bwd_blocks(int);
-int layernorm_bwd_launch(const float*, const float*, const float*, float*, float*, float*, int, int, float, hipStream_t, int accumulate = 0);
+int layernorm_bwd_launch(const float*, const float*, const float*, float*, float*, float*, int, int, float, hipStream_t, int accumulate = 0, const float* add = nullptr);
 int instnorm_bwd_launch(const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, float, hipStream_t);
 int window_attn_bwd_f32(const float*, const float*, const float*, const float*, int, int, int, const float*, const float*, const float*, int,
                         int, const float*, const int32_t*, const uint8_t*, const int32_t*, const float*, const float*, int, float*, float*,
@@ -158,15 +161,16 @@ int master_linear_act_fwd(const void* a, const void* w, const void* bias, void* 
                            (float*)aux);
 }
 
-int master_linear_dgrad(const void* g, const void* w, void* da, const void* gelu_pre, int M, int N, int K, int ldg, int ldda, int ld_pre,
-                        int dtype, master_stream_t stream) {
+int master_linear_dgrad(const void* g, const void* w, void* da, const void* gelu_pre, const void* add, int M, int N, int K, int ldg, int ldda,
+                        int ld_pre, int ld_add, int dtype, master_stream_t stream) {
     F32_ONLY("linear_dgrad");
     REQUIRE(g && w && da, "linear_dgrad: null operand");
     REQUIRE(M > 0 && N > 0 && K > 0 && N % 32 == 0 && K % 4 == 0 && ldg >= N && ldda >= K, "linear_dgrad: bad dims M=%d N=%d K=%d", M, N, K);
     REQUIRE(al16(g) && al16(w) && ldg % 4 == 0, "linear_dgrad: g/w must be 16-byte aligned, ldg %% 4 == 0");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_LINEAR_BWD, s);
-    return gemm_f32_dgrad((const float*)g, (const float*)w, (float*)da, (const float*)gelu_pre, M, N, K, ldg, ldda, ld_pre, s);
+    REQUIRE(add == nullptr || ld_add >= K, "linear_dgrad: ld_add < K");
+    return gemm_f32_dgrad((const float*)g, (const float*)w, (float*)da, (const float*)gelu_pre, (const float*)add, M, N, K, ldg, ldda, ld_pre, ld_add, s);
 }
 
 size_t master_gemm_workspace_floats(int rows, int cols) { return gemm_f32_t_workspace(rows, cols); }
@@ -245,14 +249,15 @@ int master_reduce_segments(const master_reduce_seg* segs, int count, master_stre
 }
 
 size_t master_layernorm_bwd_workspace_floats(int M, int C) { return (size_t)layernorm_bwd_blocks(M) * 2 * (size_t)C; }
-int master_layernorm_bwd(const void* x, const float* gamma, const void* g, void* dx, float* dgb, float* ws, int M, int C, float eps, int dtype,
-                         master_stream_t stream) {
+int master_layernorm_bwd(const void* x, const float* gamma, const void* g, const void* add, void* dx, float* dgb, float* ws, int M, int C, float eps,
+                         int dtype, master_stream_t stream) {
     const int accumulate = (dtype & MASTER_ACCUMULATE) != 0; dtype &= ~MASTER_ACCUMULATE;
     F32_ONLY("layernorm_bwd");
     REQUIRE(x && gamma && g && dx && dgb && ws && M > 0, "layernorm_bwd: null operand");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_LAYERNORM, s);
-    return layernorm_bwd_launch((const float*)x, gamma, (const float*)g, (float*)dx, dgb, ws, M, C, eps, s, accumulate);
+    REQUIRE(add == nullptr || al16(add), "layernorm_bwd: add must be 16-byte aligned");
+    return layernorm_bwd_launch((const float*)x, gamma, (const float*)g, (float*)dx, dgb, ws, M, C, eps, s, accumulate, (const float*)add);
 }
 
 int master_instnorm_bwd(const void* x, const void* g, const void* pad_row_in, const void* g_pad, void* dx, void* dpad, int B, int T, int C,
@@ -335,6 +340,27 @@ int master_fold_reflect(const void* dxp, void* out, int B, int H, int W, int C, 
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_TRAIN_MISC, s);
     return fold_reflect_launch((const float*)dxp, (float*)out, B, H, W, C, upsample, s);
+}
+
+int master_conv_weight_pack(const float* w, float* wp, float* wf, int Cout, int Cin, int Cp, master_stream_t stream) {
+    REQUIRE(w && wp && Cout > 0 && Cin > 0 && Cp >= Cout, "conv_weight_pack: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_TRAIN_MISC, s);
+    return conv_weight_pack_launch(w, wp, wf, Cout, Cin, Cp, s);
+}
+
+int master_bias_tile_fwd(const float* table, const long long* index, float* tile, int N, int heads, master_stream_t stream) {
+    REQUIRE(table && index && tile && N > 0 && N <= 64 && heads > 0, "bias_tile_fwd: bad arguments (N=%d heads=%d)", N, heads);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_TRAIN_MISC, s);
+    return bias_tile_fwd_launch(table, index, tile, N, heads, s);
+}
+
+int master_bias_tile_bwd(const float* dtile, const long long* index, float* dtable, int N, int heads, int entries, master_stream_t stream) {
+    REQUIRE(dtile && index && dtable && N > 0 && N <= 64 && heads > 0 && entries > 0, "bias_tile_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_TRAIN_MISC, s);
+    return bias_tile_bwd_launch(dtile, index, dtable, N, heads, entries, s);
 }
 
 int master_maxpool2x2_bwd(const void* g, const void* y, void* dx, int N, int H, int W, int C, int dtype, master_stream_t stream) {

@@ -42,6 +42,9 @@ struct TArgs {
     int Hin, Win, Cin, Hout, Wout, up, zero_pad;
     // contraction-major A only: rowsum[blockIdx.y * rowsum_slab + m] = sum over this split's contraction rows of a[k][m]  (NULL: not wanted)
     float* rowsum; size_t rowsum_slab;
+    // data-gradient form (one split): out += add[m][n] after the GELU factor - the gradient arriving over a skip connection (r03: autograd
+    // added it with one elementwise launch per residual block)
+    const float* add; int ld_add;
 };
 
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
@@ -234,7 +237,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_t_kernel(
     // loads of the GELU pre-activation, float4 stores); the element-wise form below (4-byte accesses behind per-element branches,
     // serialised by hipcc into load -> wait -> store chains) stays for outputs it alone can address.
     const bool vec_ok = (p.N & 3) == 0 && (p.ldo & 3) == 0 && (((uintptr_t)outp) & 15) == 0 &&
-                        (!p.aux || ((p.ld_aux & 3) == 0 && (((uintptr_t)p.aux) & 15) == 0));
+                        (!p.aux || ((p.ld_aux & 3) == 0 && (((uintptr_t)p.aux) & 15) == 0)) &&
+                        (!p.add || ((p.ld_add & 3) == 0 && (((uintptr_t)p.add) & 15) == 0));
     if (vec_ok) {
         constexpr int VPR = BN / 4;
         constexpr int PIECES = BM * VPR / NT;
@@ -257,7 +261,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_t_kernel(
         constexpr int BATCH = PIECES < 4 ? PIECES : 4;
 #pragma unroll
         for (int b0 = 0; b0 < PIECES; b0 += BATCH) {
-            f32x4 v[BATCH], ax[BATCH];
+            f32x4 v[BATCH], ax[BATCH], ad[BATCH];
             size_t orow[BATCH];
             bool ok[BATCH];
 #pragma unroll
@@ -269,6 +273,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_t_kernel(
                 orow[it] = (size_t)m;
                 v[it] = *(const f32x4*)(tile + row * BN + c4 * 4);
                 if (p.aux) ax[it] = *(const f32x4*)(p.aux + (size_t)m * p.ld_aux + n);
+                if (p.add) ad[it] = *(const f32x4*)(p.add + (size_t)m * p.ld_add + n);
             }
 #pragma unroll
             for (int it = 0; it < BATCH; ++it) {
@@ -277,6 +282,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_t_kernel(
 #pragma unroll
                     for (int c = 0; c < 4; ++c) x[c] *= gelu_grad(ax[it][c]);
                 }
+                if (p.add) x += ad[it];
                 if (ok[it]) *(f32x4*)(outp + orow[it] * p.ldo + n) = x;
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -295,6 +301,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_t_kernel(
                 if (m >= p.M) continue;
                 float v = acc[i][jn][e];
                 if (p.aux) v *= gelu_grad(p.aux[(size_t)m * p.ld_aux + n]);
+                if (p.add) v += p.add[(size_t)m * p.ld_add + n];
                 outp[(size_t)m * p.ldo + n] = v;
             }
         }
@@ -350,9 +357,9 @@ size_t gemm_f32_t_workspace(int M, int N) {
 }
 
 // dX[M,Kc] = G[M,Nc] . W[Nc,Kc] (* gelu'(aux) when aux != NULL)
-int gemm_f32_dgrad(const float* g, const float* w, float* out, const float* aux, int M, int Nc, int Kc, int ldg, int ldo, int ld_aux,
-                   hipStream_t s) {
-    TArgs p{g, w, out, M, Kc, Nc, ldg, Kc, ldo, 0, 0, aux, ld_aux, 0, 0, 0, 0, 0, 0, 0, nullptr, 0};
+int gemm_f32_dgrad(const float* g, const float* w, float* out, const float* aux, const float* add, int M, int Nc, int Kc, int ldg, int ldo, int ld_aux,
+                   int ld_add, hipStream_t s) {
+    TArgs p{g, w, out, M, Kc, Nc, ldg, Kc, ldo, 0, 0, aux, ld_aux, 0, 0, 0, 0, 0, 0, 0, nullptr, 0, add, ld_add};
     if (Kc > 64) {
         // fewer than one 128x128 tile per CU (the StyleTransformer's 8 192-token matrices): 64-row tiles double the workgroups
         // (r03: 64x64 tiles, four workgroups per CU, for the 8 192-token matrices: 512+ workgroups instead of 256 one-per-CU ones)
@@ -370,7 +377,7 @@ int gemm_f32_dgrad(const float* g, const float* w, float* out, const float* aux,
 // dW[Nc,Kc] = G[M,Nc]^T . X[M,Kc]      (dense output, ldo = Kc);  dbias[Nc] = column sums of G when dbias != NULL
 int gemm_f32_wgrad(const float* g, const float* x, float* out, float* dbias, int M, int Nc, int Kc, int ldg, int ldx, float* ws, size_t ws_floats,
                    hipStream_t s, int accumulate) {
-    TArgs p{g, x, out, Nc, Kc, M, ldg, ldx, Kc, 0, 0, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, nullptr, 0};
+    TArgs p{g, x, out, Nc, Kc, M, ldg, ldx, Kc, 0, 0, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, nullptr, 0, nullptr, 0};
     if (Nc > 64) return launch_t<128, 128, 64, 64, true, false>(p, out, ws, ws_floats, 0, s, accumulate, dbias);
     return launch_t<32, 256, 32, 64, true, false>(p, out, ws, ws_floats, 0, s, accumulate, dbias);
 }
@@ -379,7 +386,7 @@ int gemm_f32_wgrad(const float* g, const float* x, float* out, float* dbias, int
 int gemm_f32_conv3x3_wgrad(const float* g, const float* x, float* out, float* dbias, int B, int Hin, int Win, int Cin, int Cout, int ldg, int up,
                            int zero_pad, float* ws, size_t ws_floats, hipStream_t s) {
     const int Hout = Hin << up, Wout = Win << up;
-    TArgs p{g, x, out, Cout, 9 * Cin, B * Hout * Wout, ldg, 0, 9 * Cin, 0, 0, nullptr, 0, Hin, Win, Cin, Hout, Wout, up, zero_pad, nullptr, 0};
+    TArgs p{g, x, out, Cout, 9 * Cin, B * Hout * Wout, ldg, 0, 9 * Cin, 0, 0, nullptr, 0, Hin, Win, Cin, Hout, Wout, up, zero_pad, nullptr, 0, nullptr, 0};
     if (Cout > 64) return launch_t<128, 128, 64, 64, true, true>(p, out, ws, ws_floats, 0, s, 0, dbias);
     if (Cout > 32) return launch_t<64, 128, 32, 64, true, true>(p, out, ws, ws_floats, 0, s, 0, dbias);
     return launch_t<32, 256, 32, 64, true, true>(p, out, ws, ws_floats, 0, s, 0, dbias);

@@ -12,7 +12,8 @@ namespace {
 //      part[block][2][C]: per-workgroup partial dgamma | dbeta (added by reduce_slabs in block order). -------------------------------------
 template <int CH>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ g,
-                                                            float* __restrict__ dx, float* __restrict__ part, int M, int C, float eps) {
+                                                            float* __restrict__ dx, float* __restrict__ part, int M, int C, float eps,
+                                                            const float* __restrict__ add) {
     extern __shared__ float red[];                                // [4][2][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nchunk = C >> 2;
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                     adg[i][e] += gv[i][e] * xv[i][e];
                     adb[i][e] += gv[i][e];
                 }
+                if (add) o += *(const f32x4*)(add + (size_t)row * C + 4 * c4);       // + the gradient arriving over the skip connection around this norm
                 *(f32x4*)(dx + (size_t)row * C + 4 * c4) = o;
             }
         }
@@ -175,14 +177,15 @@ __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restri
 
 int layernorm_bwd_blocks(int M) { int b = (M + 15) / 16; return b > 512 ? 512 : (b < 1 ? 1 : b); }
 // ws: layernorm_bwd_blocks(M) * 2 * C floats; dgb: [2][C] = dgamma | dbeta
-int layernorm_bwd_launch(const float* x, const float* gamma, const float* g, float* dx, float* dgb, float* ws, int M, int C, float eps, hipStream_t s, int accumulate) {
+int layernorm_bwd_launch(const float* x, const float* gamma, const float* g, float* dx, float* dgb, float* ws, int M, int C, float eps, hipStream_t s, int accumulate,
+                         const float* add) {
     if (C % 4 != 0 || C > 1024) { master_set_error("layernorm_bwd: C %% 4 == 0 and C <= 1024 (C=%d)", C); return MASTER_ERR_INVALID; }
     const int blocks = layernorm_bwd_blocks(M);
     const size_t lds = (size_t)8 * C * sizeof(float);
     const int ch = (C / 4 + 63) / 64;
-    if (ch == 1) hipLaunchKernelGGL((layernorm_bwd_kernel<1>), dim3(blocks), dim3(256), lds, s, x, gamma, g, dx, ws, M, C, eps);
-    else if (ch == 2) hipLaunchKernelGGL((layernorm_bwd_kernel<2>), dim3(blocks), dim3(256), lds, s, x, gamma, g, dx, ws, M, C, eps);
-    else hipLaunchKernelGGL((layernorm_bwd_kernel<4>), dim3(blocks), dim3(256), lds, s, x, gamma, g, dx, ws, M, C, eps);
+    if (ch == 1) hipLaunchKernelGGL((layernorm_bwd_kernel<1>), dim3(blocks), dim3(256), lds, s, x, gamma, g, dx, ws, M, C, eps, add);
+    else if (ch == 2) hipLaunchKernelGGL((layernorm_bwd_kernel<2>), dim3(blocks), dim3(256), lds, s, x, gamma, g, dx, ws, M, C, eps, add);
+    else hipLaunchKernelGGL((layernorm_bwd_kernel<4>), dim3(blocks), dim3(256), lds, s, x, gamma, g, dx, ws, M, C, eps, add);
     return reduce_slabs_launch(ws, dgb, (size_t)2 * C, (size_t)2 * C, blocks, s, accumulate);
 }
 int instnorm_bwd_launch(const float* x, const float* g, const float* pad_in, const float* g_pad, float* dx, float* dpad, int B, int Tn, int C,

@@ -297,6 +297,59 @@ __global__ __launch_bounds__(256) void loss_tap_bwd_kernel(const T* __restrict__
     }
 }
 
+// ---- weight layouts of a trainable 3x3 convolution, both in one launch (r03: permute/flip/pad/contiguous were four torch launches per
+//      convolution and step):  w [Cout][Cin][3][3] (nn.Conv2d) ->  wp [Cout][3][3][Cin] for the forward and the weight gradient,
+//      wf [Cin][3][3][Cp] = taps flipped, channels swapped, Cout zero-padded to Cp, for the data gradient (a convolution of g with wf) ----
+__global__ __launch_bounds__(256) void conv_weight_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, float* __restrict__ wf, int Cout,
+                                                               int Cin, int Cp, size_t n_wp, size_t n_wf) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_wp) {
+        const int ci = (int)(i % Cin), tap = (int)((i / Cin) % 9), co = (int)(i / ((size_t)9 * Cin));
+        wp[i] = w[((size_t)co * Cin + ci) * 9 + tap];
+    }
+    if (wf && i < n_wf) {
+        const int co = (int)(i % Cp), tap = (int)((i / Cp) % 9), ci = (int)(i / ((size_t)9 * Cp));
+        wf[i] = co < Cout ? w[((size_t)co * Cin + ci) * 9 + (8 - tap)] : 0.f;
+    }
+}
+
+// ---- relative-position bias tile (style_transformer.py:21-28 + the key-slot padding of the attention kernels):
+//      tile[h][i][j] = table[index[i*N + j]][h] for i, j < N; 0 for i >= N; -1e30 for j >= N (padded key slots never win the softmax).
+//      Backward: dtable[e][h] = sum over the (i, j) with index[i*N + j] == e of dtile[h][i][j] - a gather over the N*N positions per
+//      table entry (deterministic; torch's index_put backward sorts the indices: ~10 launches). ----------------------------------------
+__global__ __launch_bounds__(256) void bias_tile_fwd_kernel(const float* __restrict__ table, const long long* __restrict__ index, float* __restrict__ tile,
+                                                            int N, int heads) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= heads * 4096) return;
+    const int j = t & 63, i = (t >> 6) & 63, h = t >> 12;
+    float v = 0.f;
+    if (j >= N) v = -1e30f;
+    else if (i < N) v = table[(size_t)index[i * N + j] * heads + h];
+    tile[t] = v;
+}
+// one workgroup per table entry: its threads walk the N*N positions once (index compared in registers), then one block sum per head
+__global__ __launch_bounds__(256) void bias_tile_bwd_kernel(const float* __restrict__ dtile, const long long* __restrict__ index, float* __restrict__ dtable,
+                                                            int N, int heads, int entries) {
+    __shared__ float red[4];
+    const int e = blockIdx.x, tid = threadIdx.x, NN = N * N;
+    int off[16];                                              // tile offsets of this thread's matching positions (N <= 64: at most 16 per thread), -1 = none
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int p = tid + 256 * q;
+        off[q] = (p < NN && index[p] == e) ? (p / N) * 64 + (p % N) : -1;
+    }
+    for (int h = 0; h < heads; ++h) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) if (off[q] >= 0) s += dtile[(size_t)h * 4096 + off[q]];
+        s = wave_sum(s);
+        if ((tid & 63) == 0) red[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) dtable[(size_t)e * heads + h] = (red[0] + red[1]) + (red[2] + red[3]);
+        __syncthreads();
+    }
+}
+
 // ---- the scalar arithmetic of one tap of the perceptual loss (codes/loss.py:112-130 content term, :272-322 style term), one workgroup:
 //   losses[0] (+)= sum(dist_partial) / (B*C*HW)                                  (the |IN - IN| partials of master_instnorm_distance_fwd)
 //   losses[1] (+)= mean_{i,c} f(mean_s - mean_o) + mean_{i,c} f(std_s - std_o)    f = |.| or (.)^2, std unbiased
@@ -454,6 +507,19 @@ int relu_mask_launch(const float* g, const float* relu_out, float* gm, int B, in
     const size_t total = (size_t)B * HW * Cp;
     hipLaunchKernelGGL(relu_mask_kernel, dim3(blocks_for(total)), dim3(256), 0, s, g, relu_out, gm, HW, C, Cp, g_nchw, total);
     return master_check_launch("relu_mask");
+}
+int conv_weight_pack_launch(const float* w, float* wp, float* wf, int Cout, int Cin, int Cp, hipStream_t s) {
+    const size_t n_wp = (size_t)Cout * 9 * Cin, n_wf = wf ? (size_t)Cin * 9 * Cp : 0, total = n_wp > n_wf ? n_wp : n_wf;
+    hipLaunchKernelGGL(conv_weight_pack_kernel, dim3(blocks_for(total)), dim3(256), 0, s, w, wp, wf, Cout, Cin, Cp, n_wp, n_wf);
+    return master_check_launch("conv_weight_pack");
+}
+int bias_tile_fwd_launch(const float* table, const long long* index, float* tile, int N, int heads, hipStream_t s) {
+    hipLaunchKernelGGL(bias_tile_fwd_kernel, dim3((heads * 4096 + 255) / 256), dim3(256), 0, s, table, index, tile, N, heads);
+    return master_check_launch("bias_tile_fwd");
+}
+int bias_tile_bwd_launch(const float* dtile, const long long* index, float* dtable, int N, int heads, int entries, hipStream_t s) {
+    hipLaunchKernelGGL(bias_tile_bwd_kernel, dim3(entries), dim3(256), 0, s, dtile, index, dtable, N, heads, entries);
+    return master_check_launch("bias_tile_bwd");
 }
 int fold_reflect_launch(const float* dxp, float* out, int B, int H, int W, int C, int up, hipStream_t s) {
     const size_t total = (size_t)B * (H >> up) * (W >> up) * (C / 4);

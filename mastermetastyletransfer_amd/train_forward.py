@@ -120,25 +120,32 @@ def _bias64(attn) -> Tensor:
 
 
 def _bias64_build(attn) -> Tensor:
+    from .autograd import BiasTileFn
     N = attn.window_size[0] * attn.window_size[1]
-    t = attn.relative_position_bias_table
-    b = t[attn.relative_position_index].view(N, N, -1).permute(2, 0, 1)                  # [heads,N,N]
-    b = torch.nn.functional.pad(b, (0, 64 - N, 0, 64 - N))
-    neg = torch.zeros((64, 64), dtype=t.dtype, device=t.device)
-    neg[:, N:] = -1e30
-    return (b + neg).contiguous()
+    return BiasTileFn.apply(attn.relative_position_bias_table, attn.relative_position_index, N)
 
 
-def _mlp(mlp: nn.Sequential, x: Tensor, norm: Optional[nn.LayerNorm] = None) -> Tensor:
+def _mlp(mlp: nn.Sequential, x: Tensor, norm: Optional[nn.LayerNorm] = None, fork: bool = False):
     return MLPFn.apply(x, mlp[0].weight, mlp[0].bias, mlp[3].weight, mlp[3].bias,
                        norm.weight if norm is not None else None, norm.bias if norm is not None else None,
-                       norm.eps if norm is not None else 1e-5)
+                       norm.eps if norm is not None else 1e-5, fork)
+
+
+def _mlp_residual(mlp: nn.Sequential, x: Tensor, norm: Optional[nn.LayerNorm], p: float, training: bool, sd: StochasticDepthMasks, B: int,
+                  T: int) -> Tensor:
+    """x + StochasticDepth(mlp(norm(x))).  The skip connection starts at the alias of x that MLPFn hands back, so x has one consumer and
+    the skip gradient is added inside the MLP's backward kernels (no autograd add launch)."""
+    y, xs = _mlp(mlp, x, norm, fork=True)
+    return _residual(y, xs, p, training, sd, B, T)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # ShiftedWindowAttention (three inputs) -> projected attention outputs, one per value stream (no residual)
 # ---------------------------------------------------------------------------------------------------------------------------------------
-def attention(attn, xq: Tensor, xk: Tensor, xvs: Sequence[Tensor], B: int, H: int, W: int, norm: Optional[nn.LayerNorm] = None) -> List[Tensor]:
+def attention(attn, xq: Tensor, xk: Tensor, xvs: Sequence[Tensor], B: int, H: int, W: int, norm: Optional[nn.LayerNorm] = None,
+              skips: Optional[dict] = None) -> List[Tensor]:
+    """skips (out): id(input tensor) -> the alias of it that the LayerNorm handed back (LayerNormFn fork).  A caller that uses the alias
+    for everything else the tensor feeds (the skip connection of the block) leaves the norm as the tensor's only consumer."""
     C = xq.shape[1]
     T = H * W
     plan = window_plan(H, W, attn.window_size, attn.shift_size, xq.device)
@@ -150,7 +157,11 @@ def attention(attn, xq: Tensor, xk: Tensor, xvs: Sequence[Tensor], B: int, H: in
             for src, o in memo:
                 if src is t:
                     return o
-            o = LayerNormFn.apply(t, norm.weight, norm.bias, norm.eps)
+            if skips is not None:
+                o, alias = LayerNormFn.apply(t, norm.weight, norm.bias, norm.eps, True)
+                skips[id(t)] = alias
+            else:
+                o = LayerNormFn.apply(t, norm.weight, norm.bias, norm.eps)
             memo.append((t, o))
             return o
         xq, xk, xvs = ln(xq), ln(xk), [ln(v) for v in xvs]
@@ -192,10 +203,11 @@ def block(blk, xq: Tensor, xk: Tensor, xvs: Sequence[Tensor], residuals: Sequenc
     """StyleSwinTransformerBlock.forward (:376-398) for one q/k pair and one or two value streams"""
     T = H * W
     p = blk.stochastic_depth_prob
-    branches = attention(blk.attn, xq, xk, xvs, B, H, W, norm=blk.norm1 if blk.use_norm else None)
-    outs = [_residual(br, res, p, blk.training, sd, B, T) for br, res in zip(branches, residuals)]
+    skips: dict = {}
+    branches = attention(blk.attn, xq, xk, xvs, B, H, W, norm=blk.norm1 if blk.use_norm else None, skips=skips)
+    outs = [_residual(br, skips.get(id(res), res), p, blk.training, sd, B, T) for br, res in zip(branches, residuals)]
     if not blk.exclude_MLP_after:
-        outs = [_residual(_mlp(blk.mlp, o, blk.norm2 if blk.use_norm else None), o, p, blk.training, sd, B, T) for o in outs]
+        outs = [_mlp_residual(blk.mlp, o, blk.norm2 if blk.use_norm else None, p, blk.training, sd, B, T) for o in outs]
     return outs
 
 
@@ -208,23 +220,24 @@ def style_encoder(enc, key: Tensor, scale: Tensor, shift: Tensor, B, H, W, sd: S
 
     def do_key(key):
         key = block(blk, key, key, [key], [key], B, H, W, sd)[0]                                       # :859-864
-        return _residual(_mlp(enc.encoder_MLP_Key, key), key, p_enc, tr, sd, B, T)                     # :865
+        return _mlp_residual(enc.encoder_MLP_Key, key, None, p_enc, tr, sd, B, T)                      # :865
 
     def do_scale_shift(key, scale, shift):
         # :867-882: both calls use q = k = Key: one softmax, two value streams; the residual adds draw their masks in the reference's
-        # order (attn Scale, MLP Scale, attn Shift, MLP Shift)
-        br_s, br_sh = attention(blk.attn, key, key, [scale, shift], B, H, W, norm=blk.norm1 if blk.use_norm else None)
-        s = _residual(br_s, scale, p_blk, blk.training, sd, B, T)
-        s = _residual(_mlp(enc.encoder_MLP_Scale, s), s, p_enc, tr, sd, B, T)
-        sh = _residual(br_sh, shift, p_blk, blk.training, sd, B, T)
-        sh = _residual(_mlp(enc.encoder_MLP_Shift, sh), sh, p_enc, tr, sd, B, T)
-        return s, sh
+        # order (attn Scale, MLP Scale, attn Shift, MLP Shift).  Returns the Key to hand on as well: the alias its LayerNorm gave back
+        skips: dict = {}
+        br_s, br_sh = attention(blk.attn, key, key, [scale, shift], B, H, W, norm=blk.norm1 if blk.use_norm else None, skips=skips)
+        s = _residual(br_s, skips.get(id(scale), scale), p_blk, blk.training, sd, B, T)
+        s = _mlp_residual(enc.encoder_MLP_Scale, s, None, p_enc, tr, sd, B, T)
+        sh = _residual(br_sh, skips.get(id(shift), shift), p_blk, blk.training, sd, B, T)
+        sh = _mlp_residual(enc.encoder_MLP_Shift, sh, None, p_enc, tr, sd, B, T)
+        return s, sh, skips.get(id(key), key)
 
     if enc.if_use_processed_Key_in_Scale_and_Shift_calculation:
         key = do_key(key)
-        scale, shift = do_scale_shift(key, scale, shift)
+        scale, shift, key = do_scale_shift(key, scale, shift)
     else:
-        scale, shift = do_scale_shift(key, scale, shift)
+        scale, shift, key = do_scale_shift(key, scale, shift)
         key = do_key(key)
     return key, scale, shift
 
@@ -302,7 +315,7 @@ def style_decoder(dec, fcs: Tensor, key: Tensor, scale: Tensor, shift: Tensor, B
         sigma, mu = sigma_mu(dec.decoder_MHA_for_sigma_and_mu, q_in, k_in, scale, shift, B, H, W)     # :1059
     query = MulAddFn.apply(query, sigma, mu)                                                          # :1123
     p = dec.decoder_stochastic_depth_prob                                                             # (:989)
-    return _residual(_mlp(dec.last_MLP, query), query, p, dec.training, sd, B, T)                     # :1125
+    return _mlp_residual(dec.last_MLP, query, None, p, dec.training, sd, B, T)                        # :1125
 
 
 def _mask_order(st, k: int) -> List[float]:

@@ -90,6 +90,79 @@ def test_layernorm_backward(cuda, M, C):
     check("dx", xd.grad, x.grad); check("dgamma", wd.grad, gw.grad); check("dbeta", bd.grad, gb.grad)
 
 
+@pytest.mark.parametrize("M,C,HID,ln", [(2048, 256, 1024, True), (700, 256, 1024, False), (130, 128, 512, False)])
+def test_forked_skip_connections_backward(cuda, M, C, HID, ln):
+    """x + 0.7 * mlp(norm?(x)) and x + LayerNorm(x) * 2 with the skip connection taken from the alias the Function hands back: x has a
+    single consumer and the skip gradient is added inside the backward kernels (LayerNorm backward / fc1 data-gradient epilogue)"""
+    from mastermetastyletransfer_amd.autograd import LayerNormFn, MLPFn
+    g = torch.Generator().manual_seed(M + 1)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).requires_grad_(True)
+    x, w1, b1, w2, b2 = mk(M, C), mk(HID, C, sc=C ** -0.5), mk(HID, sc=0.3), mk(C, HID, sc=HID ** -0.5), mk(C, sc=0.3)
+    gw, gb = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True), mk(C, sc=0.2)
+    go = torch.randn(M, C, generator=g)
+    xin = F.layer_norm(x, (C,), gw, gb, 1e-5) if ln else x
+    ref = x + 0.7 * F.linear(F.gelu(F.linear(xin, w1, b1)), w2, b2)
+    ref = ref + 2.0 * F.layer_norm(ref, (C,), gw, gb, 1e-5)
+    ref.backward(go)
+    leaves = [x, w1, b1, w2, b2, gw, gb]
+    dl = [t.detach().to(cuda).requires_grad_(True) for t in leaves]
+    y, xs = MLPFn.apply(dl[0], dl[1], dl[2], dl[3], dl[4], dl[5] if ln else None, dl[6] if ln else None, 1e-5, True)
+    assert xs.data_ptr() == dl[0].data_ptr()
+    h = xs + 0.7 * y
+    n, hs = LayerNormFn.apply(h, dl[5], dl[6], 1e-5, True)
+    out = hs + 2.0 * n
+    check("out", out, ref, 1e-4)
+    out.backward(go.to(cuda))
+    for nm, d, r in zip("x w1 b1 w2 b2 gamma beta".split(), dl, leaves):
+        check(nm, d.grad, r.grad)
+
+
+def test_bias_tile_and_conv_weight_pack(cuda):
+    """the relative-position bias tile (style_transformer.py:21-28) and its table gradient; the three layouts of a trainable conv weight"""
+    from mastermetastyletransfer_amd.autograd import BiasTileFn, conv_weight_pack
+    g = torch.Generator().manual_seed(3)
+    for ws, heads in ((7, 8), (8, 4), (4, 3)):
+        N = ws * ws
+        table = torch.randn((2 * ws - 1) ** 2, heads, generator=g).requires_grad_(True)
+        coords = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")).flatten(1)
+        rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0) + (ws - 1)
+        index = (rel[..., 0] * (2 * ws - 1) + rel[..., 1]).reshape(-1)
+        ref = torch.zeros(heads, 64, 64)
+        ref[:, :N, :N] = table[index].view(N, N, heads).permute(2, 0, 1)
+        ref[:, :, N:] = -1e30
+        go = torch.randn(heads, 64, 64, generator=g)
+        (ref * go).sum().backward()
+        td = table.detach().to(cuda).requires_grad_(True)
+        tile = BiasTileFn.apply(td, index.to(cuda), N)
+        assert torch.equal(tile.cpu(), ref.detach())
+        (tile * go.to(cuda)).sum().backward()
+        check("dtable", td.grad, table.grad, 1e-5)
+    for Cout, Cin in ((128, 256), (3, 32), (64, 64)):
+        w = torch.randn(Cout, Cin, 3, 3, generator=g)
+        wp, wf = conv_weight_pack(w.to(cuda), True)
+        Cp = (Cout + 31) // 32 * 32
+        assert torch.equal(wp.cpu(), w.permute(0, 2, 3, 1).contiguous())
+        ref_f = torch.zeros(Cin, 3, 3, Cp)
+        ref_f[..., :Cout] = w.flip(2, 3).permute(1, 2, 3, 0)
+        assert torch.equal(wf.cpu(), ref_f)
+
+
+def test_reduce_segments(cuda):
+    """up to four slab reductions with their own split counts in one launch; accumulate adds to the output"""
+    from mastermetastyletransfer_amd.autograd import reduce_segments
+    g = torch.Generator().manual_seed(5)
+    shapes = [(37, 8 * 4096), (12, 256), (600, 256), (1, 100)]
+    parts = [torch.randn(k, n, generator=g) for k, n in shapes]
+    outs0 = [torch.randn(n, generator=g) for _, n in shapes]
+    accs = [False, True, False, True]
+    dp = [p_.to(cuda) for p_ in parts]
+    do = [o.clone().to(cuda) for o in outs0]
+    reduce_segments([(p_, o, p_.shape[1], p_.shape[1], p_.shape[0], a) for p_, o, a in zip(dp, do, accs)])
+    for p_, o0, o, a in zip(parts, outs0, do, accs):
+        ref = p_.double().sum(0) + (o0.double() if a else 0)
+        check("segment", o, ref.float(), 1e-5)
+
+
 @pytest.mark.parametrize("B,T,C,n_pad", [(2, 1024, 256, 201), (3, 64, 256, 132), (2, 100, 64, 0), (1, 4096, 128, 0), (2, 100, 192, 30)])
 def test_instnorm_backward(cuda, B, T, C, n_pad):
     """InstanceNorm over T rows + n_pad copies of a parameter row; gradients w.r.t. x and the row (style_transformer.py:520-530)"""
