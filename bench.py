@@ -69,6 +69,8 @@ def main():
                     help="infer = the headline metric; train = BASELINE config 4: inner-loop train step bs=8 256x256 (fp32 mode), steps/s")
     ap.add_argument("--eager", action="store_true", help="enqueue kernel by kernel instead of replaying a HIP graph of the forward")
     ap.add_argument("--loss-dtype", choices=["fp32", "bf16"], default="fp32", help="--mode train: compute dtype of the frozen VGG-19 loss network")
+    ap.add_argument("--train-graph", type=int, default=int(os.environ.get("MASTER_TRAIN_GRAPH", "0")),
+                    help="--mode train: 1 = replay one hipGraph per layer count k (graph.GraphedTrainStep), 0 = enqueue launch by launch")
     args = ap.parse_args()
     if args.mode == "train":
         return train_main(args)
@@ -357,7 +359,7 @@ def extras(model, content, style, k, args, ops):
 FWD_GFLOP = {"swin_per_image": 7.552, "st_layer": 9.079, "decoder": 7.965, "vgg": 47.34}      # per image @256^2, BASELINE.md section 3
 
 
-def train_bench(device, steps=10, warmup=3, B=8, S=256, max_layers=4, roofline=True, loss_dtype="fp32"):
+def train_bench(device, steps=10, warmup=3, B=8, S=256, max_layers=4, roofline=True, loss_dtype="fp32", graph=False):
     """K train steps: random k, train-mode forward (StochasticDepth masks drawn on the device), custom_loss, backward, FusedAdam.
     Returns the result dict (steps/s, algorithmic TFLOP/s, per-family kernel times of one step, roofline of the dominant family)."""
     import random
@@ -372,18 +374,27 @@ def train_bench(device, steps=10, warmup=3, B=8, S=256, max_layers=4, roofline=T
             torch.nn.init.kaiming_normal_(m_.weight, nonlinearity="relu"); torch.nn.init.normal_(m_.bias, std=0.05)
     loss_fn = custom_loss(default_lambda_value=10.0, vgg_state_dict=vgg.state_dict()).to(device)
     loss_fn.set_compute_dtype(torch.float32 if loss_dtype == "fp32" else torch.bfloat16)     # the frozen loss network only; the model stays fp32
-    opt = FusedAdam([{"params": model.style_transformer.parameters()}, {"params": model.decoder.parameters()}], lr=1e-4)
+    opt = FusedAdam([{"params": model.style_transformer.parameters()}, {"params": model.decoder.parameters()}], lr=1e-4, capturable=graph)
     content, style = synthetic_batch(B, S, device, seed=11)
     random.seed(0)
     ks = [random.randint(1, max_layers) for _ in range(warmup + steps)]
 
-    def step(k):
+    def eager_step(k):
         out = model(content, style, k)
         total = loss_fn(content, style, out)
         opt.zero_grad()
         total.backward()
         opt.step()
         return total
+    step = eager_step
+    if graph:
+        # one hipGraph per layer count k (graph.GraphedTrainStep): the first step with a given k runs eagerly and captures - those
+        # four steps are extra warm-up here, so that the timed steps are all replays, as in a long training run
+        from mastermetastyletransfer_amd import GraphedTrainStep
+        gstep = GraphedTrainStep(model, loss_fn, opt)
+        step = lambda k: gstep(content, style, k)
+        for k in range(1, max_layers + 1):
+            step(k)
     for k in ks[:warmup]:
         step(k)
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -403,7 +414,7 @@ def train_bench(device, steps=10, warmup=3, B=8, S=256, max_layers=4, roofline=T
            "frac_of_fp32_mfma_peak": round(gf / dt / 1e3 / PEAK_TFLOPS["fp32"], 4), "final_loss": float(last.detach())}
     if roofline:
         ops.prof_reset(); ops.count_reset(); ops.prof_enable(True); ops.count_enable(True)
-        step(2)
+        eager_step(2)                                    # launch by launch: the per-family timers bracket the C calls
         torch.cuda.synchronize()
         prof, counts = ops.prof_read(), ops.count_read()
         ops.prof_enable(False); ops.count_enable(False)
@@ -472,7 +483,8 @@ def train_main(args):
         raise SystemExit("--mode train is BASELINE config 4: one GPU")
     device = torch.device("cuda:0")
     torch.cuda.set_device(device)
-    res = train_bench(device, steps=args.steps, warmup=args.warmup, roofline=not args.no_extras, loss_dtype=args.loss_dtype)
+    res = train_bench(device, steps=args.steps, warmup=args.warmup, roofline=not args.no_extras, loss_dtype=args.loss_dtype, graph=bool(args.train_graph))
+    res["hip_graphs"] = bool(args.train_graph)
     res.update({"n_gpus": 1, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
                 "config": {"workload": "train_only_inner_loop.py:519-575 step on synthetic 256x256 batches of 8 content + 8 style images: "
                                        "k = random.randint(1, 4) with random.seed(0), Swin encoder frozen, StochasticDepth p = 0.1, "

@@ -390,6 +390,10 @@ int master_loss_tap_bwd(const void* x, const float* mean, const float* var, cons
 int master_adam_chunk(void);
 int master_adam_step(const void* table, int ntensors, long long nblocks, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int step, master_stream_t stream);
+/* master_adam_step with its scalars in DEVICE memory, for a hipGraph capture of the whole train step (kernel arguments are baked into a
+ * graph; the step count of the bias corrections is not a constant): hyper = {lr, beta1, beta2, eps, weight_decay} (5 floats), *step_done =
+ * updates applied so far; the call uses step = *step_done + 1 and then increments the counter (a second one-thread launch). */
+int master_adam_step_dev(const void* table, int ntensors, long long nblocks, const float* hyper, int* step_done, master_stream_t stream);
 int master_lerp(const void* table, int ntensors, long long nblocks, float eta, master_stream_t stream);
 
 /* Lightweight per-kernel timing used by bench.py's roofline leg: when enabled, every launch is

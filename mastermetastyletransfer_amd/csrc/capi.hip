@@ -40,6 +40,7 @@ int mul_add_bwd_launch(const float*, const float*, const float*, float*, float*,
 int adam_chunk();
 int adam_launch(const void*, int, long long, float, float, float, float, float, int, hipStream_t);
 int lerp_launch(const void*, int, long long, float, hipStream_t);
+int adam_dev_launch(const void*, int, long long, const float*, int*, hipStream_t);
 int loss_tap_slices(int);
 int loss_terms_launch(const float*, const float*, const float*, int, float*, float*, float*, int, int, int, int, int, hipStream_t);
 int conv_weight_pack_launch(const float*, float*, float*, int, int, int, hipStream_t);
@@ -431,6 +432,12 @@ int master_adam_step(const void* table, int ntensors, long long nblocks, float l
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_TRAIN_MISC, s);
     return adam_launch(table, ntensors, nblocks, lr, beta1, beta2, eps, weight_decay, step, s);
+}
+int master_adam_step_dev(const void* table, int ntensors, long long nblocks, const float* hyper, int* step_done, master_stream_t stream) {
+    REQUIRE(table && hyper && step_done && ntensors > 0 && nblocks > 0 && nblocks < 0x7fffffffLL, "adam_step_dev: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_TRAIN_MISC, s);
+    return adam_dev_launch(table, ntensors, nblocks, hyper, step_done, s);
 }
 int master_lerp(const void* table, int ntensors, long long nblocks, float eta, master_stream_t stream) {
     REQUIRE(table && ntensors > 0 && nblocks > 0 && nblocks < 0x7fffffffLL, "lerp: bad arguments");

@@ -219,6 +219,38 @@ __global__ __launch_bounds__(256) void adam_kernel(const TensorRec* __restrict__
     }
 }
 
+// The same update with its scalars in DEVICE memory (r03): hyper = {lr, beta1, beta2, eps, weight_decay}, *step = number of updates done so
+// far.  A hipGraph capture of the whole train step bakes kernel arguments in; the step count of the bias corrections (and a scheduled
+// learning rate) must therefore be read at run time.  adam_step_inc_kernel, launched behind it, advances the counter.
+__global__ __launch_bounds__(256) void adam_dev_kernel(const TensorRec* __restrict__ table, int ntensors, const float* __restrict__ hyper,
+                                                       const int* __restrict__ step_done) {
+    __shared__ float sc[2];
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
+    if (threadIdx.x == 0) {                                       // in double, like adam_launch (torch's Python floats)
+        const double st = (double)(*step_done + 1);
+        sc[0] = (float)(1.0 - pow((double)b1, st));
+        sc[1] = (float)sqrt(1.0 - pow((double)b2, st));
+    }
+    __syncthreads();
+    const float bc1 = sc[0], bc2_sqrt = sc[1];
+    const int t = find_tensor(table, ntensors, blockIdx.x);
+    const TensorRec rec = table[t];
+    const long long e0 = ((long long)blockIdx.x - rec.first_block) * ADAM_CHUNK;
+    const float step = lr / bc1;
+#pragma unroll
+    for (int k = 0; k < ADAM_CHUNK / 256; ++k) {
+        const long long i = e0 + k * 256 + threadIdx.x;
+        if (i >= rec.numel) break;
+        float p = rec.p[i], g = rec.g[i];
+        if (wd != 0.f) g = fmaf(wd, p, g);
+        const float m = fmaf(b1, rec.m[i], (1.f - b1) * g);
+        const float v = fmaf(b2, rec.v[i], (1.f - b2) * g * g);
+        rec.m[i] = m; rec.v[i] = v;
+        rec.p[i] = p - step * (m / (sqrtf(v) / bc2_sqrt + eps));
+    }
+}
+__global__ void adam_step_inc_kernel(int* step_done) { *step_done += 1; }
+
 // Reptile outer update (reference train.py:524-534): theta += eta * (omega - theta);  table: p = theta, g = omega
 __global__ __launch_bounds__(256) void lerp_kernel(const TensorRec* __restrict__ table, int ntensors, float eta) {
     const int t = find_tensor(table, ntensors, blockIdx.x);
@@ -559,6 +591,11 @@ int adam_launch(const void* table, int ntensors, long long nblocks, float lr, fl
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, (const TensorRec*)table, ntensors, lr, b1, b2, eps, wd, (float)bc1,
                        (float)sqrt(bc2));
     return master_check_launch("adam");
+}
+int adam_dev_launch(const void* table, int ntensors, long long nblocks, const float* hyper, int* step_done, hipStream_t s) {
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, (const TensorRec*)table, ntensors, hyper, (const int*)step_done);
+    hipLaunchKernelGGL(adam_step_inc_kernel, dim3(1), dim3(1), 0, s, step_done);
+    return master_check_launch("adam_dev");
 }
 int lerp_launch(const void* table, int ntensors, long long nblocks, float eta, hipStream_t s) {
     hipLaunchKernelGGL(lerp_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, (const TensorRec*)table, ntensors, eta);

@@ -64,3 +64,69 @@ class GraphedStylizer:
         self.style.copy_(style_image, non_blocking=True)
         self.graph.replay()
         return self.out.clone() if copy else self.out
+
+
+class GraphedTrainStep:
+    """One inner-loop train step (train_only_inner_loop.py:519-575: train-mode forward, custom_loss, zero_grad, backward, Adam) as a
+    hipGraph per transformer-layer count k.
+
+        step = GraphedTrainStep(model, loss_fn, FusedAdam(..., capturable=True))
+        total = step(content, style, k)          # device scalar; the graph's static output for that k
+
+    The step is ~800 kernel launches, many of them a few microseconds long (the StyleTransformer's [8192, 256] matrices at batch 8): the
+    host cannot enqueue them as fast as the device finishes them and the device idles for ~3 ms of a 30 ms step.  Replaying a captured
+    graph removes the host from the loop.  The first call for a given k runs eagerly (a real training step that also fills the lazy
+    host-side caches) and then captures; every later call with that k copies the batch into the static input buffers and replays.  The
+    kernels and their order are those of the eager step, so are the numbers; StochasticDepth masks come from torch's graph-safe device
+    generator (fresh masks every replay).
+
+    Inputs must keep one shape; the optimizer must be FusedAdam(capturable=True) (its step count and learning rate live in device
+    memory; a changed `param_groups[i]["lr"]` is pushed before the next replay).  Gradients are in `param.grad` after a call, as after
+    an eager step."""
+
+    def __init__(self, model, loss_fn, optimizer, capture: bool = True):
+        from .optim import FusedAdam
+        if not isinstance(optimizer, FusedAdam) or not optimizer.capturable:
+            raise ValueError("GraphedTrainStep needs FusedAdam(capturable=True)")
+        self.model, self.loss_fn, self.opt, self.capture = model, loss_fn, optimizer, bool(capture)
+        self.content = self.style = None
+        self.graphs, self.totals, self.seen = {}, {}, {}
+        self._params = [p for g in optimizer.param_groups for p in g["params"]]
+
+    def _eager(self, k: int) -> Tensor:
+        out = self.model(self.content, self.style, k)
+        total = self.loss_fn(self.content, self.style, out)
+        self.opt.zero_grad(set_to_none=True)
+        total.backward()
+        self.opt.step()
+        return total
+
+    def __call__(self, content: Tensor, style: Tensor, k: int) -> Tensor:
+        k = int(k)
+        if self.content is None:
+            self.content, self.style = torch.empty_like(content), torch.empty_like(style)
+        if content.shape != self.content.shape or style.shape != self.style.shape:
+            raise ValueError(f"GraphedTrainStep was started with inputs of shape {tuple(self.content.shape)}")
+        self.content.copy_(content, non_blocking=True)
+        self.style.copy_(style, non_blocking=True)
+        g = self.graphs.get(k)
+        if g is None:
+            total = self._eager(k).detach()
+            self.seen[k] = self.seen.get(k, 0) + 1
+            if self.capture and self.seen[k] >= 1:
+                self._capture(k)
+            return total
+        self.opt.push_hypers()
+        g.replay()
+        from .optim import _mark_written
+        _mark_written(self._params)                       # the replay wrote the parameters behind torch's back
+        return self.totals[k]
+
+    def _capture(self, k: int) -> None:
+        dev = self.content.device
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        self.opt.zero_grad(set_to_none=True)              # the capture allocates the gradients in the graph's pool
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            total = self._eager(k)
+        self.graphs[k], self.totals[k] = g, total.detach()

@@ -73,11 +73,64 @@ def _mark_written(tensors: Iterable[Tensor]) -> None:
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam(params, lr, betas, eps, weight_decay) with the update of every tensor of a param group in one HIP launch
     (master_adam_step).  Parameters without a gradient are skipped, like torch does (frozen encoder / fast adaptation,
-    train_only_inner_loop.py:254-257, :306-318)."""
+    train_only_inner_loop.py:254-257, :306-318).
 
-    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+    capturable=True keeps the step count and the hyper-parameters of every group in device memory (master_adam_step_dev) so that
+    `step()` can be captured in a hipGraph with the rest of the train step (graph.GraphedTrainStep): a replay then advances the
+    counter itself.  `state[p]["step"]` is brought up to date from the device by state_dict() / sync_steps()."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, capturable: bool = False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.capturable = bool(capturable)
         self._tables: Dict[int, _PointerTable] = {}
+        self._dev: Dict[int, dict] = {}                  # capturable: group index -> {"step": int32[1], "hyper": float32[5], "host": tuple}
+        self._keep: List[Tensor] = []                    # pointer tables a captured graph reads at every replay
+        self._spare: Dict[int, Tensor] = {}              # one pinned table per group, ready for the next capture
+
+    # ---- capturable mode ------------------------------------------------------------------------------------------------------------
+    def _group_dev(self, gi: int, group, dev, steps_done: int) -> dict:
+        d = self._dev.get(gi)
+        if d is None:
+            d = self._dev[gi] = {"step": torch.tensor([steps_done], dtype=torch.int32, device=dev),
+                                 "hyper": torch.zeros(5, dtype=torch.float32, device=dev), "host": None}
+        return d
+
+    def push_hypers(self) -> None:
+        """copy lr / betas / eps / weight_decay of every group to the device if they changed on the host (call it outside a capture;
+        GraphedTrainStep does before every replay, so a learning-rate schedule keeps working)"""
+        for gi, group in enumerate(self.param_groups):
+            d = self._dev.get(gi)
+            if d is None:
+                continue
+            b1, b2 = group["betas"]
+            host = (float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]))
+            if host != d["host"]:
+                d["hyper"].copy_(torch.tensor(host, dtype=torch.float32))
+                d["host"] = host
+
+    def sync_steps(self) -> None:
+        """state[p]["step"] <- the device counters (one host read per group)"""
+        for gi, group in enumerate(self.param_groups):
+            d = self._dev.get(gi)
+            if d is None:
+                continue
+            n = int(d["step"].item())
+            for p in group["params"]:
+                if self.state.get(p):
+                    self.state[p]["step"] = n
+
+    def state_dict(self):
+        if self.capturable:
+            self.sync_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for gi, group in enumerate(self.param_groups):
+            d = self._dev.get(gi)
+            steps = {int(self.state[p]["step"]) for p in group["params"] if self.state.get(p)}
+            if d is not None and steps:
+                d["step"].fill_(steps.pop())
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -86,6 +139,9 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = load_library()
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        if capturing and not self.capturable:
+            raise ops.MasterHipError("FusedAdam(capturable=True) is needed to capture step() in a graph")
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
@@ -100,10 +156,13 @@ class FusedAdam(torch.optim.Optimizer):
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 st = self.state[p]
                 if not st:
+                    if capturing:
+                        raise ops.MasterHipError("FusedAdam: run one eager step before capturing (the moment buffers are created there)")
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
+                if not self.capturable:
+                    st["step"] += 1
                 recs.append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), g))
             steps = {self.state[p]["step"] for p in ps}
             if len(steps) != 1:
@@ -111,12 +170,35 @@ class FusedAdam(torch.optim.Optimizer):
             key = tuple(r[:5] for r in recs)
             b1, b2 = group["betas"]
             with torch.cuda.device(dev):
-                tab = self._tables.get(gi)
-                if tab is None or tab.dev.shape[0] != len(recs) or tab.dev.device != dev:
-                    tab = self._tables[gi] = _PointerTable(len(recs), dev)
-                tab.refresh(key, [r[:5] for r in recs])
-                _check(lib.master_adam_step(_p(tab.dev), len(recs), tab.nblocks, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                            float(group["weight_decay"]), int(steps.pop()), _stream()), "master_adam_step")
+                if capturing:
+                    # the graph re-reads this table at every replay: its own pinned rows (set aside by the last eager step - no host
+                    # allocation inside a capture) and device copy, kept alive with the optimizer
+                    rows, nblocks = _rows([r[:5] for r in recs])
+                    host = self._spare.pop(gi, None)
+                    if host is None or host.shape[0] != len(recs):
+                        raise ops.MasterHipError("FusedAdam: run one eager step before capturing")
+                    host.copy_(torch.tensor(rows, dtype=torch.int64))
+                    table = torch.empty((len(recs), 6), dtype=torch.int64, device=dev)
+                    table.copy_(host, non_blocking=True)
+                    self._keep += [host, table]
+                else:
+                    if self.capturable and (gi not in self._spare or self._spare[gi].shape[0] != len(recs)):
+                        self._spare[gi] = torch.empty((len(recs), 6), dtype=torch.int64).pin_memory()
+                    tab = self._tables.get(gi)
+                    if tab is None or tab.dev.shape[0] != len(recs) or tab.dev.device != dev:
+                        tab = self._tables[gi] = _PointerTable(len(recs), dev)
+                    tab.refresh(key, [r[:5] for r in recs])
+                    table, nblocks = tab.dev, tab.nblocks
+                if self.capturable:
+                    d = self._group_dev(gi, group, dev, int(steps.pop()))
+                    if not capturing:
+                        self.push_hypers()
+                    elif d["host"] is None:
+                        raise ops.MasterHipError("FusedAdam: run one eager step before capturing")
+                    _check(lib.master_adam_step_dev(_p(table), len(recs), nblocks, _p(d["hyper"]), _p(d["step"]), _stream()), "master_adam_step_dev")
+                else:
+                    _check(lib.master_adam_step(_p(table), len(recs), nblocks, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                float(group["weight_decay"]), int(steps.pop()), _stream()), "master_adam_step")
             _mark_written(ps)
         return loss
 

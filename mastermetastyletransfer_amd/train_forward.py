@@ -65,8 +65,14 @@ class StochasticDepthMasks:
         n (no CPU / reference stream is reproducible on the device either way - parity tests install explicit masks)."""
         if self._explicit is not None or not ps:
             return
-        keep = torch.tensor([1.0 - float(p) for p in ps], dtype=torch.float32).clamp_(min=0.0)
-        keep = keep.to(device, non_blocking=True)[:, None].expand(len(ps), B)
+        # the keep probabilities live on the device, one upload per distinct draw order (a step captured in a hipGraph must not copy
+        # from pageable host memory, and k = 1..4 give four orders)
+        cache = self.__dict__.setdefault("_keep_cache", {})
+        ck = (tuple(float(p) for p in ps), str(device))
+        keep = cache.get(ck)
+        if keep is None:
+            keep = cache[ck] = torch.tensor([1.0 - float(p) for p in ps], dtype=torch.float32).clamp_(min=0.0).to(device)
+        keep = keep[:, None].expand(len(ps), B)
         noise = torch.bernoulli(keep, generator=self.generator)
         noise = noise / keep.clamp(min=1e-30)            # p = 1 rows are all zero either way
         self.__dict__["_queue"] = [((B, float(p), device), noise[i]) for i, p in enumerate(ps)]

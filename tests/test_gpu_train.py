@@ -428,6 +428,51 @@ def test_golden_train_cases(cuda, i):
     print(f"{tag}: gradient error vs float64 oracle: HIP worst {wh:.2e} median {mh:.2e} | CPU fp32 oracle worst {wc:.2e} median {mc:.2e}")
 
 
+def test_graphed_train_step_matches_the_eager_step(cuda):
+    """GraphedTrainStep (one hipGraph per k: forward, loss, backward, FusedAdam with its step count on the device) against the same steps
+    run eagerly with the host-scalar Adam: same kernels in the same order, so the losses and the trained weights agree to rounding of
+    the bias corrections.  StochasticDepth off (the two runs would draw different masks)."""
+    from mastermetastyletransfer_amd import FusedAdam, GraphedTrainStep, custom_loss
+    sds = (seeded_state_dict(O.swin_shapes(), 1), seeded_state_dict(O.style_transformer_shapes(), 2), seeded_state_dict(O.decoder_shapes(), 3))
+    vgg = seeded_state_dict(L.vgg19_shapes(), 4)
+    B, S = 2, 64
+    batches = [(seeded_input(f"g_c{i}", (B, 3, S, S), 20 + i, kind="image").to(cuda), seeded_input(f"g_s{i}", (B, 3, S, S), 40 + i, kind="image").to(cuda))
+               for i in range(3)]
+    ks = [2, 1, 2, 2, 1, 2, 1]
+
+    def build(capturable):
+        m = _model(cuda)
+        m.swin_encoder.load_state_dict(sds[0]); m.style_transformer.load_state_dict(sds[1]); m.decoder.load_state_dict(sds[2])
+        m = m.to(cuda).train()
+        for p in m.swin_encoder.parameters():
+            p.requires_grad = False
+        for mod in m.modules():                                    # no random masks
+            for name in ("stochastic_depth_prob", "encoder_stochastic_depth_prob", "decoder_stochastic_depth_prob"):
+                if hasattr(mod, name):
+                    setattr(mod, name, 0.0)
+        loss_fn = custom_loss(default_lambda_value=10.0, vgg_state_dict=vgg).to(cuda)
+        opt = FusedAdam([{"params": m.style_transformer.parameters()}, {"params": m.decoder.parameters()}], lr=1e-3, capturable=capturable)
+        return m, loss_fn, opt
+    m1, l1, o1 = build(False)
+    m2, l2, o2 = build(True)
+    step2 = GraphedTrainStep(m2, l2, o2)
+    for i, k in enumerate(ks):
+        c, s_ = batches[i % len(batches)]
+        out = m1(c, s_, k); t1 = l1(c, s_, out); o1.zero_grad(); t1.backward(); o1.step()
+        t2 = step2(c, s_, k)
+        assert abs(float(t2) - float(t1)) <= 1e-4 * abs(float(t1)), (i, k, float(t1), float(t2))
+    assert set(step2.graphs) == {1, 2}                             # both layer counts were captured and replayed
+    for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        if p1.requires_grad:
+            check(n, p2, p1, 2e-4)
+    o2.sync_steps()
+    assert {o2.state[p]["step"] for g_ in o2.param_groups for p in g_["params"] if o2.state.get(p)} == {len(ks)}
+    # an eval forward right after the replays sees the trained weights (the replay bumps the parameters' version counters)
+    m1.eval(); m2.eval()
+    with torch.no_grad():
+        check("eval after graph replays", m2(batches[0][0], batches[0][1], 1), m1(batches[0][0], batches[0][1], 1), 2e-3)
+
+
 @pytest.mark.parametrize("B,S", [(2, 64), (8, 256)])
 def test_full_train_step(cuda, B, S):
     """MasterStyleTransferModel in train mode (frozen Swin encoder with its StochasticDepth, k from random.seed(0)), custom_loss,
