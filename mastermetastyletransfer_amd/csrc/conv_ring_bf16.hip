@@ -44,12 +44,24 @@ struct RingArgs {
 union Frag { u32x4 u; bf16x8_t b; };
 
 #define LDS_READ128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:" #imm : "=v"(dst) : "v"(addr))
+#ifdef CONV_CLOCK_PROBE   // diagnostic build only (profiles/probes/conv_ring_probe.hip): s_memtime sections of wave 0
+#define CPROBE_MARK() do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); probe_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define CPROBE_ADD(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); probe_sec[i] += t_ - probe_last; probe_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CPROBE_MARK() do {} while (0)
+#define CPROBE_ADD(i) do {} while (0)
+#endif
 
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
 template <int CIN, int COUT, int RPW>
 __global__ __launch_bounds__(256, 1) void conv_ring_kernel(RingArgs p) {
     typedef Geo<CIN, RPW> G;
+#ifdef CONV_CLOCK_PROBE
+    unsigned long long probe_sec[4] = {0, 0, 0, 0}, probe_last = 0;
+    const unsigned long long probe_t0 = __builtin_amdgcn_s_memtime();
+    CPROBE_MARK();
+#endif
     constexpr int TH = G::TH, HROWS = G::HROWS, HALO_BYTES = G::HALO_BYTES, RING = G::RING, AHEAD = G::AHEAD, NSTEPS = G::NSTEPS;
     constexpr int NT = COUT / 32;                    // output-channel tiles
     constexpr int SLOTB = COUT * KSTEP * 2;          // 16 / 8 / 4 KB
@@ -97,6 +109,7 @@ __global__ __launch_bounds__(256, 1) void conv_ring_kernel(RingArgs p) {
     if (tid < COUT) bs[tid] = p.bias ? p.bias[tid] : 0.f;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                        // halo tile, bias and the first ring steps have landed
+    CPROBE_ADD(0);                                                       // prologue: halo gather + first ring steps
 
     auto lds_off = [&](const unsigned char* ptr) { return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)ptr; };
     const unsigned halo0 = lds_off(halo), ring0 = lds_off(ring);
@@ -129,6 +142,7 @@ __global__ __launch_bounds__(256, 1) void conv_ring_kernel(RingArgs p) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
+            CPROBE_ADD(1);                                               // step head: weights landed + barrier
             const int t_dma = t_issue < NSTEPS ? t_issue++ : -1;
             const unsigned wb = ring0 + (t_cons % RING) * SLOTB + r * 128;
             ++t_cons;
@@ -157,6 +171,7 @@ __global__ __launch_bounds__(256, 1) void conv_ring_kernel(RingArgs p) {
                     if (nt == 0 && t_dma >= 0 && s < PW) { __builtin_amdgcn_sched_barrier(0); dma_piece(t_dma, s); __builtin_amdgcn_sched_barrier(0); }
                 }
             }
+            CPROBE_ADD(2);                                               // fragment reads + MFMAs + DMA issue of the step
         }
     }
 
@@ -192,6 +207,15 @@ __global__ __launch_bounds__(256, 1) void conv_ring_kernel(RingArgs p) {
             *(u32x4*)(p.out + (((size_t)b * p.Hout + oy) * p.Wout + ox) * COUT + q * 8) = v;
         }
     }
+#ifdef CONV_CLOCK_PROBE
+    CPROBE_ADD(3);                                                       // epilogue (stores issued)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 && g_probe) {
+        g_probe[blockIdx.x * 8] = __builtin_amdgcn_s_memtime() - probe_t0;
+        for (int i = 0; i < 4; ++i) g_probe[blockIdx.x * 8 + 1 + i] = probe_sec[i];
+        g_probe[blockIdx.x * 8 + 5] = probe_t0;
+    }
+#endif
 }
 
 template <int CIN, int COUT, int RPW>
