@@ -12,6 +12,7 @@ throughput on the host cores.
 """
 import argparse
 import json
+import re
 import os
 import sys
 import time
@@ -466,16 +467,21 @@ def train_traffic(family):
 
 
 def torch_launches_from_trace():
-    """torch / runtime kernel launches per train step in the newest committed trace_by_shape of `bench.py --mode train`"""
+    """kernel launches per train step (all, and torch's / the runtime's share) in the newest committed trace_by_shape of
+    `bench.py --mode train` (averaged over the traced steps' layer counts k)"""
     import glob
     hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_train_trace_by_shape*.txt")))
     if not hits:
         return None
+    for line in open(hits[-1]):
+        if line.startswith("launches per step"):
+            nums = [float(x) for x in re.findall(r"[0-9]+\.[0-9]+", line)]
+            return {"all_per_step": nums[0], "library_per_step": nums[1], "torch_per_step": nums[2], "source": os.path.relpath(hits[-1], ROOT)}
     n = 0.0
     for line in open(hits[-1]):
         if "n/step=" in line and (line.startswith("at::") or line.startswith("__amd_rocclr") or line.startswith("void at::")):
             n += float(line.split("n/step=")[1].split()[0])
-    return {"per_step": round(n, 1), "source": os.path.relpath(hits[-1], ROOT)}
+    return {"torch_per_step": round(n, 1), "source": os.path.relpath(hits[-1], ROOT)}
 
 
 def train_main(args):

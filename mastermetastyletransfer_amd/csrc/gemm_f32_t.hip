@@ -45,6 +45,7 @@ struct TArgs {
     // data-gradient form (one split): out += add[m][n] after the GELU factor - the gradient arriving over a skip connection (r03: autograd
     // added it with one elementwise launch per residual block)
     const float* add; int ld_add;
+    int xcd_remap;               // set by the launcher when gridDim.x * gridDim.y is a multiple of 8
 };
 
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
@@ -76,13 +77,23 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_t_kernel(
     const int wm = (wave / NWN) * WM, wn = (wave % NWN) * WN;
     const int r = lane & 31, h = lane >> 5;
 
+    // XCD-aware order (r03).  Workgroups go to the 8 XCDs round-robin in dispatch order (x fastest), and each XCD has its own L2: with the
+    // plain order the N-tiles of one M-tile (data gradient: same rows of G) or the tiles of one split (weight gradient: same token range
+    // of G and X) sat on different XCDs and every one of them fetched those rows again - the [8192,256].[256,256] data gradient read
+    // 73 MB for 16 MB of operands (profiles/r03_train_pmc_traffic.txt).  Remapped so that runs of total/8 consecutive logical ids share an XCD.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcd_remap) {
+        const int lin = bx + by * (int)gridDim.x, per = ((int)gridDim.x * (int)gridDim.y) >> 3;
+        const int logical = (lin & 7) * per + (lin >> 3);
+        by = logical / (int)gridDim.x; bx = logical - by * (int)gridDim.x;
+    }
     const int NTN = (p.N + BN - 1) / BN;
-    const int mt = blockIdx.x / NTN, nt = blockIdx.x % NTN;
+    const int mt = bx / NTN, nt = bx % NTN;
     const int m0 = mt * BM, n0 = nt * BN;
     const int nk_all = (p.K + BK - 1) / BK;
-    const int kt0 = blockIdx.y * p.chunks_per_split;
+    const int kt0 = by * p.chunks_per_split;
     int kt1 = kt0 + p.chunks_per_split; if (kt1 > nk_all) kt1 = nk_all;
-    float* outp = p.out + (size_t)blockIdx.y * p.slab;
+    float* outp = p.out + (size_t)by * p.slab;
 
     const bool a_vec = (p.lda & 3) == 0 && (((uintptr_t)p.a) & 15) == 0;      // else scalar loads (e.g. a 3-channel gradient)
 
@@ -227,7 +238,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_t_kernel(
             float t = 0.f;
 #pragma unroll
             for (int q = 0; q < GROUPS; ++q) t += red[q * BM + tid];
-            p.rowsum[(size_t)blockIdx.y * p.rowsum_slab + m0 + tid] = t;
+            p.rowsum[(size_t)by * p.rowsum_slab + m0 + tid] = t;
         }
         // the epilogue's own first barrier orders these reads before the tile goes into the same memory
     }
@@ -336,6 +347,9 @@ int launch_t(TArgs p, float* final_out, float* ws, size_t ws_floats, int want_sp
     if (via_ws) { p.out = ws; p.slab = slab; p.rowsum = rowsum_out ? ws + slab * splits : nullptr; p.rowsum_slab = rs_slab; }
     else { p.out = final_out; p.slab = 0; p.rowsum = rowsum_out; p.rowsum_slab = 0; }
     const size_t lds = (size_t)2 * (A_ELEMS + W_ELEMS) * sizeof(float);
+    static int xcd = -1;
+    if (xcd < 0) { const char* e = getenv("MASTER_GEMM_T_XCD"); xcd = e ? atoi(e) : 1; }
+    p.xcd_remap = xcd && ((long long)tiles * splits) % 8 == 0 && (long long)tiles * splits >= 16;
     static LdsLimit lds_limit;
     lds_limit.ensure((const void*)gemm_f32_t_kernel<BM, BN, WM, WN, AT, GATHER>, (int)lds);
     hipLaunchKernelGGL((gemm_f32_t_kernel<BM, BN, WM, WN, AT, GATHER>), dim3(tiles, splits), dim3(NT), lds, s, p);

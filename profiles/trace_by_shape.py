@@ -14,6 +14,9 @@ for r in rows:
     a = agg.setdefault((short, grid), [0, 0.0])
     a[0] += 1; a[1] += d
 tot = sum(v[1] for v in agg.values())
+nl = sum(v[0] for v in agg.values())
+lib = sum(v[0] for k, v in agg.items() if not (k[0].startswith("at::") or k[0].startswith("__amd_rocclr") or k[0].startswith("rocprim") or "at::native" in k[0]))
 print(f"total kernel time {tot/1e3:.3f} ms over {steps} steps = {tot/1e3/steps:.3f} ms/step")
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+print(f"launches per step {nl/steps:.1f} (this library's kernels {lib/steps:.1f}, torch / runtime {(nl-lib)/steps:.1f}); every (kernel, grid) pair is listed")
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"{k[0]:60s} wgs={k[1]:7d} n/step={v[0]/steps:5.1f} avg_us={v[1]/v[0]:8.1f} ms/step={v[1]/1e3/steps:7.3f} share={100*v[1]/tot:5.1f}%")
