@@ -198,3 +198,115 @@ def test_missing_swin_weights_fail_loudly(lib):
     from mastermetastyletransfer_amd import MasterStyleTransferModel
     with pytest.raises(FileNotFoundError, match="allow_random_swin_encoder"):
         MasterStyleTransferModel()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# host logic of the train step: the registry that sums the gradients of tensors used several times in one graph (autograd._SharedGrads).
+# Pure bookkeeping - exercised here with CPU tensors and plain torch arithmetic standing in for the kernels.
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def _scale_fn(registry, calls):
+    """y = x * w (+ b) as an autograd Function that delivers dw / db through `registry` the way LinearFn does"""
+    class Scale(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w, b):
+            ctx.save_for_backward(x, w)
+            ctx.tok = registry.note(w, b)
+            ctx.bias = b                                   # the registry is keyed on the tensor's identity
+            return x * w + b
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+
+            def compute(ow, ob, acc, want_w, want_b):
+                calls.append((ow is not None, ob is not None, acc, want_w, want_b))
+                dw, db = (g * x).sum(0), g.sum(0)
+                if acc:
+                    if ow is not None:
+                        ow += dw
+                    if ob is not None:
+                        ob += db
+                    return ow, ob
+                return (dw if want_w else None), (db if want_b else None)
+            dw, db = registry.deliver_pair(ctx.tok, w, ctx.bias, compute)
+            return g * w, dw, db
+    return Scale
+
+
+def test_shared_gradient_registry_sums_the_uses_of_a_tensor(lib):
+    from mastermetastyletransfer_amd.autograd import _SharedGrads
+    reg, calls = _SharedGrads(), []
+    Scale = _scale_fn(reg, calls)
+    torch.manual_seed(0)
+    w, b = torch.randn(5, requires_grad=True), torch.randn(5, requires_grad=True)
+    x = torch.randn(7, 5, requires_grad=True)
+    # reference: plain autograd over three weight-sharing "layers"
+    h = x
+    for _ in range(3):
+        h = h * w + b
+    h.sum().backward()
+    ref = (x.grad.clone(), w.grad.clone(), b.grad.clone())
+    x.grad = w.grad = b.grad = None
+    tok = reg.begin()
+    h = x
+    for _ in range(3):
+        h = Scale.apply(h, w, b)
+    reg.end(tok)
+    h.sum().backward()
+    for got, want in zip((x.grad, w.grad, b.grad), ref):
+        assert torch.allclose(got, want, rtol=1e-5, atol=1e-6)
+    # the first use computed fresh buffers, the other two accumulated into them; autograd saw ONE gradient per tensor
+    assert [c[2] for c in calls] == [False, True, True]
+    assert reg.uses == {}
+    # outside a scope every call returns its own gradient (no accumulation) and autograd adds them
+    calls.clear(); x.grad = w.grad = b.grad = None
+    h = x
+    for _ in range(3):
+        h = Scale.apply(h, w, b)
+    h.sum().backward()
+    assert [c[2] for c in calls] == [False, False, False]
+    assert torch.allclose(w.grad, ref[1], rtol=1e-5, atol=1e-6) and torch.allclose(b.grad, ref[2], rtol=1e-5, atol=1e-6)
+
+
+def test_shared_gradient_registry_slots_and_stranded_uses(lib):
+    from mastermetastyletransfer_amd import ops
+    from mastermetastyletransfer_amd.autograd import _SharedGrads
+    reg = _SharedGrads()
+    t = torch.zeros(3, requires_grad=True)
+    tok = reg.begin()
+    assert reg.note(t) is tok and reg.note(t) is tok            # two uses counted
+    reg.end(tok)
+    made = []
+    alloc = lambda: made.append(torch.zeros(3)) or made[-1]
+    reg._checked = tok                                           # (the end-of-backward check is queued on the autograd engine: not outside a backward pass)
+    out1, acc1, ret1 = reg.slot(tok, t, alloc)
+    out2, acc2, ret2 = reg.slot(tok, t, alloc)
+    assert (acc1, ret1) == (False, None) and acc2 is True and ret2 is out1 and out2 is out1 and len(made) == 1
+    # a tensor the forward did not count, or a token of another graph: a private buffer every time
+    o, a, r_ = reg.slot(object(), t, alloc)
+    assert a is False and r_ is o and len(made) == 2
+    # a counted use that never runs backward leaves an accumulated sum undelivered: _verify raises instead of losing it silently
+    tok = reg.begin(); reg.note(t); reg.note(t); reg.end(tok)
+    reg._checked = tok
+    reg.slot(tok, t, alloc)
+    with pytest.raises(ops.MasterHipError):
+        reg._verify(tok)
+
+
+def test_trace_tools_count_every_launch(tmp_path):
+    """profiles/trace_by_shape.py prints every (kernel, grid) pair and the launch totals (r02's 40-row listing under-counted the train step)"""
+    import subprocess, sys
+    rows = ["Kernel_Name,Grid_Size_X,Workgroup_Size_X,Start_Timestamp,End_Timestamp"]
+    t = 0
+    for i in range(60):                                           # 60 distinct library kernels + 30 torch launches
+        rows.append(f'"void (anonymous namespace)::k{i}_kernel(float*)",{256 * (i + 1)},256,{t},{t + 1000}'); t += 2000
+    for i in range(30):
+        rows.append(f'"void at::native::vectorized_elementwise_kernel<4, f>(int)",256,256,{t},{t + 500}'); t += 1000
+    p = tmp_path / "t_kernel_trace.csv"
+    p.write_text("\n".join(rows) + "\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "profiles", "trace_by_shape.py"), str(p), "2"], capture_output=True, text=True, check=True).stdout
+    assert "launches per step 45.0 (this library's kernels 30.0, torch / runtime 15.0)" in out
+    assert sum(1 for line in out.splitlines() if "n/step=" in line) == 61
+    out = subprocess.run([sys.executable, os.path.join(root, "profiles", "tools", "trace_compare.py"), str(p), str(p), "2"], capture_output=True, text=True, check=True).stdout
+    assert "launches 45.0 -> 45.0" in out
