@@ -18,7 +18,9 @@ import sys
 import time
 import warnings
 
-import torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this pool's driver (must be set before HIP initialises)
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
