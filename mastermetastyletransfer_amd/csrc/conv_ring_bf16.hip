@@ -2,7 +2,7 @@
 // the other conv kernels serve badly (reference codes/decoder.py:24-46):
 //     Cin 256 -> 128 (first layer, 32x32 maps)      tile  4 x 32, one pixel row per wave
 //     Cin 128 -> 128 / 64 (Upsample?, 64x64 maps)   tile  8 x 32, two rows per wave
-//     Cin  64 -> 32 (128x128 maps)                  tile 16 x 32, four rows per wave
+//     Cin  64 -> 32 (128x128 maps)                  tile  8 x 32, two rows per wave, TWO workgroups per CU (r03; was 16 x 32, one per CU)
 //
 // The implicit GEMM (gemm_bf16.hip) re-gathers every source pixel nine times through L2 (~350-550 TFLOP/s on these layers); the halo
 // kernel for Cin = 64 (conv_halo_bf16.hip) keeps its weights in registers, which Cin >= 128 cannot, and with Cout = 32 it has one
@@ -17,6 +17,7 @@
 //   per k-step Cout/32 weight fragments + RPW pixel fragments feed RPW Cout/32 MFMAs;
 //   epilogue: + bias, ReLU, bf16, transposed through the (now idle) halo region into whole pixel rows of 2 Cout bytes.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -54,8 +55,13 @@ union Frag { u32x4 u; bf16x8_t b; };
 
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
+// workgroups per CU: the 64 -> 32 layer's 8-row tile needs 60 KB of LDS and 32 accumulator registers - two of them fit and cover each
+// other's prologue / epilogue (r03, profiles/r03_conv_ring_probe_mi355x.txt: 47 % of that layer's workgroup life; 47 -> 30 us at bs=32).
+// The same trade for 128 -> 64 (4-row tile, 3-slot ring: 76 KB) measured neutral - twice the weight stream per pixel - and is not built.
+template <int CIN, int COUT, int RPW> constexpr int ring_occupancy() { return (CIN == 64 && RPW <= 2) ? 2 : 1; }
+
 template <int CIN, int COUT, int RPW>
-__global__ __launch_bounds__(256, 1) void conv_ring_kernel(RingArgs p) {
+__global__ __launch_bounds__(256, (ring_occupancy<CIN, COUT, RPW>())) void conv_ring_kernel(RingArgs p) {
     typedef Geo<CIN, RPW> G;
 #ifdef CONV_CLOCK_PROBE
     unsigned long long probe_sec[4] = {0, 0, 0, 0}, probe_last = 0;
@@ -240,6 +246,11 @@ int conv_ring_bf16(const bf16_t* x, const bf16_t* w, const float* bias, bf16_t* 
     if (Cin == 256 && Cout == 128 && Hout % 4 == 0) return launch<256, 128, 1>(p, s);
     if (Cin == 128 && Cout == 128 && Hout % 8 == 0) return launch<128, 128, 2>(p, s);
     if (Cin == 128 && Cout == 64 && Hout % 8 == 0) return launch<128, 64, 2>(p, s);
-    if (Cin == 64 && Cout == 32 && Hout % 16 == 0) return launch<64, 32, 4>(p, s);
+    if (Cin == 64 && Cout == 32) {
+        static int tile8 = -1;
+        if (tile8 < 0) { const char* e = getenv("MASTER_CONV_RING_64_TILE8"); tile8 = e ? atoi(e) : 1; }
+        if (tile8 && Hout % 8 == 0) return launch<64, 32, 2>(p, s);
+        if (Hout % 16 == 0) return launch<64, 32, 4>(p, s);
+    }
     return MASTER_ERR_UNSUPPORTED;
 }
