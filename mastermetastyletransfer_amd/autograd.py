@@ -620,7 +620,15 @@ class WindowAttnFn(torch.autograd.Function):
             out, acc, dbias = sg.slot(tok, bias_src, lambda: torch.empty((heads, 64, 64), dtype=F, device=dev))
             segs.append((dbws, out, heads * 4096, heads * 4096, B * plan.nW, acc))
         if segs:
-            reduce_segments(segs)
+            # segments that write the same buffer (one tensor passed for two pad rows) must not share a launch: workgroups of one
+            # launch run in any order, and the second segment adds to what the first one writes
+            seen_out, batch = set(), []
+            for sg_ in segs:
+                if sg_[1].data_ptr() in seen_out:
+                    reduce_segments(batch)
+                    seen_out, batch = set(), []
+                seen_out.add(sg_[1].data_ptr()); batch.append(sg_)
+            reduce_segments(batch)
         return (outs[0], outs[1], outs[2], outs[3], gkp, gv0p, gv1p, dbias, None, None, None, None, None, None)
 
 
