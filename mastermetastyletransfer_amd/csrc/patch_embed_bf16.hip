@@ -30,19 +30,8 @@ __global__ __launch_bounds__(256) void patch_embed_bf16_kernel(PeArgs p) {
     const long npatch = (long)p.B * PH * PW;
     const long p0 = (long)blockIdx.x * 128;
 
-    // ---- weights -> bf16 A fragments: lane (channel tile*32 + r, half h) holds W[e][16s + 8h .. +8], s = 0..2 -----------
-    Frag wf[4][3];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const float* wp = p.w + (t * 32 + r) * KP + 16 * s + 8 * h;
-            const f32x4 a = *(const f32x4*)wp, c = *(const f32x4*)(wp + 4);
-            wf[t][s].u[0] = pack_bf16x2(a[0], a[1]); wf[t][s].u[1] = pack_bf16x2(a[2], a[3]);
-            wf[t][s].u[2] = pack_bf16x2(c[0], c[1]); wf[t][s].u[3] = pack_bf16x2(c[2], c[3]);
-        }
-
-    // ---- pixels -> X[patch][c*16 + dy*4 + dx] (bf16): 128 patches x 12 (c, dy) float4 loads, 6 per thread --------------------
+    // ---- pixels: 128 patches x 12 (c, dy) float4 loads, 6 per thread, requested first (they land while the weights are arranged) ------
+    f32x4 pv[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int item = tid + 256 * i;
@@ -50,8 +39,46 @@ __global__ __launch_bounds__(256) void patch_embed_bf16_kernel(PeArgs p) {
         long pg = p0 + pl; pg = pg < npatch ? pg : npatch - 1;
         const int px = (int)(pg % PW); const long t2 = pg / PW; const int py = (int)(t2 % PH); const int b = (int)(t2 / PH);
         const int c = cd >> 2, dy = cd & 3;
-        const f32x4 v = *(const f32x4*)(p.img + (((size_t)b * 3 + c) * p.H + 4 * py + dy) * p.W + 4 * px);
-        u32x2 o; o[0] = pack_bf16x2(v[0], v[1]); o[1] = pack_bf16x2(v[2], v[3]);
+        pv[i] = *(const f32x4*)(p.img + (((size_t)b * 3 + c) * p.H + 4 * py + dy) * p.W + 4 * px);
+    }
+
+    // ---- weights -> bf16 A fragments: lane (channel tile*32 + r, half h) holds W[e][16s + 8h .. +8], s = 0..2.  r03: the [128][48] fp32
+    //      matrix goes through LDS - six coalesced float4 loads per thread, rows padded to 52 floats (16 consecutive rows = 16 distinct
+    //      16-B slots) - instead of 24 fragment loads per lane that each touched 32 rows x 32 B (the texture-address path, see
+    //      profiles/r03_linear_probe_mi355x.txt) --------------------------------------------------------------------------------------
+    constexpr int WLD = 52;
+    {
+        float* Wl = (float*)X;                                      // 128 x 52 x 4 B = 26.6 KB of the 32-KB region
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int item = tid + 256 * i;                         // float4 index into the dense [128][48] matrix
+            const int row = item / 12, c4 = item - row * 12;
+            *(f32x4*)(Wl + row * WLD + 4 * c4) = *(const f32x4*)(p.w + (size_t)item * 4);
+        }
+    }
+    __syncthreads();
+    Frag wf[4][3];
+    {
+        const float* Wl = (const float*)X;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const float* wp = Wl + (t * 32 + r) * WLD + 16 * s + 8 * h;
+                const f32x4 a = *(const f32x4*)wp, c = *(const f32x4*)(wp + 4);
+                wf[t][s].u[0] = pack_bf16x2(a[0], a[1]); wf[t][s].u[1] = pack_bf16x2(a[2], a[3]);
+                wf[t][s].u[2] = pack_bf16x2(c[0], c[1]); wf[t][s].u[3] = pack_bf16x2(c[2], c[3]);
+            }
+    }
+    __syncthreads();                                                // every wave holds its fragments: the region becomes the patch records
+
+    // ---- X[patch][c*16 + dy*4 + dx] (bf16) ---------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int item = tid + 256 * i;
+        const int pl = item & 127, cd = item >> 7;
+        const int c = cd >> 2, dy = cd & 3;
+        u32x2 o; o[0] = pack_bf16x2(pv[i][0], pv[i][1]); o[1] = pack_bf16x2(pv[i][2], pv[i][3]);
         *(u32x2*)(X + pl * XREC + (c * 16 + dy * 4) * 2) = o;
     }
     __syncthreads();
