@@ -129,57 +129,79 @@ __global__ __launch_bounds__(256, (ring_occupancy<CIN, COUT, RPW>())) void conv_
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[tt][nt][e] = 0.f;
 
-    int t_cons = 0;
-    for (int tap = 0; tap < 9; ++tap) {
+    // ---- main loop: NSTEPS ring steps of 64 k (tap-major: step t = tap t / HALVES, channels 64 (t % HALVES) ..), four 16-k sub-steps each.
+    //      r03: the wait + barrier for step t + 1 sits in front of the LAST sub-step of step t (whose fragments are in registers by then),
+    //      and the first fragments of step t + 1 are read under that sub-step's MFMAs: the exposed LDS latency at every step boundary
+    //      (profiles/r03_conv_ring_probe_mi355x.txt: the step ran 1 524 cycles for 1 024 of MFMAs) is gone. ---------------------------------
+    constexpr int HALVES = CIN / KSTEP;
+    constexpr int LATE = PW == 4 ? 1 : 0;                                // DMA pieces of the current step not yet issued when the early head runs
+    unsigned pix[RPW]; int psw[RPW];
+    unsigned wb = 0; int half = 0;
+    auto set_step = [&](int t) __attribute__((always_inline)) {
+        const int tap = t / HALVES;
+        half = t - tap * HALVES;
         const int dy = tap / 3, dx = tap - 3 * dy;                       // halo offsets 0..2 (= tap offsets -1..1, the halo starts at -1)
-        // halo pixel of this lane's output pixel for this tap, per token tile tt (output row 2 wave + tt)
-        unsigned pix[RPW]; int psw[RPW];
 #pragma unroll
-        for (int tt = 0; tt < RPW; ++tt) {
+        for (int tt = 0; tt < RPW; ++tt) {                               // halo pixel of this lane's output pixel for this tap, per token tile
             const int hp = (RPW * wave + tt + dy) * HW_ + r + dx;
             pix[tt] = halo0 + hp * (CIN * 2); psw[tt] = pix_swz(hp);
         }
+        wb = ring0 + (t % RING) * SLOTB + r * 128;
+    };
+    auto head = [&](int t, bool early) __attribute__((always_inline)) {
+        // my DMA pieces of step t have landed -> barrier -> everyone's have, and everyone left the slot the next DMA step goes into.
+        // vmcnt counts in order: "at most n outstanding" with n = the pieces issued AFTER step t's.
+        const int ahead = t_issue - 1 - t;                               // steps issued beyond step t (<= AHEAD - 1)
+        if (early && LATE) { if (ahead >= 2) wait_vm<2 * PW - LATE>(); else if (ahead == 1) wait_vm<PW - LATE>(); else wait_vm<0>(); }
+        else { if (ahead >= 2) wait_vm<2 * PW>(); else if (ahead == 1) wait_vm<PW>(); else wait_vm<0>(); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    u32x4 a[2][NT], xb[2][RPW];
+    auto rd = [&](int buf, int s) __attribute__((always_inline)) {       // k-step s of the current ring step: channels 64 half + 16 s ..
+        const unsigned ad = wb + ((32 * s) ^ xsw);
+        LDS_READ128(a[buf][0], ad, 0);
+        if (NT >= 2) LDS_READ128(a[buf][NT >= 2 ? 1 : 0], ad, 4096);
+        if (NT == 4) { LDS_READ128(a[buf][NT - 2], ad, 8192); LDS_READ128(a[buf][NT - 1], ad, 12288); }
+        const int c = 8 * half + 2 * s + h;                              // 16-B channel chunk within the pixel row
 #pragma unroll
-        for (int half = 0; half < CIN / KSTEP; ++half) {                 // ring steps of this tap: channels [64 half, 64 half + 64)
-            // my DMA pieces of step t_cons have landed -> barrier -> everyone's have, and everyone left the slot step t_cons+3 goes into
-            {
-                const int ahead = t_issue - 1 - t_cons;                 // steps issued beyond the one about to be consumed (<= AHEAD - 1)
-                if (ahead >= 2) wait_vm<2 * PW>(); else if (ahead == 1) wait_vm<PW>(); else wait_vm<0>();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-            CPROBE_ADD(1);                                               // step head: weights landed + barrier
-            const int t_dma = t_issue < NSTEPS ? t_issue++ : -1;
-            const unsigned wb = ring0 + (t_cons % RING) * SLOTB + r * 128;
-            ++t_cons;
-            u32x4 a[2][NT], xb[2][RPW];
-            auto rd = [&](int buf, int s) {                              // k-step s of this ring step: channels 64 half + 16 s ..
-                const unsigned ad = wb + ((32 * s) ^ xsw);
-                LDS_READ128(a[buf][0], ad, 0);
-                if (NT >= 2) LDS_READ128(a[buf][NT >= 2 ? 1 : 0], ad, 4096);
-                if (NT == 4) { LDS_READ128(a[buf][NT - 2], ad, 8192); LDS_READ128(a[buf][NT - 1], ad, 12288); }
-                const int c = 8 * half + 2 * s + h;                      // 16-B channel chunk within the pixel row
+        for (int tt = 0; tt < RPW; ++tt) LDS_READ128(xb[buf][tt], pix[tt] + ((c ^ psw[tt]) << 4), 0);
+    };
+    head(0, false);
+    CPROBE_ADD(1);
+    int t_dma = t_issue < NSTEPS ? t_issue++ : -1;                       // the step whose pieces go out during step 0
+    set_step(0);
+    rd(0, 0);
+    for (int t = 0; t < NSTEPS; ++t) {
+        int t_dma_next = -1;
 #pragma unroll
-                for (int tt = 0; tt < RPW; ++tt) LDS_READ128(xb[buf][tt], pix[tt] + ((c ^ psw[tt]) << 4), 0);
-            };
-            rd(0, 0);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (s + 1 < 4) { rd((s + 1) & 1, s + 1); wait_lgkm<NT + RPW>(); } else { wait_lgkm<0>(); }
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    Frag f; f.u = a[s & 1][nt];
-#pragma unroll
-                    for (int tt = 0; tt < RPW; ++tt) {
-                        Frag xf; xf.u = xb[s & 1][tt];
-                        acc[tt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, xf.b, acc[tt][nt], 0, 0, 0);
-                    }
-                    if (nt == 0 && t_dma >= 0 && s < PW) { __builtin_amdgcn_sched_barrier(0); dma_piece(t_dma, s); __builtin_amdgcn_sched_barrier(0); }
+        for (int s = 0; s < 4; ++s) {
+            if (s + 1 < 4) { rd((s + 1) & 1, s + 1); wait_lgkm<NT + RPW>(); }
+            else {
+                wait_lgkm<0>();                                          // the last sub-step's fragments are in registers: this step is done with LDS
+                if (t + 1 < NSTEPS) {
+                    CPROBE_ADD(2);
+                    head(t + 1, true);
+                    CPROBE_ADD(1);                                       // step head: weights landed + barrier
+                    t_dma_next = t_issue < NSTEPS ? t_issue++ : -1;
+                    set_step(t + 1);
+                    rd(0, 0);                                            // buffer 0 is free (sub-step 3 computes from buffer 1)
                 }
             }
-            CPROBE_ADD(2);                                               // fragment reads + MFMAs + DMA issue of the step
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                Frag f; f.u = a[s & 1][nt];
+#pragma unroll
+                for (int tt = 0; tt < RPW; ++tt) {
+                    Frag xf; xf.u = xb[s & 1][tt];
+                    acc[tt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, xf.b, acc[tt][nt], 0, 0, 0);
+                }
+                if (nt == 0 && t_dma >= 0 && s < PW) { __builtin_amdgcn_sched_barrier(0); dma_piece(t_dma, s); __builtin_amdgcn_sched_barrier(0); }
+            }
         }
+        t_dma = t_dma_next;
     }
+    CPROBE_ADD(2);                                                       // fragment reads + MFMAs + DMA issue
 
     // ---- epilogue: + bias, ReLU, bf16; each wave transposes its [32 RPW pixels][COUT] tile through the idle halo region (16-B chunks
     //      swizzled by the pixel index) and stores whole pixel rows (COUT * 2 bytes) -----------------------------------------------------
