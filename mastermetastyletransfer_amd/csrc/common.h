@@ -32,23 +32,40 @@ __device__ __forceinline__ float fast_erf(float z) {
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 
-// GELU for the bf16 mode, two values per instruction: x * clamp01(0.5 + x R(x^2)) with R a degree-6 polynomial fitted to
-// (Phi(x) - 0.5)/x on [0,4] (|error| vs the erf form <= 1.9e-4 over all x, below bf16 resolution; beyond |x| > 4 the
-// polynomial runs off in the right direction and the clamp pins Phi to 0 or 1, +-inf included).  9 packed-fp32 instructions
-// per pair (v_pk_mul/v_pk_fma, the clamp is the VOP3P output modifier) against ~29 op slots for the exp/rcp forms, whose
-// transcendentals issue at quarter rate.  The fp32 parity mode keeps gelu_erf.
+// GELU for the bf16 mode: x * clamp01(0.5 + x R(x^2)), R fitted to (Phi(x) - 0.5)/x; beyond the fitted range the polynomial runs off in
+// the right direction (even degree of R, positive leading coefficient) and the clamp pins Phi to 0 or 1, +-inf included.
+//   degree 4 (default, r03): least-squares fit of the GELU error under a N(0, 2) weight on |x| <= 3.2 (where pre-activations live):
+//     rms error 2.7e-4 for N(0,1) inputs, 3.7e-4 for N(0,1.5), |error| <= 2.3e-3 (reached near |x| = 3) - the hidden activations are
+//     rounded to bf16 (relative 2e-3) right after.  7 VALU instructions per value.
+//   degree 6 (-DMASTER_GELU_DEG6, r01/r02): |error| <= 1.9e-4.  9 instructions per value.
+// The GELU arithmetic is the exposed VALU time of the fused MLP kernels (18.7 k of 111 k clocks per workgroup with degree 6,
+// profiles/r02_mlp_probe_*.txt); exp / rcp forms cost ~29 op slots (transcendentals issue at quarter rate).  The fp32 parity mode keeps gelu_erf.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
+__device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {                   // two values per instruction (v_pk_mul / v_pk_fma)
     const f32x2 t = x * x;
+#ifdef MASTER_GELU_DEG6
     f32x2 R = t * 2.278150468e-08f + -1.598605536e-06f;
-    R = R * t + 4.795558198e-05f;
-    R = R * t + -8.140160353e-04f;
-    R = R * t + 8.772390895e-03f;
-    R = R * t + -6.457311660e-02f;
-    R = R * t + 3.978833556e-01f;
+    R = R * t + 4.795558198e-05f; R = R * t + -8.140160353e-04f; R = R * t + 8.772390895e-03f;
+    R = R * t + -6.457311660e-02f; R = R * t + 3.978833556e-01f;
+#else
+    f32x2 R = t * 1.579773891e-05f + -5.356991246e-04f;
+    R = R * t + 7.651804271e-03f; R = R * t + -6.262873859e-02f; R = R * t + 3.968234232e-01f;
+#endif
     f32x2 p;
     asm("v_pk_fma_f32 %0, %1, %2, 0.5 op_sel_hi:[1,1,0] clamp" : "=v"(p) : "v"(x), "v"(R));
     return x * p;
+}
+__device__ __forceinline__ float gelu_poly1(float xx) {                  // one value (the fine-grained form of mlp_bf16.hip)
+    const float t = xx * xx;
+#ifdef MASTER_GELU_DEG6
+    float R = fmaf(t, 2.278150468e-08f, -1.598605536e-06f);
+    R = fmaf(R, t, 4.795558198e-05f); R = fmaf(R, t, -8.140160353e-04f); R = fmaf(R, t, 8.772390895e-03f);
+    R = fmaf(R, t, -6.457311660e-02f); R = fmaf(R, t, 3.978833556e-01f);
+#else
+    float R = fmaf(t, 1.579773891e-05f, -5.356991246e-04f);
+    R = fmaf(R, t, 7.651804271e-03f); R = fmaf(R, t, -6.262873859e-02f); R = fmaf(R, t, 3.968234232e-01f);
+#endif
+    return xx * __builtin_amdgcn_fmed3f(fmaf(xx, R, 0.5f), 0.0f, 1.0f);
 }
 
 template <int ACT>

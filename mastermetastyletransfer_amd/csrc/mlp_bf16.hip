@@ -237,13 +237,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
 #elif defined(MLP_X_PLAINGELU)        // probe builds: the same polynomial in un-packed fp32 (18 instructions per pair instead of 9 packed)
         f32x2 v;
 #pragma unroll
-        for (int z = 0; z < 2; ++z) {
-            const float xx = hprev[jt][e0 + z], t = xx * xx;
-            float R = fmaf(t, 2.278150468e-08f, -1.598605536e-06f);
-            R = fmaf(R, t, 4.795558198e-05f); R = fmaf(R, t, -8.140160353e-04f); R = fmaf(R, t, 8.772390895e-03f);
-            R = fmaf(R, t, -6.457311660e-02f); R = fmaf(R, t, 3.978833556e-01f);
-            v[z] = xx * __builtin_amdgcn_fmed3f(fmaf(xx, R, 0.5f), 0.0f, 1.0f);
-        }
+        for (int z = 0; z < 2; ++z) v[z] = gelu_poly1(hprev[jt][e0 + z]);
 #else
         const f32x2 v = gelu_poly2(f32x2{hprev[jt][e0], hprev[jt][e0 + 1]});          // common.h; b1 is already in the accumulator
 #endif
@@ -266,11 +260,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
     auto gelu_fine = [&](int v) __attribute__((always_inline)) {          // v = 0..63: value index inside the previous hidden chunk
         const int ks = v >> 3, jtg = ks >> 1, sg = ks & 1, q = (v >> 1) & 3, z = v & 1;
         const int e0 = 4 * (2 * sg + (q >> 1)) + 2 * (q & 1);
-        const float xx = hprev[jtg][e0 + z], t = xx * xx;
-        float R = fmaf(t, 2.278150468e-08f, -1.598605536e-06f);
-        R = fmaf(R, t, 4.795558198e-05f); R = fmaf(R, t, -8.140160353e-04f); R = fmaf(R, t, 8.772390895e-03f);
-        R = fmaf(R, t, -6.457311660e-02f); R = fmaf(R, t, 3.978833556e-01f);
-        gfine[z] = xx * __builtin_amdgcn_fmed3f(fmaf(xx, R, 0.5f), 0.0f, 1.0f);
+        gfine[z] = gelu_poly1(hprev[jtg][e0 + z]);                        // common.h
         if (z == 1) gu[q] = pack_bf16x2(gfine[0], gfine[1]);
         if ((v & 7) == 7) gelu_swap(jtg, sg);
         asm volatile("" :: "v"(gfine[z]));                                // pin: LLVM otherwise sinks the arithmetic below the MFMAs
