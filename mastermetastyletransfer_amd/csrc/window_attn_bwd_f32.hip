@@ -45,7 +45,10 @@ __global__ __launch_bounds__(256) void window_attn_bwd_f32_kernel(AttnBwdArgs p)
     const int head = pid % p.heads;
     const int w = (pid / p.heads) % p.nW;
     const int b = pid / (p.heads * p.nW);
-    const int32_t* src = p.src + w * 64;
+    // the window's gather-table row is read ONCE (slot = lane) and handed around with ds_bpermute: every row this kernel gathers used to
+    // start with a dependent load of its table entry (the same cure as the forward kernel's, window_attn_f32.hip r03)
+    const int my_src = lane < p.N ? p.src[w * 64 + lane] : -1;
+    auto src_of = [&](int slot) __attribute__((always_inline)) { return __shfl(my_src, slot, 64); };
     const int32_t* pord = p.pad_ord + w * 64;
     const uint8_t* reg = p.region ? p.region + w * 64 : nullptr;
     const size_t tok0 = (size_t)b * p.T;
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_f32_kernel(AttnBwdArgs p)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int slot = t * 32 + r;
-        const int idx = slot < p.N ? src[slot] : -1;
+        const int idx = src_of(slot);
         const bool key_on = slot < p.N, real = idx >= 0;
         const size_t tok = tok0 + (real ? idx : 0);
         const int co = coff + 16 * h;
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_f32_kernel(AttnBwdArgs p)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int key = kt * 32 + rowof(e, h);
-                const int idx = key < p.N ? src[key] : -1;
+                const int idx = src_of(key);
                 kk[e] = key < p.N ? (idx >= 0 ? p.k[(tok0 + idx) * p.ldk + coff + r] : *kpad) : 0.0f;
             }
 #pragma unroll
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_f32_kernel(AttnBwdArgs p)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             const int slot = qt * 32 + r;
-            const int idx = slot < p.N ? src[slot] : -1;
+            const int idx = src_of(slot);
             if (idx < 0) continue;
             float* op = p.dq + (tok0 + idx) * p.lddq + coff + 4 * h;
 #pragma unroll
@@ -242,8 +245,8 @@ __global__ __launch_bounds__(256) void window_attn_bwd_f32_kernel(AttnBwdArgs p)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             const int slot = kt * 32 + r;
+            const int idx = src_of(slot);                                // before the branch: a cross-lane read wants every lane active
             if (slot >= p.N) continue;
-            const int idx = src[slot];
             float* op = idx >= 0 ? dtok + (tok0 + idx) * ldd + coff + 4 * h
                                  : dpad + ((size_t)b * p.n_pad + pord[slot]) * p.C + coff + 4 * h;
 #pragma unroll
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_f32_kernel(AttnBwdArgs p)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int qi = qt * 32 + rowof(e, h);
-                const int idx = qi < p.N ? src[qi] : -1;
+                const int idx = src_of(qi);
                 xx[e] = idx >= 0 ? xsrc[(tok0 + idx) * ldx + coff + r] : 0.0f;
             }
 #pragma unroll
