@@ -202,6 +202,11 @@ int master_patch_merge_linear_fwd(const void* x, const float* gamma, const float
  *   |IN(a) - IN(b)| (squared = 0) or (IN(a) - IN(b))^2 into partial[pairs * S] - the caller's fixed-order sum / (pairs*C*HW)
  *   is content_loss_each_term (loss.py:112-118).  C a power-of-two multiple of 8 (bf16) / 4 (fp32) up to 2048 / 1024. */
 int master_image_to_nhwc_fwd(const float* img, void* out, int N, int H, int W, int Cpad, int dtype, master_stream_t stream);
+/* VGG-19 conv1_1 (+ ReLU) straight from the fp32 NCHW image: Conv2d(3, 64, 3, padding = 1) (loss.py:23-37) with w in nn.Conv2d's own
+ * [64][3][3][3] layout -> NHWC [N,H,W,64] in `dtype`.  Replaces master_image_to_nhwc_fwd + master_conv3x3_zero_fwd for that layer (no
+ * zero-padded 32-channel copy of the images, 27 real taps instead of 288). */
+int master_vgg_conv1_fwd(const float* img, const float* w, const float* bias, void* out, int N, int H, int W, int relu, int dtype,
+                         master_stream_t stream);
 int master_conv3x3_zero_fwd(const void* x, const void* w, const void* bias, void* out, int B, int H, int W, int Cin, int Cout,
                             int relu, int dtype, master_stream_t stream);
 int master_maxpool2x2_fwd(const void* x, void* out, int N, int H, int W, int C, int dtype, master_stream_t stream);

@@ -748,14 +748,16 @@ class PerceptualLossFn(torch.autograd.Function):
         B = output.shape[0]
         dev = output.device
         dt = vgg.compute_dtype
-        x = ops.image_to_nhwc([content, style, output.detach()], _CPAD, dt)      # one NHWC batch [content | style | output]
         acts = {}                         # conv index -> ReLU output [3B,H,W,C]
         taps = []
-        h = x
+        h = None
         for i in range(30):
             if i in VGG19_CONVS:
-                w, b = vgg._weights(i)
-                h = ops.conv3x3_zero(h, w, b, relu=True, logical_cin=vgg.features[i].weight.shape[1])
+                if i == 0:                # conv1_1 straight from the NCHW images: one NHWC batch [content | style | output]
+                    h = ops.vgg_conv1([content, style, output.detach()], vgg.features[0].weight, vgg.features[0].bias, dt)
+                else:
+                    w, b = vgg._weights(i)
+                    h = ops.conv3x3_zero(h, w, b, relu=True, logical_cin=vgg.features[i].weight.shape[1])
                 acts[i] = h
             elif i in VGG19_POOLS:
                 h = ops.maxpool2x2(h)

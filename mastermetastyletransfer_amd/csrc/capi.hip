@@ -56,6 +56,7 @@ int window_attn_bwd_f32(const float*, const float*, const float*, const float*, 
                         float*, float*, int, int, int, float*, float*, float*, float*, int, int, int, int, int, int, float, hipStream_t);
 int gemm_f32_conv3x3(const float*, const float*, const float*, float*, int, int, int, int, int, int, int, int,
                      hipStream_t, int zero_pad = 0);
+template <typename T> int vgg_conv1_launch(const float*, const float*, const float*, void*, int, int, int, int, hipStream_t);
 template <typename T> int image_to_nhwc_launch(const float*, void*, int, int, int, int, hipStream_t);
 template <typename T> int maxpool2_launch(const void*, void*, int, int, int, int, hipStream_t);
 template <typename T> int chan_stats_launch(const void*, float*, float*, float*, int, int, int, hipStream_t);
@@ -626,6 +627,16 @@ int master_image_to_nhwc_fwd(const float* img, void* out, int N, int H, int W, i
     if (dtype == MASTER_F32) return image_to_nhwc_launch<float>(img, out, N, H, W, Cpad, (hipStream_t)stream);
     if (dtype == MASTER_BF16) return image_to_nhwc_launch<bf16_t>(img, out, N, H, W, Cpad, (hipStream_t)stream);
     master_set_error("image_to_nhwc: bad dtype %d", dtype); return MASTER_ERR_INVALID;
+}
+
+int master_vgg_conv1_fwd(const float* img, const float* w, const float* bias, void* out, int N, int H, int W, int relu, int dtype,
+                         master_stream_t stream) {
+    REQUIRE(img && w && bias && out && N > 0 && H > 0 && W > 0, "vgg_conv1: bad operand");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_CONV, s);
+    if (dtype == MASTER_F32) return vgg_conv1_launch<float>(img, w, bias, out, N, H, W, relu, s);
+    if (dtype == MASTER_BF16) return vgg_conv1_launch<bf16_t>(img, w, bias, out, N, H, W, relu, s);
+    master_set_error("vgg_conv1: bad dtype %d", dtype); return MASTER_ERR_INVALID;
 }
 
 int master_maxpool2x2_fwd(const void* x, void* out, int N, int H, int W, int C, int dtype, master_stream_t stream) {

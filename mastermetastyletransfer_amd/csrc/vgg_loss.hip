@@ -129,6 +129,58 @@ __global__ __launch_bounds__(256) void in_dist_kernel(const T* __restrict__ x, c
     if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// ---- VGG-19 conv1_1 + ReLU (loss.py:23-37: Conv2d(3, 64, 3, padding=1) on the fp32 NCHW image), direct (r03).  As an implicit GEMM the
+//      layer ran with its 3 input channels zero-padded to 32 (K = 288 for 27 real taps) behind a pass that wrote that padded NHWC copy of
+//      the images (201 MB at 24 x 256^2): ~0.7 ms of the train step for 5 GFLOP.  Here: workgroup = 4 output rows x 64 pixels, wave = one
+//      row, LANE = OUTPUT CHANNEL (Cout = 64 = the wave): the lane's 27 weights live in registers, the 3 x 6 x 66 input halo tile (zero
+//      padding resolved at load) in LDS; every input value is a wave-uniform LDS read (a 3-wide sliding window per (channel, ky): 9
+//      reads per pixel), 27 FMAs per pixel and lane, and the store of a pixel is ONE contiguous 256-byte (fp32) / 128-byte (bf16) row.
+template <typename T>
+__global__ __launch_bounds__(256) void vgg_conv1_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        T* __restrict__ out, int H, int W, int relu) {
+    __shared__ float halo[3][6][68];                             // rows y0-1 .. y0+4, columns x0-1 .. x0+64
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.z, y0 = blockIdx.y * 4, x0 = blockIdx.x * 64;
+    for (int i = tid; i < 3 * 6 * 66; i += 256) {
+        const int ci = i / (6 * 66), rem = i - ci * (6 * 66), ry = rem / 66, rx = rem - ry * 66;
+        const int gy = y0 - 1 + ry, gx = x0 - 1 + rx;
+        halo[ci][ry][rx] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? img[(((size_t)n * 3 + ci) * H + gy) * W + gx] : 0.f;
+    }
+    // fp64 accumulation (vector fp64 FMAs issue at the rate of un-packed fp32 ones on this chip): the layer's output is the correctly
+    // rounded fp32 value of the 27-term sum.  The loss behind it normalises nearly constant channels (InstanceNorm, eps 1e-5) and
+    // amplifies first-layer rounding by orders of magnitude on small maps (profiles/r02_grad_conditioning.txt).
+    double wg[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) wg[k] = (double)w[lane * 27 + k]; // nn.Conv2d layout [co][ci][ky][kx]
+    const double b = (double)bias[lane];
+    __syncthreads();
+    const int y = y0 + wave;
+    if (y >= H) return;
+    int npx = W - x0; npx = npx > 64 ? 64 : npx;
+    T* orow = out + (((size_t)n * H + y) * W + x0) * 64 + lane;
+    double win[9][3];                                            // [(ci, ky)][kx]: the three columns under the current pixel
+#pragma unroll
+    for (int r = 0; r < 9; ++r) { win[r][0] = (double)halo[r / 3][wave + r % 3][0]; win[r][1] = (double)halo[r / 3][wave + r % 3][1]; }
+    auto pixel = [&](int px, int i0, int i1, int i2) __attribute__((always_inline)) {      // window columns (i0, i1, i2) = (px-1, px, px+1)
+#pragma unroll
+        for (int r = 0; r < 9; ++r) win[r][i2] = (double)halo[r / 3][wave + r % 3][px + 2];
+        double acc = b;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            acc = fma(wg[3 * r + 0], win[r][i0], acc);
+            acc = fma(wg[3 * r + 1], win[r][i1], acc);
+            acc = fma(wg[3 * r + 2], win[r][i2], acc);
+        }
+        float o = (float)acc;
+        if (relu) o = fmaxf(o, 0.f);
+        Elem<T>::st(orow + (size_t)px * 64, o);
+    };
+    int px = 0;
+    for (; px + 3 <= npx; px += 3) { pixel(px, 0, 1, 2); pixel(px + 1, 1, 2, 0); pixel(px + 2, 2, 0, 1); }   // the window rotates: no register moves
+    if (px < npx) { pixel(px, 0, 1, 2); ++px; }
+    if (px < npx) pixel(px, 1, 2, 0);
+}
+
 }  // namespace
 
 template <typename T> int image_to_nhwc_launch(const float* img, void* out, int N, int H, int W, int CP, hipStream_t s) {
@@ -157,6 +209,12 @@ template <typename T> int in_dist_launch(const void* x, const float* mean, const
     hipLaunchKernelGGL((in_dist_kernel<T>), dim3(stats_slices(HW), pairs), dim3(256), 0, s, (const T*)x, mean, var, partial, pair_off, HW, C, eps, squared);
     return master_check_launch("in_dist");
 }
+template <typename T> int vgg_conv1_launch(const float* img, const float* w, const float* bias, void* out, int N, int H, int W, int relu, hipStream_t s) {
+    hipLaunchKernelGGL((vgg_conv1_kernel<T>), dim3((W + 63) / 64, (H + 3) / 4, N), dim3(256), 0, s, img, w, bias, (T*)out, H, W, relu);
+    return master_check_launch("vgg_conv1");
+}
+template int vgg_conv1_launch<float>(const float*, const float*, const float*, void*, int, int, int, int, hipStream_t);
+template int vgg_conv1_launch<bf16_t>(const float*, const float*, const float*, void*, int, int, int, int, hipStream_t);
 template int image_to_nhwc_launch<float>(const float*, void*, int, int, int, int, hipStream_t);
 template int image_to_nhwc_launch<bf16_t>(const float*, void*, int, int, int, int, hipStream_t);
 template int maxpool2_launch<float>(const void*, void*, int, int, int, int, hipStream_t);

@@ -78,12 +78,15 @@ class VGG19_custom(nn.Module):
     def forward(self, x: Tensor):
         """x: fp32 NCHW image batch (or a list of batches, laid out one after the other) -> list of four NHWC feature maps in the
         compute dtype"""
-        h = ops.image_to_nhwc(x, _CPAD, self.compute_dtype)
+        h = None
         taps = []
         for i in range(30):
             if i in VGG19_CONVS:
-                w, b = self._weights(i)
-                h = ops.conv3x3_zero(h, w, b, relu=True, logical_cin=VGG19_CONVS[i][0])                           # conv i and the ReLU at i+1 in one launch
+                if i == 0:                                                             # conv1_1 + ReLU straight from the NCHW image (27 real taps)
+                    h = ops.vgg_conv1(x, self.features[0].weight, self.features[0].bias, self.compute_dtype)
+                else:
+                    w, b = self._weights(i)
+                    h = ops.conv3x3_zero(h, w, b, relu=True, logical_cin=VGG19_CONVS[i][0])                       # conv i and the ReLU at i+1 in one launch
             elif i in VGG19_POOLS:
                 h = ops.maxpool2x2(h)
             elif i in VGG19_TAPS:

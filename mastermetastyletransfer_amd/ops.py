@@ -23,7 +23,7 @@ K_FAMILIES = ("linear", "conv3x3", "window_attn", "layernorm", "instnorm", "patc
 EXPORTS = (
     "master_version", "master_last_error_string", "master_linear_fwd", "master_conv3x3_reflect_fwd",
     "master_window_attn_fwd", "master_layernorm_fwd", "master_instnorm_fwd", "master_patch_embed_fwd",
-    "master_patch_merge_ln_fwd", "master_patch_merge_linear_fwd", "master_resize_plan", "master_preprocess_fwd", "master_postprocess_fwd", "master_image_to_nhwc_fwd", "master_conv3x3_zero_fwd", "master_maxpool2x2_fwd", "master_channel_stats_fwd", "master_stats_slices", "master_instnorm_distance_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_linear_ln_fwd", "master_attn_block_fwd", "master_window_attn_proj_fwd", "master_linear_group_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
+    "master_patch_merge_ln_fwd", "master_patch_merge_linear_fwd", "master_resize_plan", "master_preprocess_fwd", "master_postprocess_fwd", "master_image_to_nhwc_fwd", "master_vgg_conv1_fwd", "master_conv3x3_zero_fwd", "master_maxpool2x2_fwd", "master_channel_stats_fwd", "master_stats_slices", "master_instnorm_distance_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_linear_ln_fwd", "master_attn_block_fwd", "master_window_attn_proj_fwd", "master_linear_group_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
     # train step
     "master_linear_act_fwd", "master_linear_dgrad", "master_linear_wgrad", "master_gemm_workspace_floats", "master_colsum",
     "master_colsum_workspace_floats", "master_reduce_slabs", "master_reduce_segments", "master_layernorm_bwd", "master_layernorm_bwd_workspace_floats",
@@ -90,6 +90,7 @@ def load_library() -> ctypes.CDLL:
     lib.master_preprocess_fwd.argtypes = [vp, ci, ci, ci, vp, ci, ci, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp]
     lib.master_postprocess_fwd.argtypes = [vp, vp, ci, ci, ci, vp]
     lib.master_image_to_nhwc_fwd.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
+    lib.master_vgg_conv1_fwd.argtypes = [vp] * 4 + [ci] * 5 + [vp]
     lib.master_conv3x3_zero_fwd.argtypes = [vp] * 4 + [ci] * 7 + [vp]
     lib.master_maxpool2x2_fwd.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
     lib.master_channel_stats_fwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
@@ -540,6 +541,29 @@ def conv3x3_zero(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, re
                bytes=x.element_size() * (B * H * W * lc + Cout * 9 * lc + out.numel()))
     _check(load_library().master_conv3x3_zero_fwd(_p(x), _p(w_packed), _p(bias), _p(out), B, H, W, Cin, Cout, int(relu), _dt(x), _stream()),
            "master_conv3x3_zero_fwd")
+    return out
+
+
+@_on_device
+def vgg_conv1(img, weight: torch.Tensor, bias: torch.Tensor, dtype: torch.dtype, relu: bool = True) -> torch.Tensor:
+    """Conv2d(3, 64, 3, padding=1) (+ ReLU) straight from fp32 NCHW images -> NHWC [N,H,W,64] in `dtype` (master_vgg_conv1_fwd).  A list of
+    image batches of one H x W is written into consecutive batch slices of one output.  weight: nn.Conv2d's [64,3,3,3]."""
+    imgs = list(img) if isinstance(img, (list, tuple)) else [img]
+    _dev(*imgs)
+    imgs = [i.contiguous().float() for i in imgs]
+    _, _, H, W = imgs[0].shape
+    if any(tuple(i.shape[1:]) != (3, H, W) for i in imgs) or tuple(weight.shape) != (64, 3, 3, 3):
+        raise ValueError("vgg_conv1: images [N,3,H,W] of one size and a [64,3,3,3] weight")
+    w = weight.detach().float().contiguous()
+    b = bias.detach().float().contiguous()
+    out = torch.empty((sum(i.shape[0] for i in imgs), H, W, 64), dtype=dtype, device=imgs[0].device)
+    lo = 0
+    for i in imgs:
+        n = i.shape[0]
+        if _COUNT_ON:
+            _count("conv3x3", flops=2.0 * n * H * W * 27 * 64, bytes=4.0 * n * 3 * H * W + out.element_size() * n * H * W * 64)
+        _check(load_library().master_vgg_conv1_fwd(_p(i), _p(w), _p(b), _p(out[lo:lo + n]), n, H, W, int(relu), _dt(out), _stream()), "master_vgg_conv1_fwd")
+        lo += n
     return out
 
 
