@@ -334,6 +334,15 @@ int master_conv3x3_wgrad(const void* g, const void* x, void* dw, void* dbias, in
 int master_relu_mask(const void* g, const void* relu_out, void* gm, int B, int HW, int C, int Cp, int g_nchw, int dtype,
                      master_stream_t stream);
 
+/* Backward of the decoder's LAST convolution, Conv2d(Cin = 32, 3, 3, padding_mode='reflect') without ReLU (decoder.py:54), straight from the
+ * image gradient g in NCHW [B,3,H,W] and nn.Conv2d's own weight layout w [3][Cin][3][3] (no 32-channel padded copies):
+ * _dgrad: dxp [B,H+2,W+2,Cin], the data gradient on the reflect-padded domain (fold it with master_fold_reflect);
+ * _wgrad: dw [3][Cin][3][3] and dbias [3] (NULL: skipped) from the NHWC input x [B,H,W,Cin]; ws: _workspace_floats(B, H, W) floats. */
+int master_conv3x3_cout3_dgrad(const float* g, const float* w, float* dxp, int B, int H, int W, int Cin, master_stream_t stream);
+size_t master_conv3x3_cout3_wgrad_workspace_floats(int B, int H, int W);
+int master_conv3x3_cout3_wgrad(const float* g, const float* x, float* dw, float* dbias, float* ws, size_t ws_floats, int B, int H, int W, int Cin,
+                               master_stream_t stream);
+
 /* Weight layouts of a trainable 3x3 convolution (decoder.py:24-54) from nn.Conv2d's w [Cout][Cin][3][3], one launch:
  * wp [Cout][3][3][Cin] (master_conv3x3_reflect_fwd / master_conv3x3_wgrad) and, when wf != NULL, wf [Cin][3][3][Cp] = taps flipped, channels
  * swapped, Cout zero-padded to Cp (master_conv3x3_dgrad). */

@@ -653,6 +653,29 @@ def conv_backward(g: Tensor, y_relu: Optional[Tensor], x: Tensor, weight: Tensor
     H, W = Hin << up, Win << up
     Cp = _pad32(Cout)
     dev = x.device
+    if Cout == 3 and Cin == 32 and reflect and not upsample and g_nchw and y_relu is None and dgrad_add is None and dgrad_relu_src is None:
+        # the decoder's last layer (32 -> 3, no ReLU): direct kernels on the NCHW image gradient - no 32-channel padded copy of it, no
+        # GEMMs that spend 29/32 of their work on zero channels
+        g = _f32c(g)
+        w3 = _f32c(weight.detach())
+        dw = db = dx = None
+        if need_dw or need_db:
+            dw = torch.empty((3, Cin, 3, 3), dtype=F, device=dev)
+            db = torch.empty((3,), dtype=F, device=dev) if need_db else None
+            ws = _ws(lib.master_conv3x3_cout3_wgrad_workspace_floats(B, H, W), dev)
+            if ops._COUNT_ON:
+                ops._count("conv_wgrad", flops=2.0 * B * H * W * 3 * 9 * Cin, bytes=4.0 * (B * H * W * 3 + x.numel() + 3 * 9 * Cin))
+            _check(lib.master_conv3x3_cout3_wgrad(_p(g), _p(x), _p(dw), _p(db), _p(ws), ws.numel(), B, H, W, Cin, _stream()), "master_conv3x3_cout3_wgrad")
+            if not need_dw:
+                dw = None
+        if need_dx:
+            dxp = torch.empty((B, H + 2, W + 2, Cin), dtype=F, device=dev)
+            if ops._COUNT_ON:
+                ops._count("conv_dgrad", flops=2.0 * B * H * W * 3 * 9 * Cin, bytes=4.0 * (B * H * W * (3 + Cin) + 3 * 9 * Cin))
+            _check(lib.master_conv3x3_cout3_dgrad(_p(g), _p(w3), _p(dxp), B, H, W, Cin, _stream()), "master_conv3x3_cout3_dgrad")
+            dx = torch.empty((B, H, W, Cin), dtype=F, device=dev)
+            _check(lib.master_fold_reflect(_p(dxp), _p(dx), B, H, W, Cin, 0, F32, _stream()), "master_fold_reflect")
+        return dx, dw, db
     if premasked and Cp == Cout and not g_nchw:
         gm = g
     else:

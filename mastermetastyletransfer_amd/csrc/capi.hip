@@ -44,6 +44,9 @@ int adam_dev_launch(const void*, int, long long, const float*, int*, hipStream_t
 int loss_tap_slices(int);
 int loss_terms_launch(const float*, const float*, const float*, int, float*, float*, float*, int, int, int, int, int, hipStream_t);
 int conv_weight_pack_launch(const float*, float*, float*, int, int, int, hipStream_t);
+int conv_cout3_dgrad_launch(const float*, const float*, float*, int, int, int, hipStream_t);
+size_t conv_cout3_wgrad_workspace(int, int, int);
+int conv_cout3_wgrad_launch(const float*, const float*, float*, float*, float*, int, int, int, hipStream_t);
 int bias_tile_fwd_launch(const float*, const long long*, float*, int, int, hipStream_t);
 int bias_tile_bwd_launch(const float*, const long long*, float*, int, int, int, hipStream_t);
 template <typename T> int loss_tap_bwd_launch(const void*, const float*, const float*, const float*, const float*, float*, void*, int, int, int,
@@ -342,6 +345,24 @@ int master_fold_reflect(const void* dxp, void* out, int B, int H, int W, int C, 
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_TRAIN_MISC, s);
     return fold_reflect_launch((const float*)dxp, (float*)out, B, H, W, C, upsample, s);
+}
+
+int master_conv3x3_cout3_dgrad(const float* g, const float* w, float* dxp, int B, int H, int W, int Cin, master_stream_t stream) {
+    REQUIRE(g && w && dxp && B > 0 && H >= 2 && W >= 2, "conv3x3_cout3_dgrad: bad arguments");
+    if (Cin != 32) { master_set_error("conv3x3_cout3_dgrad: built for Cin = 32 (got %d)", Cin); return MASTER_ERR_UNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_CONV_DGRAD, s);
+    return conv_cout3_dgrad_launch(g, w, dxp, B, H, W, s);
+}
+size_t master_conv3x3_cout3_wgrad_workspace_floats(int B, int H, int W) { return conv_cout3_wgrad_workspace(B, H, W); }
+int master_conv3x3_cout3_wgrad(const float* g, const float* x, float* dw, float* dbias, float* ws, size_t ws_floats, int B, int H, int W, int Cin,
+                               master_stream_t stream) {
+    REQUIRE(g && x && dw && ws && B > 0 && H >= 2 && W >= 2, "conv3x3_cout3_wgrad: bad arguments");
+    if (Cin != 32) { master_set_error("conv3x3_cout3_wgrad: built for Cin = 32 (got %d)", Cin); return MASTER_ERR_UNSUPPORTED; }
+    REQUIRE(ws_floats >= conv_cout3_wgrad_workspace(B, H, W), "conv3x3_cout3_wgrad: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_CONV_WGRAD, s);
+    return conv_cout3_wgrad_launch(g, x, dw, dbias, ws, B, H, W, s);
 }
 
 int master_conv_weight_pack(const float* w, float* wp, float* wf, int Cout, int Cin, int Cp, master_stream_t stream) {

@@ -29,7 +29,7 @@ EXPORTS = (
     "master_colsum_workspace_floats", "master_reduce_slabs", "master_reduce_segments", "master_layernorm_bwd", "master_layernorm_bwd_workspace_floats",
     "master_instnorm_bwd", "master_window_attn_bwd", "master_conv3x3_dgrad", "master_conv3x3_wgrad", "master_relu_mask",
     "master_fold_reflect", "master_maxpool2x2_bwd", "master_nhwc_to_image", "master_rowscale_add", "master_mul_add_fwd",
-    "master_mul_add_bwd", "master_colsum_prod", "master_channel_affine_fwd", "master_softmax_rows_fwd", "master_softmax_rows_bwd", "master_loss_tap_bwd", "master_loss_tap_workspace_floats", "master_loss_terms_fwd", "master_conv_weight_pack", "master_bias_tile_fwd", "master_bias_tile_bwd", "master_adam_chunk", "master_adam_step", "master_adam_step_dev", "master_lerp",
+    "master_mul_add_bwd", "master_colsum_prod", "master_channel_affine_fwd", "master_softmax_rows_fwd", "master_softmax_rows_bwd", "master_loss_tap_bwd", "master_loss_tap_workspace_floats", "master_loss_terms_fwd", "master_conv_weight_pack", "master_conv3x3_cout3_dgrad", "master_conv3x3_cout3_wgrad", "master_conv3x3_cout3_wgrad_workspace_floats", "master_bias_tile_fwd", "master_bias_tile_bwd", "master_adam_chunk", "master_adam_step", "master_adam_step_dev", "master_lerp",
 )
 
 _lib = None
@@ -114,6 +114,10 @@ def load_library() -> ctypes.CDLL:
     lib.master_reduce_slabs.argtypes = [vp, vp, cz, cz, ci, vp]
     lib.master_reduce_segments.argtypes = [vp, ci, vp]
     lib.master_conv_weight_pack.argtypes = [vp] * 3 + [ci] * 3 + [vp]
+    lib.master_conv3x3_cout3_dgrad.argtypes = [vp] * 3 + [ci] * 4 + [vp]
+    lib.master_conv3x3_cout3_wgrad.argtypes = [vp] * 5 + [cz] + [ci] * 4 + [vp]
+    lib.master_conv3x3_cout3_wgrad_workspace_floats.argtypes = [ci] * 3
+    lib.master_conv3x3_cout3_wgrad_workspace_floats.restype = cz
     lib.master_bias_tile_fwd.argtypes = [vp] * 3 + [ci, ci, vp]
     lib.master_bias_tile_bwd.argtypes = [vp] * 3 + [ci] * 3 + [vp]
     lib.master_colsum_prod.argtypes = [vp] * 4 + [ci] * 4 + [vp]
