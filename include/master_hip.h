@@ -246,19 +246,27 @@ int master_convert(const void* src, void* dst, size_t n, int src_dtype, int dst_
 int master_linear_act_fwd(const void* a, const void* w, const void* bias, void* out, void* aux, int M, int N, int K, int lda, int ldo,
                           int act, int dtype, master_stream_t stream);
 
+/* master_linear_act_fwd on a residual branch under torchvision StochasticDepth(p, "row") (style_transformer.py:390-397), one launch:
+ *     out[m,:] = res[m,:] + rowscale[m / rows_per_scale] * act(a[m,:] . w^T + bias)        (res, rowscale optional = NULL)
+ * rowscale: one fp32 factor per image (0 or 1/(1-p)), rows_per_scale = tokens per image.  In the backward the same factor applies to the
+ * upstream gradient of the branch: master_linear_dgrad / master_linear_wgrad take it as `rowscale` (dgrad scales its output rows, wgrad
+ * the rows of g it stages, and with them the bias gradient), so no scaled copy of g is ever written. */
+int master_linear_res_fwd(const void* a, const void* w, const void* bias, const void* res, const float* rowscale, int rows_per_scale, void* out,
+                          void* aux, int M, int N, int K, int lda, int ldo, int ldr, int act, int dtype, master_stream_t stream);
+
 /* Data gradient of out = a . w^T:  da[M,K] = g[M,N] . w[N,K]; with gelu_pre != NULL the result is multiplied by gelu'(gelu_pre[M,K])
  * (the backward of the GELU that produced `a`); with add != NULL, add[M,K] (row stride ld_add) is added last - the gradient reaching `a`
  * over a skip connection.  N % 32 == 0, K % 4 == 0. */
-int master_linear_dgrad(const void* g, const void* w, void* da, const void* gelu_pre, const void* add, int M, int N, int K, int ldg, int ldda,
-                        int ld_pre, int ld_add, int dtype, master_stream_t stream);
+int master_linear_dgrad(const void* g, const void* w, void* da, const void* gelu_pre, const void* add, const float* rowscale, int rows_per_scale,
+                        int M, int N, int K, int ldg, int ldda, int ld_pre, int ld_add, int dtype, master_stream_t stream);
 
 /* Weight gradient of out = a . w^T + bias:  dw[N,K] = g[M,N]^T . a[M,K] (dense, row stride K) and, when dbias != NULL, the bias gradient
  * dbias[N] = sum_m g[m][n] from the same pass over g (what autograd's Linear backward returns for weight and bias; MASTER_ACCUMULATE adds to
  * both).  The contraction over the M tokens is split across workgroups; ws holds the partial tiles and row sums:
  * master_gemm_workspace_floats(N, K) floats are always enough. */
 size_t master_gemm_workspace_floats(int rows, int cols);
-int master_linear_wgrad(const void* g, const void* a, void* dw, void* dbias, int M, int N, int K, int ldg, int lda, void* ws, size_t ws_floats,
-                        int dtype, master_stream_t stream);
+int master_linear_wgrad(const void* g, const void* a, void* dw, void* dbias, const float* rowscale, int rows_per_scale, int M, int N, int K, int ldg,
+                        int lda, void* ws, size_t ws_floats, int dtype, master_stream_t stream);
 
 /* out[n] = sum_m x[m][n]  (bias gradients).  N % 4 == 0; ws: master_colsum_workspace_floats(M, N) floats. */
 size_t master_colsum_workspace_floats(int M, int N);

@@ -152,36 +152,47 @@ shared_grads = _SharedGrads()
 # raw launches (device guard: the autograd engine may call backward from another thread / with another current device)
 # ---------------------------------------------------------------------------------------------------------------------------------------
 @ops._on_device
-def linear_act_fwd(a: Tensor, w: Tensor, bias: Optional[Tensor], act: int, want_pre: bool) -> Tuple[Tensor, Optional[Tensor]]:
+def linear_act_fwd(a: Tensor, w: Tensor, bias: Optional[Tensor], act: int, want_pre: bool, res: Optional[Tensor] = None,
+                   rowscale: Optional[Tensor] = None, rows_per_scale: int = 0) -> Tuple[Tensor, Optional[Tensor]]:
+    """act(a . w^T + bias); with `res` / `rowscale`: res + rowscale[row // rows_per_scale] * (that) in the same launch (a residual branch
+    under StochasticDepth "row": one factor per image)"""
     M, K = a.shape
     N = w.shape[0]
     out = torch.empty((M, N), dtype=F, device=a.device)
     pre = torch.empty_like(out) if want_pre else None
-    _check(load_library().master_linear_act_fwd(_p(a), _p(w), _p(bias), _p(out), _p(pre), M, N, K, a.stride(0), N, act, F32, _stream()),
-           "master_linear_act_fwd")
+    lib = load_library()
+    if res is None and rowscale is None:
+        _check(lib.master_linear_act_fwd(_p(a), _p(w), _p(bias), _p(out), _p(pre), M, N, K, a.stride(0), N, act, F32, _stream()), "master_linear_act_fwd")
+    else:
+        _check(lib.master_linear_res_fwd(_p(a), _p(w), _p(bias), _p(res), _p(rowscale), int(rows_per_scale), _p(out), _p(pre), M, N, K, a.stride(0), N,
+                                         res.stride(0) if res is not None else 0, act, F32, _stream()), "master_linear_res_fwd")
     return out, pre
 
 
 @ops._on_device
-def linear_dgrad(g: Tensor, w: Tensor, gelu_pre: Optional[Tensor] = None, add: Optional[Tensor] = None) -> Tensor:
-    """g . w (* gelu'(gelu_pre)) (+ add: the gradient arriving over a skip connection, added in the GEMM's epilogue)"""
+def linear_dgrad(g: Tensor, w: Tensor, gelu_pre: Optional[Tensor] = None, add: Optional[Tensor] = None, rowscale: Optional[Tensor] = None,
+                 rows_per_scale: int = 0) -> Tensor:
+    """g . w (* gelu'(gelu_pre)) (* rowscale[row // rows_per_scale]: g belongs to a StochasticDepth branch) (+ add: the gradient arriving
+    over a skip connection) - all in the GEMM's epilogue"""
     M, N = g.shape
     K = w.shape[1]
     da = torch.empty((M, K), dtype=F, device=g.device)
     if ops._COUNT_ON:
         ops._count("linear_bwd", flops=2.0 * M * N * K, bytes=4.0 * (M * N + N * K + M * K * (1 + (gelu_pre is not None) + (add is not None))))
-    _check(load_library().master_linear_dgrad(_p(g), _p(w), _p(da), _p(gelu_pre), _p(add), M, N, K, g.stride(0), K, K,
+    _check(load_library().master_linear_dgrad(_p(g), _p(w), _p(da), _p(gelu_pre), _p(add), _p(rowscale), int(rows_per_scale), M, N, K, g.stride(0), K, K,
                                               add.stride(0) if add is not None else 0, F32, _stream()), "master_linear_dgrad")
     return da
 
 
 @ops._on_device
 def linear_wgrad(g: Tensor, a: Optional[Tensor], out: Optional[Tensor] = None, accumulate: bool = False, dbias: Optional[Tensor] = None,
-                 want_bias: bool = False, want_weight: bool = True):
+                 want_bias: bool = False, want_weight: bool = True, rowscale: Optional[Tensor] = None, rows_per_scale: int = 0):
     """-> (dw [N,K] = g^T . a, db [N] = column sums of g or None): one GEMM launch + one slab reduce for both (the bias gradient rides
     along in the workgroups of the weight gradient's first column tile).  want_weight False: the bias gradient alone (master_colsum)."""
     M, N = g.shape
     if not want_weight:
+        if rowscale is not None:
+            raise ops.MasterHipError("linear_wgrad: a row-scaled bias gradient alone is not built (weight and bias are always wanted together)")
         return None, colsum(g, dbias, accumulate)
     K = a.shape[1]
     lib = load_library()
@@ -191,7 +202,7 @@ def linear_wgrad(g: Tensor, a: Optional[Tensor], out: Optional[Tensor] = None, a
     ws = _ws(nws, g.device)
     if ops._COUNT_ON:
         ops._count("linear_bwd", flops=2.0 * M * N * K, bytes=4.0 * (M * N + M * K + N * K))
-    _check(lib.master_linear_wgrad(_p(g), _p(a), _p(dw), _p(db), M, N, K, g.stride(0), a.stride(0), _p(ws), ws.numel(),
+    _check(lib.master_linear_wgrad(_p(g), _p(a), _p(dw), _p(db), _p(rowscale), int(rows_per_scale), M, N, K, g.stride(0), a.stride(0), _p(ws), ws.numel(),
                                    F32 | (ACCUMULATE if accumulate else 0), _stream()), "master_linear_wgrad")
     return dw, db
 
@@ -261,35 +272,47 @@ def rowscale_add(x: Tensor, res: Optional[Tensor], scale: Tensor, B: int, T: int
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # Linear / MLP / norms / elementwise
 # ---------------------------------------------------------------------------------------------------------------------------------------
-def _weight_bias_grads(token, g: Tensor, a: Tensor, w: Tensor, bias: Optional[Tensor], need_w: bool, need_b: bool):
-    """(dw, db) of out = a . w^T + bias for the upstream gradient g, through the shared-gradient registry"""
+def _weight_bias_grads(token, g: Tensor, a: Tensor, w: Tensor, bias: Optional[Tensor], need_w: bool, need_b: bool,
+                       rowscale: Optional[Tensor] = None, rows_per_scale: int = 0):
+    """(dw, db) of out = a . w^T + bias for the upstream gradient g (scaled per image by `rowscale` when the Linear sits on a
+    StochasticDepth branch), through the shared-gradient registry"""
     sg = shared_grads
+    rs = dict(rowscale=rowscale, rows_per_scale=rows_per_scale)
     if need_w and need_b:
-        return sg.deliver_pair(token, w, bias, lambda ow, ob, acc, ww, wb: linear_wgrad(g, a, ow, acc, dbias=ob, want_bias=wb, want_weight=ww))
-    dw = sg.deliver(token, w, lambda o, acc: linear_wgrad(g, a, o, acc)[0]) if need_w else None
+        return sg.deliver_pair(token, w, bias, lambda ow, ob, acc, ww, wb: linear_wgrad(g, a, ow, acc, dbias=ob, want_bias=wb, want_weight=ww, **rs))
+    dw = sg.deliver(token, w, lambda o, acc: linear_wgrad(g, a, o, acc, **rs)[0]) if need_w else None
+    if need_b and rowscale is not None:
+        raise ops.MasterHipError("a row-scaled bias gradient without its weight gradient is not built")
     db = sg.deliver(token, bias, lambda o, acc: colsum(g, o, acc)) if need_b else None
     return dw, db
 
 
 class LinearFn(torch.autograd.Function):
-    """a [M,K] @ w[N,K]^T + bias   (nn.Linear: Wq/Wk/Wv/proj, style_transformer.py:114-116,156)"""
+    """a [M,K] @ w[N,K]^T + bias   (nn.Linear: Wq/Wk/Wv/proj, style_transformer.py:114-116,156).
+    With `res` (and `mask` [B], T tokens per image): res + mask[image] * (a @ w^T + bias) - the projection of an attention branch with its
+    StochasticDepth row mask and residual add (style_transformer.py:390-391) in the same launch; in the backward the mask is applied
+    inside the data- and weight-gradient GEMMs and the upstream gradient goes to `res` untouched."""
 
     @staticmethod
-    def forward(ctx, a: Tensor, w: Tensor, bias: Optional[Tensor]):
+    def forward(ctx, a: Tensor, w: Tensor, bias: Optional[Tensor], res: Optional[Tensor] = None, mask: Optional[Tensor] = None, T: int = 0):
         a, w = _f32c(a), _f32c(w)
-        out, _ = linear_act_fwd(a, w, bias, ops.ACT_NONE, False)
-        ctx.save_for_backward(a, w, bias)
+        res_c = _f32c(res) if res is not None else None
+        out, _ = linear_act_fwd(a, w, bias, ops.ACT_NONE, False, res=res_c, rowscale=mask, rows_per_scale=T)
+        ctx.save_for_backward(a, w, bias, mask)
         ctx.has_bias = bias is not None
+        ctx.T = int(T)
         ctx.shared = shared_grads.note(w, bias)
         return out
 
     @staticmethod
     def backward(ctx, g: Tensor):
-        a, w, bias = ctx.saved_tensors
+        a, w, bias, mask = ctx.saved_tensors
         g = _f32c(g)
-        da = linear_dgrad(g, w) if ctx.needs_input_grad[0] else None
-        dw, db = _weight_bias_grads(ctx.shared, g, a, w, bias if ctx.has_bias else None, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
-        return da, dw, db
+        rs = dict(rowscale=mask, rows_per_scale=ctx.T)
+        da = linear_dgrad(g, w, **rs) if ctx.needs_input_grad[0] else None
+        dw, db = _weight_bias_grads(ctx.shared, g, a, w, bias if ctx.has_bias else None, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2], **rs)
+        n_in = len(ctx.needs_input_grad)                             # apply() may have been called with the three Linear arguments only
+        return (da, dw, db, (g if (n_in > 3 and ctx.needs_input_grad[3]) else None), None, None)[:n_in]
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -328,25 +351,34 @@ class MLPFn(torch.autograd.Function):
     The GELU backward is the epilogue of fc2's data-gradient GEMM (gelu'(pre) on the saved pre-activation)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, ln_g, ln_b, eps: float, fork: bool = False):
+    def forward(ctx, x, w1, b1, w2, b2, ln_g, ln_b, eps: float, fork: bool = False, mask: Optional[Tensor] = None, T: int = 0):
+        """fork: also return x (the caller adds the skip connection itself).  mask [B] (T tokens per image): return the whole residual
+        block  x + mask[image] * mlp(norm(x))  - fc2's epilogue adds the skip connection and applies the StochasticDepth row mask."""
         x, w1, w2 = _f32c(x), _f32c(w1), _f32c(w2)
         xn = ops.layernorm(x, ln_g.detach(), ln_b.detach(), eps) if ln_g is not None else x
         h, pre = linear_act_fwd(xn, w1, b1, ops.ACT_GELU, True)
-        y, _ = linear_act_fwd(h, w2, b2, ops.ACT_NONE, False)
-        ctx.save_for_backward(x, xn, pre, h, w1, w2, ln_g, b1, b2)
+        if mask is not None:
+            y, _ = linear_act_fwd(h, w2, b2, ops.ACT_NONE, False, res=x, rowscale=mask, rows_per_scale=T)
+        else:
+            y, _ = linear_act_fwd(h, w2, b2, ops.ACT_NONE, False)
+        ctx.save_for_backward(x, xn, pre, h, w1, w2, ln_g, b1, b2, mask)
         ctx.eps = eps
+        ctx.T = int(T)
         ctx.shared = shared_grads.note(w1, b1, w2, b2, ln_g)
-        return (y, x) if fork else y             # fork: x again, for the skip connection around the MLP (see LayerNormFn)
+        return (y, x) if (fork and mask is None) else y
 
     @staticmethod
     def backward(ctx, g: Tensor, g_skip: Optional[Tensor] = None):
-        x, xn, pre, h, w1, w2, ln_g, b1, b2 = ctx.saved_tensors
+        x, xn, pre, h, w1, w2, ln_g, b1, b2, mask = ctx.saved_tensors
         g = _f32c(g)
-        skip = _f32c(g_skip) if g_skip is not None else None
+        rs = dict(rowscale=mask, rows_per_scale=ctx.T)
+        # the gradient reaching x over the skip connection: the upstream gradient itself when the block's residual add is fused (mask),
+        # the alias' gradient when the caller added the skip connection (fork)
+        skip = g if mask is not None else (_f32c(g_skip) if g_skip is not None else None)
         need = ctx.needs_input_grad
         sg, tok = shared_grads, ctx.shared
-        dw2, db2 = _weight_bias_grads(tok, g, h, w2, b2, need[3], need[4])
-        dpre = linear_dgrad(g, w2, gelu_pre=pre)                        # (g . W2) * gelu'(pre)
+        dw2, db2 = _weight_bias_grads(tok, g, h, w2, b2, need[3], need[4], **rs)
+        dpre = linear_dgrad(g, w2, gelu_pre=pre, **rs)                  # (mask * g . W2) * gelu'(pre)
         dw1, db1 = _weight_bias_grads(tok, dpre, xn, w1, b1, need[1], need[2])
         dx = dg = dbeta = None
         if need[0] or (ln_g is not None and (need[5] or need[6])):
@@ -365,7 +397,7 @@ class MLPFn(torch.autograd.Function):
                 dx = linear_dgrad(dpre, w1, add=skip)                   # the skip gradient joins in the GEMM's epilogue
         elif skip is not None:
             dx = skip
-        return dx, dw1, db1, dw2, db2, dg, dbeta, None, None
+        return (dx, dw1, db1, dw2, db2, dg, dbeta, None, None, None, None)[:len(ctx.needs_input_grad)]
 
 
 class InstNormFn(torch.autograd.Function):

@@ -10,7 +10,7 @@
 
 // ---- kernel launchers defined in the other translation units --------------------------------
 int gemm_f32_linear(const float*, const float*, const float*, const float*, const float*, float*, int, int, int, int,
-                    int, int, int, hipStream_t, float* aux = nullptr);
+                    int, int, int, hipStream_t, float* aux = nullptr, const float* rowscale = nullptr, int rs_rows = 1);
 // ---- train step (gemm_f32.hip, gemm_f32_t.hip, norms_bwd.hip, window_attn_bwd_f32.hip, train_misc.hip) ----
 int window_attn_proj_bf16(const bf16_t*, const bf16_t*, const bf16_t*, int, int, int, const bf16_t*, const bf16_t*, int, int, const float*,
                           const int32_t*, const uint8_t*, const bf16_t*, const float*, const bf16_t*, int, bf16_t*, int, int, int, int, int,
@@ -19,8 +19,10 @@ int linear_ts_group_bf16(int, const bf16_t* const*, const bf16_t* const*, const 
                          const float*, const float*, int, int, float, hipStream_t);
 int gemm_f32_conv3x3_dgrad(const float*, const float*, float*, const float*, const float*, int, int, int, int, int, int, hipStream_t);
 size_t gemm_f32_t_workspace(int, int);
-int gemm_f32_dgrad(const float*, const float*, float*, const float*, const float*, int, int, int, int, int, int, int, hipStream_t);
-int gemm_f32_wgrad(const float*, const float*, float*, float*, int, int, int, int, int, float*, size_t, hipStream_t, int accumulate = 0);
+int gemm_f32_dgrad(const float*, const float*, float*, const float*, const float*, int, int, int, int, int, int, int, hipStream_t, const float* rowscale = nullptr,
+                   int rs_rows = 1);
+int gemm_f32_wgrad(const float*, const float*, float*, float*, int, int, int, int, int, float*, size_t, hipStream_t, int accumulate = 0,
+                   const float* rowscale = nullptr, int rs_rows = 1);
 int gemm_f32_conv3x3_wgrad(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, float*, size_t, hipStream_t);
 int reduce_slabs_launch(const float*, float*, size_t, size_t, int, hipStream_t, int accumulate = 0);
 int reduce_segments_launch(const float* const*, float* const*, const size_t*, const size_t*, const int*, const int*, int, hipStream_t);
@@ -166,8 +168,22 @@ int master_linear_act_fwd(const void* a, const void* w, const void* bias, void* 
                            (float*)aux);
 }
 
-int master_linear_dgrad(const void* g, const void* w, void* da, const void* gelu_pre, const void* add, int M, int N, int K, int ldg, int ldda,
-                        int ld_pre, int ld_add, int dtype, master_stream_t stream) {
+int master_linear_res_fwd(const void* a, const void* w, const void* bias, const void* res, const float* rowscale, int rows_per_scale, void* out,
+                          void* aux, int M, int N, int K, int lda, int ldo, int ldr, int act, int dtype, master_stream_t stream) {
+    F32_ONLY("linear_res_fwd");
+    REQUIRE(a && w && out, "linear_res_fwd: null operand");
+    REQUIRE(M > 0 && N > 0 && K > 0 && K % 32 == 0 && lda >= K && ldo >= N, "linear_res_fwd: bad dims M=%d N=%d K=%d", M, N, K);
+    REQUIRE(al16(a) && al16(w) && lda % 4 == 0, "linear_res_fwd: a/w must be 16-byte aligned, lda %% 4 == 0");
+    REQUIRE(res == nullptr || ldr >= N, "linear_res_fwd: ldr < N");
+    REQUIRE(rowscale == nullptr || rows_per_scale > 0, "linear_res_fwd: rows_per_scale must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(MASTER_K_LINEAR, s);
+    return gemm_f32_linear((const float*)a, (const float*)w, (const float*)bias, nullptr, (const float*)res, (float*)out, M, N, K, lda, ldo, ldr, act, s,
+                           (float*)aux, rowscale, rows_per_scale);
+}
+
+int master_linear_dgrad(const void* g, const void* w, void* da, const void* gelu_pre, const void* add, const float* rowscale, int rows_per_scale,
+                        int M, int N, int K, int ldg, int ldda, int ld_pre, int ld_add, int dtype, master_stream_t stream) {
     F32_ONLY("linear_dgrad");
     REQUIRE(g && w && da, "linear_dgrad: null operand");
     REQUIRE(M > 0 && N > 0 && K > 0 && N % 32 == 0 && K % 4 == 0 && ldg >= N && ldda >= K, "linear_dgrad: bad dims M=%d N=%d K=%d", M, N, K);
@@ -175,13 +191,15 @@ int master_linear_dgrad(const void* g, const void* w, void* da, const void* gelu
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_LINEAR_BWD, s);
     REQUIRE(add == nullptr || ld_add >= K, "linear_dgrad: ld_add < K");
-    return gemm_f32_dgrad((const float*)g, (const float*)w, (float*)da, (const float*)gelu_pre, (const float*)add, M, N, K, ldg, ldda, ld_pre, ld_add, s);
+    REQUIRE(rowscale == nullptr || rows_per_scale > 0, "linear_dgrad: rows_per_scale must be positive");
+    return gemm_f32_dgrad((const float*)g, (const float*)w, (float*)da, (const float*)gelu_pre, (const float*)add, M, N, K, ldg, ldda, ld_pre, ld_add, s,
+                          rowscale, rows_per_scale);
 }
 
 size_t master_gemm_workspace_floats(int rows, int cols) { return gemm_f32_t_workspace(rows, cols); }
 
-int master_linear_wgrad(const void* g, const void* a, void* dw, void* dbias, int M, int N, int K, int ldg, int lda, void* ws, size_t ws_floats,
-                        int dtype, master_stream_t stream) {
+int master_linear_wgrad(const void* g, const void* a, void* dw, void* dbias, const float* rowscale, int rows_per_scale, int M, int N, int K, int ldg,
+                        int lda, void* ws, size_t ws_floats, int dtype, master_stream_t stream) {
     const int accumulate = (dtype & MASTER_ACCUMULATE) != 0; dtype &= ~MASTER_ACCUMULATE;
     F32_ONLY("linear_wgrad");
     REQUIRE(g && a && dw, "linear_wgrad: null operand");
@@ -189,7 +207,9 @@ int master_linear_wgrad(const void* g, const void* a, void* dw, void* dbias, int
     REQUIRE(al16(a) && al16(dw) && (ws == nullptr || al16(ws)), "linear_wgrad: a/dw/ws must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_LINEAR_BWD, s);
-    return gemm_f32_wgrad((const float*)g, (const float*)a, (float*)dw, (float*)dbias, M, N, K, ldg, lda, (float*)ws, ws_floats, s, accumulate);
+    REQUIRE(rowscale == nullptr || rows_per_scale > 0, "linear_wgrad: rows_per_scale must be positive");
+    return gemm_f32_wgrad((const float*)g, (const float*)a, (float*)dw, (float*)dbias, M, N, K, ldg, lda, (float*)ws, ws_floats, s, accumulate, rowscale,
+                          rows_per_scale);
 }
 
 size_t master_colsum_workspace_floats(int M, int N) { return (size_t)colsum_slabs(M, N) * (size_t)N; }

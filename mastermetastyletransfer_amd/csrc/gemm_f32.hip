@@ -28,6 +28,9 @@ struct GemmArgs {
     // pixels (y - 2 + ty, x - 2 + tx): the data-gradient of a padded 3x3 convolution on the padded domain.
     // mask_relu: r1 is not a multiplier but a ReLU output whose sign gates the result:  out = r1 > 0 ? acc + r2 : 0
     float* aux; int off, mask_relu;
+    // rowscale: out = rowscale[m / rs_rows] * act(acc + bias) + r2 - a residual branch under torchvision StochasticDepth(p, "row")
+    // (style_transformer.py:390-397: one factor per image, rs_rows = tokens per image), r03: was a separate elementwise launch
+    const float* rowscale; int rs_rows; unsigned rs_magic;      // rs_magic = ceil(2^32 / rs_rows) when M * rs_rows < 2^32: m / rs_rows = umulhi(m, magic)
 };
 
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
@@ -56,6 +59,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(Ge
     const int mt = (j / NTN) * 8 + (id & 7), nt = j % NTN;
     if (mt >= MT) return;
     const int m0 = mt * BM, n0 = nt * BN;
+    float tile_sc = 1.0f; bool tile_sc_ok = false;                      // per-image row scale of a tile whose rows belong to one image: fetched up front
+    if (!CONV && p.rowscale) {
+        const int mlast = (m0 + BM - 1 < p.M ? m0 + BM - 1 : p.M - 1);
+        const int i0 = p.rs_magic ? (int)__umulhi((unsigned)m0, p.rs_magic) : m0 / p.rs_rows;
+        const int i1 = p.rs_magic ? (int)__umulhi((unsigned)mlast, p.rs_magic) : mlast / p.rs_rows;
+        tile_sc_ok = i0 == i1;
+        tile_sc = p.rowscale[i0];
+    }
 
     // ---- per-thread staging descriptors -------------------------------------------------------
     const int kc = (tid & 7) * 4;
@@ -177,6 +188,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(Ge
                     if (!(p.r1[(size_t)m * p.ldr + n] > 0.0f)) v = 0.0f;
                 } else {
                     if (p.r1) v *= p.r1[(size_t)m * p.ldr + n];
+                    if (!CONV && p.rowscale) v *= tile_sc_ok ? tile_sc : p.rowscale[p.rs_magic ? (int)__umulhi((unsigned)m, p.rs_magic) : m / p.rs_rows];
                     if (p.r2) v += p.r2[(size_t)m * p.ldr + n];
                 }
                 if (CONV && p.out_nchw) {
@@ -233,6 +245,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_dma_kerne
     const int mt = (j8 / NTN) * 8 + (id & 7), nt = j8 % NTN;           // XCD-aware order, as above
     if (mt >= MT) return;
     const int m0 = mt * BM, n0 = nt * BN;
+    float tile_sc = 1.0f; bool tile_sc_ok = false;                      // per-image row scale of a tile whose rows belong to one image: fetched up front
+    if (!CONV && p.rowscale) {
+        const int mlast = (m0 + BM - 1 < p.M ? m0 + BM - 1 : p.M - 1);
+        const int i0 = p.rs_magic ? (int)__umulhi((unsigned)m0, p.rs_magic) : m0 / p.rs_rows;
+        const int i1 = p.rs_magic ? (int)__umulhi((unsigned)mlast, p.rs_magic) : mlast / p.rs_rows;
+        tile_sc_ok = i0 == i1;
+        tile_sc = p.rowscale[i0];
+    }
 
     // ---- per-lane DMA sources: piece j of this wave = tile rows (wave * XPW + j) * 8 + (lane >> 3), LDS chunk position lane & 7 ------
     const int prow = lane >> 3, ppos = lane & 7;
@@ -394,6 +414,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_dma_kerne
                     for (int c = 0; c < 4; ++c) x[c] = a1[it][c] > 0.0f ? x[c] : 0.0f;
                 } else {
                     if (p.r1) x *= a1[it];
+                    if (!CONV && p.rowscale) x *= tile_sc_ok ? tile_sc : p.rowscale[p.rs_magic ? (int)__umulhi((unsigned)orow[it], p.rs_magic) : (int)orow[it] / p.rs_rows];
                     if (p.r2) x += a2[it];
                 }
                 if (ok[it]) *(f32x4*)(p.out + orow[it] * p.ldo + n) = x;
@@ -423,6 +444,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_dma_kerne
                     if (!(p.r1[(size_t)m * p.ldr + n] > 0.0f)) v = 0.0f;
                 } else {
                     if (p.r1) v *= p.r1[(size_t)m * p.ldr + n];
+                    if (!CONV && p.rowscale) v *= p.rowscale[p.rs_magic ? (int)__umulhi((unsigned)m, p.rs_magic) : m / p.rs_rows];
                     if (p.r2) v += p.r2[(size_t)m * p.ldr + n];
                 }
                 if (CONV && p.out_nchw) {
@@ -591,8 +613,11 @@ int dispatch(const GemmArgs& p, hipStream_t s) {
 }  // namespace
 
 int gemm_f32_linear(const float* a, const float* w, const float* bias, const float* r1, const float* r2, float* out,
-                    int M, int N, int K, int lda, int ldo, int ldr, int act, hipStream_t s, float* aux = nullptr) {
-    GemmArgs p{a, w, bias, r1, r2, out, M, N, K, lda, ldo, ldr, act, 0, 0, 0, 1, 1, 0, 0, 0, aux, 0, 0};
+                    int M, int N, int K, int lda, int ldo, int ldr, int act, hipStream_t s, float* aux = nullptr, const float* rowscale = nullptr,
+                    int rs_rows = 1) {
+    const unsigned long long d = (unsigned long long)(rs_rows > 0 ? rs_rows : 1);
+    const unsigned magic = (rowscale && d > 1 && (unsigned long long)M * d < (1ull << 32)) ? (unsigned)(((1ull << 32) + d - 1) / d) : 0u;
+    GemmArgs p{a, w, bias, r1, r2, out, M, N, K, lda, ldo, ldr, act, 0, 0, 0, 1, 1, 0, 0, 0, aux, 0, 0, rowscale, rs_rows > 0 ? rs_rows : 1, magic};
     return dispatch<false>(p, s);
 }
 

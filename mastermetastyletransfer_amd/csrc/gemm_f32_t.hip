@@ -46,9 +46,17 @@ struct TArgs {
     // added it with one elementwise launch per residual block)
     const float* add; int ld_add;
     int xcd_remap;               // set by the launcher when gridDim.x * gridDim.y is a multiple of 8
+    // The upstream gradient G belongs to a residual branch under StochasticDepth(p, "row"): its rows carry one factor per image,
+    // rowscale[row / rs_rows] (r03: was a separate elementwise launch producing a scaled copy of G).
+    //   data-gradient form (A = G row-major):  out[m] *= rowscale[m / rs_rows] in the epilogue, before `add`;
+    //   weight-gradient form (A = G with the contraction index on the rows): staged rows k are scaled by rowscale[k / rs_rows].
+    const float* rowscale; int rs_rows; unsigned rs_magic;      // rs_magic = ceil(2^32 / rs_rows) when rows * rs_rows < 2^32: row / rs_rows = umulhi(row, magic)
 };
 
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// row -> image index of a per-image row scale: one v_mul_hi instead of an integer division (~25 instructions) per staged piece
+__device__ __forceinline__ int rs_index(unsigned row, int rows, unsigned magic) { return magic ? (int)__umulhi(row, magic) : (int)(row / (unsigned)rows); }
 
 __device__ __forceinline__ float gelu_grad(float x) {
     // d/dx [ x Phi(x) ] = Phi(x) + x phi(x)
@@ -95,6 +103,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_t_kernel(
     int kt1 = kt0 + p.chunks_per_split; if (kt1 > nk_all) kt1 = nk_all;
     float* outp = p.out + (size_t)by * p.slab;
 
+    // data-gradient form with a per-image row scale: when the tile's rows belong to ONE image (always, for maps of a multiple of BM tokens)
+    // the factor is fetched here, long before the epilogue needs it; a tile that straddles two images looks its rows up one by one
+    float tile_sc = 1.0f; bool tile_sc_ok = false;
+    if (!AT && p.rowscale) {
+        const int mlast = (m0 + BM - 1 < p.M ? m0 + BM - 1 : p.M - 1);
+        const int i0 = rs_index((unsigned)m0, p.rs_rows, p.rs_magic), i1 = rs_index((unsigned)mlast, p.rs_rows, p.rs_magic);
+        tile_sc_ok = i0 == i1;
+        tile_sc = p.rowscale[i0];
+    }
     const bool a_vec = (p.lda & 3) == 0 && (((uintptr_t)p.a) & 15) == 0;      // else scalar loads (e.g. a 3-channel gradient)
 
     // ---- W^T gather descriptors (conv weight gradient): column group -> (tap, ci) is fixed per thread and chunk slot ----------------
@@ -111,6 +128,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_t_kernel(
     }
 
     f32x4 a_st[ACH], w_st[WCH];
+    float a_sc[ACH];                                             // per staged A piece: the row scale of its contraction row (weight-gradient form)
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) a_sc[i] = 1.0f;
     // bias gradient: thread c = tid + i NT stages contraction row c / (BM/4), columns (c % (BM/4)) * 4 .. +3 of every chunk; NT is a multiple
     // of BM/4, so all of a thread's pieces are the same four columns: one running f32x4, added where the staged values are consumed
     // (stage_store) - next to the load it would put a wait for the global loads in front of the MFMAs they are meant to hide under
@@ -131,6 +151,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_t_kernel(
                     else
 #pragma unroll
                         for (int e = 0; e < 4; ++e) if (m + e < p.M) v[e] = src[e];
+                    // the row's StochasticDepth factor is fetched here but applied where the staged values are consumed (stage_store): a
+                    // multiply next to the load would put a wait for the global loads in front of the MFMAs they are meant to hide under
+                    if (p.rowscale) a_sc[i] = p.rowscale[rs_index((unsigned)(k0 + kr), p.rs_rows, p.rs_magic)];
                 }
                 a_st[i] = v;
             }
@@ -170,6 +193,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_t_kernel(
 #pragma unroll
             for (int i = 0; i < ACH; ++i) {
                 const int c = tid + i * NT;
+                if (p.rowscale) a_st[i] *= a_sc[i];
                 if (c < BK * BM / 4) *(f32x4*)(As + buf * A_ELEMS + (c / (BM / 4)) * LDA_T + (c % (BM / 4)) * 4) = a_st[i];
                 if (do_rowsum) a_sum += a_st[i];                               // zeros where c or the row is out of range; every chunk passes here once
             }
@@ -293,6 +317,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_t_kernel(
 #pragma unroll
                     for (int c = 0; c < 4; ++c) x[c] *= gelu_grad(ax[it][c]);
                 }
+                if (!AT && p.rowscale) x *= tile_sc_ok ? tile_sc : p.rowscale[rs_index((unsigned)orow[it], p.rs_rows, p.rs_magic)];
                 if (p.add) x += ad[it];
                 if (ok[it]) *(f32x4*)(outp + orow[it] * p.ldo + n) = x;
             }
@@ -312,6 +337,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_t_kernel(
                 if (m >= p.M) continue;
                 float v = acc[i][jn][e];
                 if (p.aux) v *= gelu_grad(p.aux[(size_t)m * p.ld_aux + n]);
+                if (!AT && p.rowscale) v *= tile_sc_ok ? tile_sc : p.rowscale[rs_index((unsigned)m, p.rs_rows, p.rs_magic)];
                 if (p.add) v += p.add[(size_t)m * p.ld_add + n];
                 outp[(size_t)m * p.ldo + n] = v;
             }
@@ -350,6 +376,10 @@ int launch_t(TArgs p, float* final_out, float* ws, size_t ws_floats, int want_sp
     static int xcd = -1;
     if (xcd < 0) { const char* e = getenv("MASTER_GEMM_T_XCD"); xcd = e ? atoi(e) : 1; }
     p.xcd_remap = xcd && ((long long)tiles * splits) % 8 == 0 && (long long)tiles * splits >= 16;
+    {   // exact for every row < 2^32 / rs_rows
+        const unsigned long long rows = AT ? (unsigned long long)p.K : (unsigned long long)p.M, d = (unsigned long long)(p.rs_rows > 0 ? p.rs_rows : 1);
+        p.rs_magic = (p.rowscale && d > 1 && rows * d < (1ull << 32)) ? (unsigned)(((1ull << 32) + d - 1) / d) : 0u;
+    }
     static LdsLimit lds_limit;
     lds_limit.ensure((const void*)gemm_f32_t_kernel<BM, BN, WM, WN, AT, GATHER>, (int)lds);
     hipLaunchKernelGGL((gemm_f32_t_kernel<BM, BN, WM, WN, AT, GATHER>), dim3(tiles, splits), dim3(NT), lds, s, p);
@@ -372,8 +402,8 @@ size_t gemm_f32_t_workspace(int M, int N) {
 
 // dX[M,Kc] = G[M,Nc] . W[Nc,Kc] (* gelu'(aux) when aux != NULL)
 int gemm_f32_dgrad(const float* g, const float* w, float* out, const float* aux, const float* add, int M, int Nc, int Kc, int ldg, int ldo, int ld_aux,
-                   int ld_add, hipStream_t s) {
-    TArgs p{g, w, out, M, Kc, Nc, ldg, Kc, ldo, 0, 0, aux, ld_aux, 0, 0, 0, 0, 0, 0, 0, nullptr, 0, add, ld_add};
+                   int ld_add, hipStream_t s, const float* rowscale, int rs_rows) {
+    TArgs p{g, w, out, M, Kc, Nc, ldg, Kc, ldo, 0, 0, aux, ld_aux, 0, 0, 0, 0, 0, 0, 0, nullptr, 0, add, ld_add, 0, rowscale, rs_rows > 0 ? rs_rows : 1};
     if (Kc > 64) {
         // fewer than one 128x128 tile per CU (the StyleTransformer's 8 192-token matrices): 64-row tiles double the workgroups
         // (r03: 64x64 tiles, four workgroups per CU, for the 8 192-token matrices: 512+ workgroups instead of 256 one-per-CU ones)
@@ -390,8 +420,8 @@ int gemm_f32_dgrad(const float* g, const float* w, float* out, const float* aux,
 
 // dW[Nc,Kc] = G[M,Nc]^T . X[M,Kc]      (dense output, ldo = Kc);  dbias[Nc] = column sums of G when dbias != NULL
 int gemm_f32_wgrad(const float* g, const float* x, float* out, float* dbias, int M, int Nc, int Kc, int ldg, int ldx, float* ws, size_t ws_floats,
-                   hipStream_t s, int accumulate) {
-    TArgs p{g, x, out, Nc, Kc, M, ldg, ldx, Kc, 0, 0, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, nullptr, 0, nullptr, 0};
+                   hipStream_t s, int accumulate, const float* rowscale, int rs_rows) {
+    TArgs p{g, x, out, Nc, Kc, M, ldg, ldx, Kc, 0, 0, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, nullptr, 0, nullptr, 0, 0, rowscale, rs_rows > 0 ? rs_rows : 1};
     if (Nc > 64) return launch_t<128, 128, 64, 64, true, false>(p, out, ws, ws_floats, 0, s, accumulate, dbias);
     return launch_t<32, 256, 32, 64, true, false>(p, out, ws, ws_floats, 0, s, accumulate, dbias);
 }

@@ -25,7 +25,7 @@ EXPORTS = (
     "master_window_attn_fwd", "master_layernorm_fwd", "master_instnorm_fwd", "master_patch_embed_fwd",
     "master_patch_merge_ln_fwd", "master_patch_merge_linear_fwd", "master_resize_plan", "master_preprocess_fwd", "master_postprocess_fwd", "master_image_to_nhwc_fwd", "master_vgg_conv1_fwd", "master_conv3x3_zero_fwd", "master_maxpool2x2_fwd", "master_channel_stats_fwd", "master_stats_slices", "master_instnorm_distance_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_linear_ln_fwd", "master_attn_block_fwd", "master_window_attn_proj_fwd", "master_linear_group_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
     # train step
-    "master_linear_act_fwd", "master_linear_dgrad", "master_linear_wgrad", "master_gemm_workspace_floats", "master_colsum",
+    "master_linear_act_fwd", "master_linear_res_fwd", "master_linear_dgrad", "master_linear_wgrad", "master_gemm_workspace_floats", "master_colsum",
     "master_colsum_workspace_floats", "master_reduce_slabs", "master_reduce_segments", "master_layernorm_bwd", "master_layernorm_bwd_workspace_floats",
     "master_instnorm_bwd", "master_window_attn_bwd", "master_conv3x3_dgrad", "master_conv3x3_wgrad", "master_relu_mask",
     "master_fold_reflect", "master_maxpool2x2_bwd", "master_nhwc_to_image", "master_rowscale_add", "master_mul_add_fwd",
@@ -106,9 +106,10 @@ def load_library() -> ctypes.CDLL:
     # ---- train step ----
     cz, cll = ctypes.c_size_t, ctypes.c_longlong
     lib.master_linear_act_fwd.argtypes = [vp] * 5 + [ci] * 7 + [vp]
-    lib.master_linear_dgrad.argtypes = [vp] * 5 + [ci] * 8 + [vp]
+    lib.master_linear_dgrad.argtypes = [vp] * 6 + [ci] * 9 + [vp]
+    lib.master_linear_res_fwd.argtypes = [vp] * 5 + [ci] + [vp, vp] + [ci] * 8 + [vp]
     lib.master_gemm_workspace_floats.argtypes = [ci, ci]; lib.master_gemm_workspace_floats.restype = cz
-    lib.master_linear_wgrad.argtypes = [vp] * 4 + [ci] * 5 + [vp, cz, ci, vp]
+    lib.master_linear_wgrad.argtypes = [vp] * 5 + [ci] * 6 + [vp, cz, ci, vp]
     lib.master_colsum_workspace_floats.argtypes = [ci, ci]; lib.master_colsum_workspace_floats.restype = cz
     lib.master_colsum.argtypes = [vp] * 3 + [ci] * 4 + [vp]
     lib.master_reduce_slabs.argtypes = [vp, vp, cz, cz, ci, vp]

@@ -131,27 +131,36 @@ def _bias64_build(attn) -> Tensor:
     return BiasTileFn.apply(attn.relative_position_bias_table, attn.relative_position_index, N)
 
 
-def _mlp(mlp: nn.Sequential, x: Tensor, norm: Optional[nn.LayerNorm] = None, fork: bool = False):
+def _sd_mask(p: float, training: bool, sd: StochasticDepthMasks, B: int, device) -> Tensor:
+    """the [B] row mask of one residual branch (torchvision StochasticDepth "row": identity - ones - when not training or p == 0)"""
+    return sd.draw(B, p, device) if (training and p > 0.0) else _ones(B, device)
+
+
+def _mlp(mlp: nn.Sequential, x: Tensor, norm: Optional[nn.LayerNorm] = None, fork: bool = False, mask: Optional[Tensor] = None, T: int = 0):
     return MLPFn.apply(x, mlp[0].weight, mlp[0].bias, mlp[3].weight, mlp[3].bias,
                        norm.weight if norm is not None else None, norm.bias if norm is not None else None,
-                       norm.eps if norm is not None else 1e-5, fork)
+                       norm.eps if norm is not None else 1e-5, fork, mask, T)
 
 
 def _mlp_residual(mlp: nn.Sequential, x: Tensor, norm: Optional[nn.LayerNorm], p: float, training: bool, sd: StochasticDepthMasks, B: int,
-                  T: int) -> Tensor:
-    """x + StochasticDepth(mlp(norm(x))).  The skip connection starts at the alias of x that MLPFn hands back, so x has one consumer and
-    the skip gradient is added inside the MLP's backward kernels (no autograd add launch)."""
-    y, xs = _mlp(mlp, x, norm, fork=True)
-    return _residual(y, xs, p, training, sd, B, T)
+                  T: int, mask: Optional[Tensor] = None) -> Tensor:
+    """x + StochasticDepth(mlp(norm(x))) as ONE autograd Function: fc2's epilogue adds the skip connection and applies the row mask, the
+    backward kernels apply the mask to the branch's gradient and add the skip gradient (no rowscale_add launch, no autograd add).
+    `mask`: drawn by the caller when the reference's draw order asks for it earlier."""
+    if mask is None:
+        mask = _sd_mask(p, training, sd, B, x.device)
+    return _mlp(mlp, x, norm, mask=mask, T=T)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # ShiftedWindowAttention (three inputs) -> projected attention outputs, one per value stream (no residual)
 # ---------------------------------------------------------------------------------------------------------------------------------------
 def attention(attn, xq: Tensor, xk: Tensor, xvs: Sequence[Tensor], B: int, H: int, W: int, norm: Optional[nn.LayerNorm] = None,
-              skips: Optional[dict] = None) -> List[Tensor]:
+              skips: Optional[dict] = None, res_masks: Optional[Sequence] = None) -> List[Tensor]:
     """skips (out): id(input tensor) -> the alias of it that the LayerNorm handed back (LayerNormFn fork).  A caller that uses the alias
-    for everything else the tensor feeds (the skip connection of the block) leaves the norm as the tensor's only consumer."""
+    for everything else the tensor feeds (the skip connection of the block) leaves the norm as the tensor's only consumer.
+    res_masks: [(residual tensor, StochasticDepth row mask [B])] per value stream: the function then returns the finished residual
+    blocks  res + mask * proj(attention)  instead of the bare projections (the residual is looked up in `skips` first)."""
     C = xq.shape[1]
     T = H * W
     plan = window_plan(H, W, attn.window_size, attn.shift_size, xq.device)
@@ -201,6 +210,16 @@ def attention(attn, xq: Tensor, xk: Tensor, xvs: Sequence[Tensor], B: int, H: in
         o0, o1 = WindowAttnFn.apply(tq, tk, vs[0], v1, attn.Wk.bias, attn.Wv.bias, attn.Wv.bias if v1 is not None else None, bias64,
                                     (oq, ok, 0, 0), plan, B, T, attn.num_heads, scale)
         cores = [o0] if v1 is None else [o0, o1]
+    if res_masks is not None:
+        # projection + StochasticDepth row mask + residual add of every value stream in one launch each (LinearFn with res / mask).  In
+        # the first layer Scale and Shift are the same tensor (style_transformer.py:1235-1236): one attention core, projected once per
+        # stream because each stream has its own mask and residual
+        outs = []
+        for j, i in enumerate(vmap):
+            res, mask = res_masks[j]
+            res = skips.get(id(res), res) if skips is not None else res
+            outs.append(LinearFn.apply(cores[i], attn.proj.weight, attn.proj.bias, res, mask, T))
+        return outs
     projected = [LinearFn.apply(c, attn.proj.weight, attn.proj.bias) for c in cores]
     return [projected[i] for i in vmap]
 
@@ -210,8 +229,9 @@ def block(blk, xq: Tensor, xk: Tensor, xvs: Sequence[Tensor], residuals: Sequenc
     T = H * W
     p = blk.stochastic_depth_prob
     skips: dict = {}
-    branches = attention(blk.attn, xq, xk, xvs, B, H, W, norm=blk.norm1 if blk.use_norm else None, skips=skips)
-    outs = [_residual(br, skips.get(id(res), res), p, blk.training, sd, B, T) for br, res in zip(branches, residuals)]
+    # masks in the reference's draw order: the attention branches first, then their MLPs
+    masks = [_sd_mask(p, blk.training, sd, B, xq.device) for _ in residuals]
+    outs = attention(blk.attn, xq, xk, xvs, B, H, W, norm=blk.norm1 if blk.use_norm else None, skips=skips, res_masks=list(zip(residuals, masks)))
     if not blk.exclude_MLP_after:
         outs = [_mlp_residual(blk.mlp, o, blk.norm2 if blk.use_norm else None, p, blk.training, sd, B, T) for o in outs]
     return outs
@@ -232,11 +252,13 @@ def style_encoder(enc, key: Tensor, scale: Tensor, shift: Tensor, B, H, W, sd: S
         # :867-882: both calls use q = k = Key: one softmax, two value streams; the residual adds draw their masks in the reference's
         # order (attn Scale, MLP Scale, attn Shift, MLP Shift).  Returns the Key to hand on as well: the alias its LayerNorm gave back
         skips: dict = {}
-        br_s, br_sh = attention(blk.attn, key, key, [scale, shift], B, H, W, norm=blk.norm1 if blk.use_norm else None, skips=skips)
-        s = _residual(br_s, skips.get(id(scale), scale), p_blk, blk.training, sd, B, T)
-        s = _mlp_residual(enc.encoder_MLP_Scale, s, None, p_enc, tr, sd, B, T)
-        sh = _residual(br_sh, skips.get(id(shift), shift), p_blk, blk.training, sd, B, T)
-        sh = _mlp_residual(enc.encoder_MLP_Shift, sh, None, p_enc, tr, sd, B, T)
+        dev = key.device
+        m_s, m_smlp = _sd_mask(p_blk, blk.training, sd, B, dev), _sd_mask(p_enc, tr, sd, B, dev)      # the four masks in the reference's order,
+        m_sh, m_shmlp = _sd_mask(p_blk, blk.training, sd, B, dev), _sd_mask(p_enc, tr, sd, B, dev)    # drawn before the fused launches use them
+        s, sh = attention(blk.attn, key, key, [scale, shift], B, H, W, norm=blk.norm1 if blk.use_norm else None, skips=skips,
+                          res_masks=[(scale, m_s), (shift, m_sh)])
+        s = _mlp_residual(enc.encoder_MLP_Scale, s, None, p_enc, tr, sd, B, T, mask=m_smlp)
+        sh = _mlp_residual(enc.encoder_MLP_Shift, sh, None, p_enc, tr, sd, B, T, mask=m_shmlp)
         return s, sh, skips.get(id(key), key)
 
     if enc.if_use_processed_Key_in_Scale_and_Shift_calculation:
