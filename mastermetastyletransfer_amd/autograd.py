@@ -191,9 +191,8 @@ def linear_wgrad(g: Tensor, a: Optional[Tensor], out: Optional[Tensor] = None, a
     along in the workgroups of the weight gradient's first column tile).  want_weight False: the bias gradient alone (master_colsum)."""
     M, N = g.shape
     if not want_weight:
-        if rowscale is not None:
-            raise ops.MasterHipError("linear_wgrad: a row-scaled bias gradient alone is not built (weight and bias are always wanted together)")
-        return None, colsum(g, dbias, accumulate)
+        gb = rowscale_add(g, None, rowscale, rowscale.numel(), rows_per_scale) if rowscale is not None else g
+        return None, colsum(gb, dbias, accumulate)
     K = a.shape[1]
     lib = load_library()
     dw = out if out is not None else torch.empty((N, K), dtype=F, device=g.device)
@@ -281,9 +280,11 @@ def _weight_bias_grads(token, g: Tensor, a: Tensor, w: Tensor, bias: Optional[Te
     if need_w and need_b:
         return sg.deliver_pair(token, w, bias, lambda ow, ob, acc, ww, wb: linear_wgrad(g, a, ow, acc, dbias=ob, want_bias=wb, want_weight=ww, **rs))
     dw = sg.deliver(token, w, lambda o, acc: linear_wgrad(g, a, o, acc, **rs)[0]) if need_w else None
-    if need_b and rowscale is not None:
-        raise ops.MasterHipError("a row-scaled bias gradient without its weight gradient is not built")
-    db = sg.deliver(token, bias, lambda o, acc: colsum(g, o, acc)) if need_b else None
+    db = None
+    if need_b:
+        # a bias that trains while its weight is frozen: the rare case without a weight-gradient GEMM to ride in - scale a copy of g
+        gb = rowscale_add(g, None, rowscale, rowscale.numel(), rows_per_scale) if rowscale is not None else g
+        db = sg.deliver(token, bias, lambda o, acc: colsum(gb, o, acc))
     return dw, db
 
 
