@@ -25,7 +25,7 @@ import torch  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}     # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "x3": 2500.0 / 3}     # dense MFMA peaks, MI355X_MICROARCH.md; x3: three bf16 MFMAs per product
 BF16_REL_L2_BOUND = 2.5e-2                          # bf16 mode vs the fp32 CPU oracle (measured 1.7e-2); the run fails above it
 HBM_PEAK_GBS = 8000.0
 
@@ -43,7 +43,7 @@ def build_model(device, dtype, window=7):
         if n.startswith("swin_encoder") and n.endswith("bias"):
             torch.nn.init.trunc_normal_(p, std=0.02)
     m = m.to(device).eval()
-    m.set_compute_dtype(torch.float32 if dtype == "fp32" else torch.bfloat16)
+    m.set_compute_dtype({"fp32": torch.float32, "bf16": torch.bfloat16, "x3": "bf16x3"}[dtype])
     return m
 
 
@@ -65,8 +65,9 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--layers", type=int, default=1, help="transformer_layer_count k")
     ap.add_argument("--window", type=int, default=7, help="StyleTransformer window (7 = BASELINE.json; 8 = the reference constructor's default)")
-    ap.add_argument("--dtype", choices=["fp32", "bf16"], default=os.environ.get("MASTER_BENCH_DTYPE", "bf16"),
-                    help="bf16 = BASELINE.json's configuration (bf16 MFMA, fp32 accumulate); fp32 = exact-fp32 parity mode")
+    ap.add_argument("--dtype", choices=["fp32", "bf16", "x3"], default=os.environ.get("MASTER_BENCH_DTYPE", "bf16"),
+                    help="bf16 = BASELINE.json's configuration (bf16 MFMA, fp32 accumulate); fp32 = exact-fp32 parity mode; "
+                         "x3 = fast parity mode (fp32 storage, three bf16 MFMAs per product on split operands)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / parity / cpu_baseline legs")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = the headline metric; train = BASELINE config 4: inner-loop train step bs=8 256x256 (fp32 mode), steps/s")

@@ -40,7 +40,15 @@ enum master_status {
     MASTER_ERR_LAUNCH = -3       /* hipLaunch reported an error */
 };
 
-enum master_dtype { MASTER_F32 = 0, MASTER_BF16 = 1 };
+enum master_dtype {
+    MASTER_F32 = 0, MASTER_BF16 = 1,
+    /* fp32 storage, contractions as three bf16 MFMAs per product on split operands (x = hi + lo, a*w = a_lo*w_hi + a_hi*w_lo +
+     * a_hi*w_hi, fp32 accumulation): the parity-grade FAST mode - 1.2e-4 max-abs on the stylized image against the fp32 CPU path
+     * (bar 1e-3) at 5.3x the matrix-core rate of the exact-fp32 form.  Accepted by master_linear_fwd and
+     * master_conv3x3_reflect_fwd; activations, bias, residuals and outputs are fp32 exactly as with MASTER_F32, the WEIGHT operand
+     * must have gone through master_split_weights.  Every other kernel of this mode runs with MASTER_F32. */
+    MASTER_F32X3 = 2
+};
 /* OR-ed into the `dtype` argument of master_linear_wgrad / master_colsum / master_layernorm_bwd: the parameter gradient is ADDED to
  * the output buffer (dw and dbias / out / dgb) instead of overwriting it - the gradient of a tensor used several times in one graph (the k
  * StyleTransformer layers share their weights, style_transformer.py:1239) is summed by the kernel's own slab reduce instead of by one
@@ -57,10 +65,19 @@ const char* master_last_error_string(void);
  *   :390-397,:865-882,:1125 (residual adds), :1123 (Query*sigma+mu via r1=Query, r2=mu).
  * Because a Linear acts per token, the projections run on the un-padded, un-rolled token matrix;
  * padding/roll/window partition are index math inside master_window_attn_fwd.
- * lda/ldo/ldr are row strides in elements (r1 and r2 share ldr).  K % 32 == 0. */
+ * lda/ldo/ldr are row strides in elements (r1 and r2 share ldr).  K % 32 == 0.
+ * dtype = MASTER_F32X3: a, r1, r2, out fp32, w = master_split_weights(fp32 weight); lda % 4 == 0. */
 int master_linear_fwd(const void* a, const void* w, const void* bias, const void* r1, const void* r2,
                       void* out, int M, int N, int K, int lda, int ldo, int ldr, int act, int dtype,
                       master_stream_t stream);
+
+/* Weight preparation of the MASTER_F32X3 mode: w fp32 [rows, K] (K % 32 == 0; a conv weight as [Cout, 9*Cin]) -> out, the same number
+ * of bytes: per row and 32-wide k chunk 32 bf16 hi = bf16(w) followed by 32 bf16 lo = bf16(w - hi) (round to nearest even) - the
+ * 128-byte row segments the GEMM's LDS-DMA pieces copy.  Done once per weight (the host mirror caches it per parameter version).
+ * layout 0: k in natural order (master_linear_fwd, master_conv3x3_reflect_fwd, w1 of master_mlp_fwd).  layout 1: inside every group of
+ * 16 k the order 0-3, 8-11, 4-7, 12-15 - the order in which a packed 32x32 MFMA accumulator tile presents its rows as an operand; w2 of
+ * master_mlp_fwd (MASTER_F32X3) must be in this layout, so that the GELU'd hidden tile feeds the second product without a lane exchange. */
+int master_split_weights(const float* w, void* out, size_t rows, size_t K, int layout, master_stream_t stream);
 
 /* master_linear_fwd with the block's LayerNorm folded in:  out = r1 (.) (LayerNorm(x) . w^T + bias) + r2, one launch
  * (norm1 + the fused qkv projection of a Swin / StyleSwinTransformerBlock: style_transformer.py:390, :114-116).
@@ -74,8 +91,9 @@ int master_linear_ln_fwd(const void* x, const float* ln_gamma, const float* ln_b
  * activations stay in registers.  x, res, out: [M,C] token matrices (row strides ldx/ldr/ldo); w1 [HID,C],
  * w2 [C,HID] as nn.Linear stores them; b1, b2, ln_gamma, ln_beta fp32; ln_gamma == NULL skips the LayerNorm;
  * res == NULL skips the residual.  Replaces torchvision MLP + residual (+ the preceding norm2):
- * style_transformer.py:366,:392,:839-841,:865-882,:991,:1125.  MASTER_BF16 only, C in {128,256}, HID % 128 == 0
- * (MASTER_ERR_UNSUPPORTED otherwise: callers then use two master_linear_fwd calls). */
+ * style_transformer.py:366,:392,:839-841,:865-882,:991,:1125.  MASTER_BF16: C in {128,256}, HID % 128 == 0.  MASTER_F32X3: x, res, out
+ * fp32, w1 = master_split_weights(W1, layout 0), w2 = master_split_weights(W2, layout 1), exact-erf GELU, C in {128,256}, HID % 64 == 0.
+ * (MASTER_ERR_UNSUPPORTED otherwise, and for MASTER_F32: callers then use two master_linear_fwd calls). */
 int master_mlp_fwd(const void* x, const float* ln_gamma, const float* ln_beta, const void* w1, const float* b1,
                    const void* w2, const float* b2, const void* res, void* out, int M, int C, int HID, int ldx,
                    int ldr, int ldo, float eps, int dtype, master_stream_t stream);
@@ -85,7 +103,7 @@ int master_mlp_fwd(const void* x, const float* ln_gamma, const float* ln_beta, c
  * .permute(0,2,3,1)); out is NHWC [B,Hout,Wout,Cout] or, with out_nchw, NCHW [B,Cout,Hout,Wout]
  * (always fp32 when out_nchw: it is the model output), Hout = Hin << upsample.
  * Replaces nn.Upsample + nn.Conv2d(padding_mode='reflect') + nn.ReLU, decoder.py:23-55.
- * Cin % 32 == 0. */
+ * Cin % 32 == 0.  dtype = MASTER_F32X3: x and out fp32, w = master_split_weights of the [Cout, 9*Cin] matrix. */
 int master_conv3x3_reflect_fwd(const void* x, const void* w, const void* bias, void* out, int B, int Hin,
                                int Win, int Cin, int Cout, int upsample, int relu, int out_nchw, int dtype,
                                master_stream_t stream);

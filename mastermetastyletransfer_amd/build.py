@@ -25,10 +25,15 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 # two fused MLP kernels (they need the AGPR half of the register file: +5 % slower, or spills) nor linear_ts (neutral).
 VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 EXTRA_FLAGS = {f: VGPR_FORM for f in (
-    "attn_block_bf16.hip", "conv_ring_bf16.hip", "conv_tail_bf16.hip", "gemm_bf16.hip", "gemm_f32.hip", "gemm_f32_t.hip",
+    "attn_block_bf16.hip", "conv_ring_bf16.hip", "conv_tail_bf16.hip", "gemm_bf16.hip", "gemm_f32.hip", "gemm_f32_t.hip", "gemm_x3.hip",
     "window_attn_f32.hip", "window_attn_bwd_f32.hip", "window_attn_bf16.hip", "patch_embed_bf16.hip",
     # one wave per SIMD with 490 live registers (Wproj rows + bias fragments resident): with AGPR accumulators hipcc spills 53 of them
     "window_attn_proj_bf16.hip")}
+# gemm_x3.hip MUST be built with VGPR accumulators (r04): with AGPR accumulators hipcc copies the 16 accumulator registers of the 128x32 tile
+# out to VGPRs and back around the divergent tap arithmetic of the convolution gather in every k chunk, and the first five copies
+# (a11..a15) came back wrong in a fraction of the workgroups of the 32 -> 32 convolution at 256^2 (nondeterministic output, found by
+# profiles/tools/x3_determinism.py, now tests/test_gpu_x3.py::test_x3_kernels_repeatable_at_scale); the VGPR form has no such copies
+# and is bit-repeatable.
 # The two fp32 GEMM files are scheduled by the compiler (no hand-placed sched_barriers): its max-ILP strategy is worth 0.4-1.2 % on the
 # fp32 mode and the train step; on the whole library it costs the bf16 step 5 % (the hand-scheduled kernels), so only here.
 for _f in ("gemm_f32.hip", "gemm_f32_t.hip"):

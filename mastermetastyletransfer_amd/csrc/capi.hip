@@ -101,6 +101,12 @@ int postprocess_launch(const float*, uint8_t*, int, int, int, hipStream_t);
 int mlp_c128_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const float*,
                   const bf16_t*, bf16_t*, int, int, int, int, int, int, float, hipStream_t);
 
+int gemm_x3_split_weights(const float*, void*, size_t, size_t, int, hipStream_t);
+int mlp_x3(const float*, const float*, const float*, const void*, const float*, const void*, const float*, const float*, float*, int, int, int, int, int, int,
+           float, hipStream_t);
+int gemm_x3_linear(const float*, const void*, const float*, const float*, const float*, float*, int, int, int, int, int, int, int, hipStream_t);
+int gemm_x3_conv3x3(const float*, const void*, const float*, float*, int, int, int, int, int, int, int, int, hipStream_t, int zero_pad);
+
 // ---- error string -------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 void master_set_error(const char* fmt, ...) {
@@ -508,10 +514,13 @@ int master_linear_fwd(const void* a, const void* w, const void* bias, const void
     REQUIRE(M > 0 && N > 0 && K > 0 && K % 32 == 0, "linear: need M,N>0 and K%%32==0 (M=%d N=%d K=%d)", M, N, K);
     REQUIRE(lda >= K && ldo >= N && ((r1 == nullptr && r2 == nullptr) || ldr >= N), "linear: bad leading dims");
     REQUIRE(act >= MASTER_ACT_NONE && act <= MASTER_ACT_RELU, "linear: bad act %d", act);
-    const int ea = dtype == MASTER_F32 ? 4 : 8;   // elements per 16 B
+    const int ea = dtype == MASTER_BF16 ? 8 : 4;   // elements per 16 B
     REQUIRE(al16(a) && al16(w) && lda % ea == 0, "linear: a/w must be 16-byte aligned, lda%%%d==0", ea);
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_LINEAR, s);
+    if (dtype == MASTER_F32X3)
+        return gemm_x3_linear((const float*)a, w, (const float*)bias, (const float*)r1, (const float*)r2, (float*)out, M, N, K, lda, ldo,
+                              ldr, act, s);
     if (dtype == MASTER_F32)
         return gemm_f32_linear((const float*)a, (const float*)w, (const float*)bias, (const float*)r1,
                                (const float*)r2, (float*)out, M, N, K, lda, ldo, ldr, act, s);
@@ -527,6 +536,13 @@ int master_linear_fwd(const void* a, const void* w, const void* bias, const void
     }
     master_set_error("linear: bad dtype %d", dtype);
     return MASTER_ERR_INVALID;
+}
+
+int master_split_weights(const float* w, void* out, size_t rows, size_t K, int layout, master_stream_t stream) {
+    REQUIRE(w && out && rows > 0 && K > 0 && K % 32 == 0, "split_weights: need K%%32==0 (rows=%zu K=%zu)", rows, K);
+    REQUIRE(layout == 0 || layout == 1, "split_weights: layout 0 (plain) or 1 (accumulator k order)");
+    REQUIRE(al16(w) && al16(out), "split_weights: 16-byte alignment");
+    return gemm_x3_split_weights(w, out, rows, K, layout, (hipStream_t)stream);
 }
 
 int master_linear_ln_fwd(const void* x, const float* ln_gamma, const float* ln_beta, const void* w, const void* bias,
@@ -605,7 +621,14 @@ int master_mlp_fwd(const void* x, const float* ln_gamma, const float* ln_beta, c
     REQUIRE(x && w1 && b1 && w2 && b2 && out, "mlp: null operand");
     REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), "mlp: ln_gamma and ln_beta come together");
     REQUIRE(M > 0 && C > 0 && HID > 0 && ldx >= C && ldo >= C && (res == nullptr || ldr >= C), "mlp: bad dims");
-    if (dtype != MASTER_BF16) { master_set_error("mlp: fused kernel is bf16-only; use two master_linear_fwd calls in fp32 mode"); return MASTER_ERR_UNSUPPORTED; }
+    if (dtype == MASTER_F32X3) {
+        REQUIRE(al16(x) && al16(w1) && al16(w2) && al16(out) && (!res || al16(res)) && ldx % 4 == 0 && ldo % 4 == 0 && ldr % 4 == 0,
+                "mlp(x3): alignment (x/w/res/out 16 B, ldx, ldo, ldr %% 4)");
+        hipStream_t s3 = (hipStream_t)stream;
+        ProfScope ps3(MASTER_K_MLP, s3);
+        return mlp_x3((const float*)x, ln_gamma, ln_beta, w1, b1, w2, b2, (const float*)res, (float*)out, M, C, HID, ldx, ldr, ldo, eps, s3);
+    }
+    if (dtype != MASTER_BF16) { master_set_error("mlp: fused kernel is bf16 / f32x3 only; use two master_linear_fwd calls in fp32 mode"); return MASTER_ERR_UNSUPPORTED; }
     REQUIRE(al16(x) && al16(w1) && al16(w2) && ldx % 8 == 0 && ldo % 4 == 0 && ldr % 4 == 0, "mlp: alignment (x/w 16 B, ldx%%8, ldo%%4, ldr%%4)");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_MLP, s);
@@ -631,6 +654,8 @@ int master_conv3x3_reflect_fwd(const void* x, const void* w, const void* bias, v
     REQUIRE(al16(x) && al16(w), "conv3x3: x/w must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_CONV, s);
+    if (dtype == MASTER_F32X3)
+        return gemm_x3_conv3x3((const float*)x, w, (const float*)bias, (float*)out, B, Hin, Win, Cin, Cout, upsample, relu, out_nchw, s, 0);
     if (dtype == MASTER_F32)
         return gemm_f32_conv3x3((const float*)x, (const float*)w, (const float*)bias, (float*)out, B, Hin, Win, Cin,
                                 Cout, upsample, relu, out_nchw, s);

@@ -1,0 +1,407 @@
+// Split-bf16 ("bf16x3") GEMM family: the parity-grade fast mode (MASTER_F32X3).
+//
+//   out[M,N] = r1 (.) act(A[M,K] . W[N,K]^T + bias) + r2          A, r1, r2, out: fp32 in HBM;  W: pre-split weights
+//
+// Every fp32 operand x is written as x = hi + lo + O(2^-17 |x|) with hi = bf16(x), lo = bf16(x - hi), and a product a*w is
+// evaluated as  a_lo*w_hi + a_hi*w_lo + a_hi*w_hi  on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: three matrix-core
+// instructions of 32 clocks where the exact-fp32 form (v_mfma_f32_32x32x2_f32) needs eight of 64, i.e. 833 TFLOP/s of peak
+// instead of 157; the dropped lo*lo term and the two residuals are ~2^-16 relative per product (measured end to end:
+// 1.2e-4 max-abs on the stylized image against the fp32 CPU path, bar 1e-3 - profiles/r04_x3_numerics_sim.txt).
+//
+//   * W arrives PRE-SPLIT (master_split_weights, once per weight): per row and 32-wide k chunk 64 B of hi then 64 B of lo =
+//     the 128-byte row segment of the fp32 kernel (gemm_f32.hip), so the weight tile reaches LDS by the same LDS-DMA pieces
+//     (8 rows x 128 B, source-swizzled 16-byte units: unit u of row R lands at position u ^ ((R >> 1) & 7)).
+//   * A stays fp32 in HBM (norms, attention and residual adds read it as such).  A thread loads 8 consecutive floats of a row
+//     (two global_load_dwordx4, issued two chunks ahead), splits them in registers (v_cvt_pk_bf16_f32, shift / mask, subtract,
+//     v_cvt_pk_bf16_f32: 24 VALU per 8 values, once per element and workgroup) and stores the hi and lo units into the same
+//     swizzled 128-byte row image (two ds_write_b128).
+//   * 3-slot ring, ONE s_barrier per chunk, counted vmcnt: at step kt a wave waits for the pieces of chunk kt (chunk kt+1's stay
+//     in flight), the barrier publishes W(kt) and everybody's A(kt) stores, chunk kt+2 is requested, the 6 MFMAs per
+//     (32x32 tile, chunk) run from slot kt % 3, and A(kt+1) is split into slot (kt+1) % 3.
+//   * k order: MFMA k-step s (of 2), lane half h takes unit 2s + h of the hi half and unit 4 + 2s + h of the lo half, for A and W
+//     alike, so the permutation cancels.
+//   * epilogue: the row form of gemm_f32.hip (accumulators through the idle ring, whole 16-byte row pieces out).
+// CONV: implicit GEMM of the decoder's 3x3 reflect-pad (+ nearest x2 upsample) convolutions (decoder.py:24-54): the A gather moves
+// its source pixel when the TAP changes.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct X3Args {
+    const float* a; const float* w; const float* bias; const float* r1; const float* r2; float* out;      // w: split weights, addressed in 4-byte units
+    int M, N, K, lda, ldo, ldr, act;
+    int Hin, Win, Cin, Hout, Wout, up, out_nchw, zero_pad;
+};
+
+__device__ __attribute__((aligned(16))) float g_zero_row_x3[512];          // never written: zero-initialised by the loader
+
+__device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+template <int V> struct template_int { static constexpr int value = V; };
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// 8 fp32 -> 8 bf16 hi + 8 bf16 lo (round-to-nearest-even both times; x - hi is exact in fp32)
+__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const unsigned p = pack_bf16x2(x0[2 * j], x0[2 * j + 1]);
+        hi[j] = p;
+        lo[j] = pack_bf16x2(x0[2 * j] - __uint_as_float(p << 16), x0[2 * j + 1] - __uint_as_float(p & 0xffff0000u));
+        const unsigned q = pack_bf16x2(x1[2 * j], x1[2 * j + 1]);
+        hi[2 + j] = q;
+        lo[2 + j] = pack_bf16x2(x1[2 * j] - __uint_as_float(q << 16), x1[2 * j + 1] - __uint_as_float(q & 0xffff0000u));
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool CONV>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3_kernel(X3Args p) {
+    constexpr int NWN = BN / WN;
+    constexpr int NWAVES = (BM / WM) * NWN;
+    constexpr int NT = NWAVES * 64;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int RP = NT / 4;                                            // A rows staged per pass (4 threads per 128-byte row)
+    constexpr int APASS = BM / RP;
+    constexpr int WPIECES = BN / 8;                                       // 1-KB LDS-DMA pieces of the weight tile per chunk
+    constexpr int WPW = (WPIECES + NWAVES - 1) / NWAVES;
+    constexpr int PER = 2 * APASS + WPW;                                  // vector-memory operations a (DMA-issuing) wave starts per chunk
+    constexpr int NSTAGE = 3;
+    constexpr int STAGE = (BM + BN) * 128;                                // bytes per ring slot: A rows (hi | lo), then W rows
+    static_assert(BM % RP == 0 && APASS >= 1, "A rows must divide over the threads");
+    static_assert(WPIECES % WPW == 0, "weight pieces must divide over the issuing waves");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave / NWN) * WM, wn = (wave % NWN) * WN;
+    const int r = lane & 31, h = lane >> 5;
+    static_assert(WPIECES >= NWAVES, "every wave issues WPW weight pieces per chunk");
+
+    const int MT = (p.M + BM - 1) / BM, NTN = (p.N + BN - 1) / BN;
+    const int id = blockIdx.x;
+    const int j8 = id >> 3;
+    const int mt = (j8 / NTN) * 8 + (id & 7), nt = j8 % NTN;           // XCD-aware order: the N tiles of an M tile share id % 8
+    if (mt >= MT) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int nk = p.K / BK;
+
+    // ---- A staging: thread = (row arow + i * RP, 8-float unit k8) ------------------------------------------------------------------
+    const int arow = tid >> 2, k8 = tid & 3;
+    const float* a_src[APASS];
+    int cy[CONV ? APASS : 1], cx[CONV ? APASS : 1], cimg[CONV ? APASS : 1];
+    int a_dst[APASS];                                                    // byte offset of the thread's hi unit inside a slot
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+        const int row = arow + i * RP;
+        a_dst[i] = row * 128 + ((k8 ^ ((row >> 1) & 7)) << 4);            // lo unit: same row, position (4 + k8) ^ sw = hi position ^ 4
+        int m = m0 + row; m = m < p.M ? m : p.M - 1;
+        if (CONV) {
+            const int hw = p.Hout * p.Wout;
+            const int b = m / hw, pix = m - b * hw;
+            cy[i] = pix / p.Wout; cx[i] = pix - cy[i] * p.Wout; cimg[i] = b * p.Hin * p.Win;
+            a_src[i] = p.a;
+        } else {
+            a_src[i] = p.a + (size_t)m * p.lda + k8 * 8;
+        }
+    }
+    auto set_tap = [&](int tap) __attribute__((always_inline)) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const int Hs = p.Hin << p.up, Ws = p.Win << p.up;
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            const int yy = cy[i] + dy, xx = cx[i] + dx;
+            const int sy = reflect1(yy, Hs) >> p.up, sx = reflect1(xx, Ws) >> p.up;
+            const bool outside = p.zero_pad && ((unsigned)yy >= (unsigned)Hs || (unsigned)xx >= (unsigned)Ws);
+            a_src[i] = outside ? (const float*)g_zero_row_x3 + k8 * 8
+                               : p.a + ((size_t)(cimg[i] + sy * p.Win + sx)) * p.Cin + k8 * 8;
+        }
+    };
+    int i_tap = 0, i_c0 = 0;
+    if (CONV) set_tap(0);
+    // The A loads are inline asm: hipcc's own wait insertion answers a register load that is consumed two loop iterations later (across
+    // the back edge, next to LDS-DMA it cannot count) with s_waitcnt vmcnt(0) in front of the NEXT group of loads, which serialises the
+    // pipeline.  Written this way the vector-memory queue holds exactly the operations of this source in program order, and the waits
+    // below are counted by hand: wait_regs<N>() leaves the N youngest operations in flight and ties the destination registers to the wait.
+    auto load_a = [&](int kt, f32x4 (&ra)[APASS][2]) __attribute__((always_inline)) {
+        // chunks past the end re-read the last one (the pipeline below requests two chunks ahead in EVERY step, so that the number of
+        // operations in flight is the same in every step and each wait is one instruction with a constant count)
+        const int ka = CONV ? i_c0 : (kt < nk ? kt : nk - 1) * BK;
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            const float* src = a_src[i] + ka;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[i][0]) : "v"(src) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(ra[i][1]) : "v"(src) : "memory");
+        }
+        if (CONV && !(i_tap == 8 && i_c0 == p.Cin - BK)) {
+            i_c0 += BK;
+            if (i_c0 == p.Cin) { i_c0 = 0; ++i_tap; set_tap(i_tap); }
+        }
+    };
+    auto store_a = [&](int slot_i, const f32x4 (&ra)[APASS][2]) __attribute__((always_inline)) {
+        unsigned char* slot = ring + slot_i * STAGE;
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            u32x4 hi, lo;
+            split8(ra[i][0], ra[i][1], hi, lo);
+            *(u32x4*)(slot + a_dst[i]) = hi;
+            *(u32x4*)(slot + (a_dst[i] ^ 64)) = lo;
+        }
+    };
+
+    // ---- W pieces by LDS-DMA: piece j of this wave = tile rows (wave * WPW + j) * 8 + (lane >> 3), LDS unit position lane & 7 ----------
+    const int prow = lane >> 3, ppos = lane & 7;
+    const float* w_src[WPW];
+#pragma unroll
+    for (int j = 0; j < WPW; ++j) {
+        const int row = (wave * WPW + j) * 8 + prow;
+        int n = n0 + row; n = n < p.N ? n : p.N - 1;
+        w_src[j] = p.w + (size_t)n * p.K + (ppos ^ ((row >> 1) & 7)) * 4;
+    }
+    auto issue_w = [&](int kt, int slot_i) __attribute__((always_inline)) {
+        unsigned char* slot = ring + slot_i * STAGE + BM * 128;
+        const int kw = (kt < nk ? kt : nk - 1) * BK;
+#pragma unroll
+        for (int j = 0; j < WPW; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j] + kw),
+                                             (__attribute__((address_space(3))) void*)(slot + (wave * WPW + j) * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.0f;
+
+    const int fsw = (r >> 1) & 7;
+
+    auto compute = [&](int slot) __attribute__((always_inline)) {
+        const unsigned char* ab = ring + slot * STAGE + (wm + r) * 128;
+        const unsigned char* wb = ring + slot * STAGE + BM * 128 + (wn + r) * 128;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int ohi = ((2 * s + h) ^ fsw) << 4, olo = ohi ^ 64;
+            bf16x8_t ah[TM], al[TM], wh[TN], wl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *(const bf16x8_t*)(ab + i * 32 * 128 + ohi);
+                al[i] = *(const bf16x8_t*)(ab + i * 32 * 128 + olo);
+            }
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+                wh[jn] = *(const bf16x8_t*)(wb + jn * 32 * 128 + ohi);
+                wl[jn] = *(const bf16x8_t*)(wb + jn * 32 * 128 + olo);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) {
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], wh[jn], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wl[jn], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wh[jn], acc[i][jn], 0, 0, 0);
+                }
+        }
+    };
+
+    // wait until all but the N youngest vector-memory operations of this wave are done; the A registers are in/out operands so that
+    // nothing that reads them can be scheduled above the wait (ONE such statement per use: two alternatives behind a branch make
+    // hipcc copy the still-loading registers in front of the wait)
+    auto wait_regs = [&](f32x4 (&ra)[APASS][2]) __attribute__((always_inline)) {
+        constexpr int WCNT = PER + WPW;
+        if constexpr (APASS == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ra[0][0]), "+v"(ra[0][1]) : "n"(WCNT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]) : "n"(WCNT) : "memory");
+    };
+    static_assert(APASS == 1 || APASS == 2, "wait_regs covers one or two A passes");
+
+    // queue order: [A(0)] [W(0)] [A(1)] [W(1)] | step kt: [A(kt+2)] [W(kt+2)] - 2 APASS loads and WPW pieces per chunk
+    f32x4 ra0[APASS][2], ra1[APASS][2];
+    load_a(0, ra0); issue_w(0, 0);
+    load_a(1, ra1); issue_w(1, 1);
+    wait_regs(ra0);                                                        // A(0): W(0) and the group of chunk 1 stay in flight
+    store_a(0, ra0);
+
+    int s_cur = 0, s_nxt = 1, s_nn = 2;                                    // ring slots of chunks kt, kt + 1, kt + 2
+    auto body = [&](int kt, f32x4 (&nxt)[APASS][2], f32x4 (&fre)[APASS][2]) __attribute__((always_inline)) {
+        wait_vmcnt<PER>();                                                 // W(kt) has landed: only the group of chunk kt + 1 is still in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // this wave's A(kt) stores
+        __builtin_amdgcn_s_barrier();
+        load_a(kt + 2, fre); issue_w(kt + 2, s_nn);
+        compute(s_cur);
+        wait_regs(nxt);                                                    // A(kt + 1): W(kt + 1) and the group of chunk kt + 2 stay in flight
+        store_a(s_nxt, nxt);
+        asm volatile("" ::: "memory");
+        const int t = s_cur; s_cur = s_nxt; s_nxt = s_nn; s_nn = t;
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        body(kt, ra1, ra0);
+        if (kt + 1 < nk) body(kt + 1, ra0, ra1);
+    }
+    // the two look-ahead groups past the end and this wave's last (look-ahead) A stores must have landed before the barrier below lets
+    // other waves write the output tile over the ring (a store still in flight would land on top of it)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+    // ---- epilogue (the row form of gemm_f32.hip) ---------------------------------------------------------------------------------------
+    const bool vec_ok = (p.N & 3) == 0 && !(CONV && p.out_nchw) && (p.ldo & 3) == 0 && (((uintptr_t)p.out) & 15) == 0 &&
+                        (!p.bias || (((uintptr_t)p.bias) & 15) == 0) &&
+                        ((!p.r1 && !p.r2) || ((p.ldr & 3) == 0 && ((((uintptr_t)p.r1) | ((uintptr_t)p.r2)) & 15) == 0));
+    if (vec_ok) {
+        constexpr int VPR = BN / 4;                                       // float4 pieces per tile row
+        constexpr int PIECES = BM * VPR / NT;
+        static_assert((BM * VPR) % NT == 0, "row pieces must divide over the threads");
+        static_assert(BM * BN * 4 <= NSTAGE * STAGE, "the output tile must fit in the ring");
+        float* tile = (float*)ring;
+        __builtin_amdgcn_s_barrier();                                      // every wave has left the main loop: the ring is free
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    tile[(wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * BN + wn + jn * 32 + r] = acc[i][jn][e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int c4 = tid % VPR, row0 = tid / VPR;
+        int n = n0 + c4 * 4;
+        const bool n_ok = n < p.N;
+        n = n_ok ? n : p.N - 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *(const f32x4*)(p.bias + n);
+        constexpr int BATCH = PIECES < 4 ? PIECES : 4;
+#pragma unroll
+        for (int b0 = 0; b0 < PIECES; b0 += BATCH) {
+            f32x4 v[BATCH], a1[BATCH], a2[BATCH];
+            size_t orow[BATCH];
+            bool ok[BATCH];
+#pragma unroll
+            for (int it = 0; it < BATCH; ++it) {
+                const int row = row0 + (b0 + it) * (NT / VPR);
+                int m = m0 + row;
+                ok[it] = n_ok && m < p.M;
+                m = m < p.M ? m : p.M - 1;
+                orow[it] = (size_t)m;
+                v[it] = *(const f32x4*)(tile + row * BN + c4 * 4);
+                if (p.r1) a1[it] = *(const f32x4*)(p.r1 + (size_t)m * p.ldr + n);
+                if (p.r2) a2[it] = *(const f32x4*)(p.r2 + (size_t)m * p.ldr + n);
+            }
+#pragma unroll
+            for (int it = 0; it < BATCH; ++it) {
+                f32x4 x = v[it] + bv;
+                if (p.act == MASTER_ACT_GELU) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[c] = gelu_erf(x[c]);
+                } else if (p.act == MASTER_ACT_RELU) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[c] = fmaxf(x[c], 0.0f);
+                }
+                if (p.r1) x *= a1[it];
+                if (p.r2) x += a2[it];
+                if (ok[it]) *(f32x4*)(p.out + orow[it] * p.ldo + n) = x;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
+    const int hw_out = p.Hout * p.Wout;
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int n = n0 + wn + jn * 32 + r;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m >= p.M) continue;
+                float v = acc[i][jn][e] + bv;
+                if (p.act == MASTER_ACT_GELU) v = gelu_erf(v);
+                else if (p.act == MASTER_ACT_RELU) v = fmaxf(v, 0.0f);
+                if (p.r1) v *= p.r1[(size_t)m * p.ldr + n];
+                if (p.r2) v += p.r2[(size_t)m * p.ldr + n];
+                if (CONV && p.out_nchw) {
+                    const int b = m / hw_out, pix = m - b * hw_out;
+                    p.out[((size_t)b * p.N + n) * hw_out + pix] = v;
+                } else {
+                    p.out[(size_t)m * p.ldo + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool CONV>
+int launch(const X3Args& p, hipStream_t s) {
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    const int MT = (p.M + BM - 1) / BM, NTN = (p.N + BN - 1) / BN;
+    const int grid = ((MT + 7) / 8) * 8 * NTN;
+    const size_t lds = (size_t)3 * (BM + BN) * 128;
+    static LdsLimit lds_limit;
+    lds_limit.ensure((const void*)gemm_x3_kernel<BM, BN, WM, WN, CONV>, (int)lds);
+    hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, WM, WN, CONV>), dim3(grid), dim3(NT), lds, s, p);
+    return master_check_launch("gemm_x3");
+}
+
+// MASTER_X3_TILE: 0 = by shape (default), 1 = 128x128 / 4 waves, 2 = 128x128 / 8 waves, 3 = 256x128 / 8 waves (A/B runs)
+static int x3_tile() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MASTER_X3_TILE"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
+template <bool CONV>
+int dispatch(const X3Args& p, hipStream_t s) {
+    const int force = x3_tile();
+    if (p.N > 64) {
+        if (force == 1) return launch<128, 128, 64, 64, CONV>(p, s);
+        if (force == 2) return launch<128, 128, 32, 64, CONV>(p, s);
+        if (force == 3) return launch<256, 128, 64, 64, CONV>(p, s);
+        // fewer than two 256-row tiles per CU: 128-row tiles (eight waves: two per SIMD) fill the chip better
+        const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 127) / 128);
+        if (t256 < 512) return launch<128, 128, 32, 64, CONV>(p, s);
+        return launch<256, 128, 64, 64, CONV>(p, s);
+    }
+    if (p.N > 32 || force == 4) return launch<256, 64, 64, 32, CONV>(p, s);
+    return launch<128, 32, 32, 32, CONV>(p, s);
+}
+
+// ---- weight split: fp32 [rows, K] -> per row and 32-wide chunk: 32 bf16 hi, 32 bf16 lo (same byte size and row stride as the fp32 matrix) ----
+// layout 1 (the second Linear of the fused MLP, mlp_x3.hip): inside every group of 16 k the order is 0-3, 8-11, 4-7, 12-15 - the k order
+// of a packed 32x32 accumulator tile used as an MFMA operand (lane half h holds rows 4h + 0..3 and 8 + 4h + 0..3 of each group).
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, unsigned* __restrict__ out, size_t n8, int layout) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;            // one 8-element unit of the OUTPUT per thread
+    if (i >= n8) return;
+    const size_t chunk = i >> 2, u = i & 3;                               // 4 units per 32-wide chunk
+    const float* src = layout == 1 ? w + chunk * 32 + (u >> 1) * 16 + (u & 1) * 4 : w + i * 8;
+    const f32x4 x0 = *(const f32x4*)src, x1 = *(const f32x4*)(src + (layout == 1 ? 8 : 4));
+    u32x4 hi, lo;
+    split8(x0, x1, hi, lo);
+    *(u32x4*)(out + chunk * 32 + u * 4) = hi;
+    *(u32x4*)(out + chunk * 32 + 16 + u * 4) = lo;
+}
+
+}  // namespace
+
+int gemm_x3_split_weights(const float* w, void* out, size_t rows, size_t K, int layout, hipStream_t s) {
+    const size_t n8 = rows * K / 8;
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, w, (unsigned*)out, n8, layout);
+    return master_check_launch("split_weights");
+}
+
+int gemm_x3_linear(const float* a, const void* w, const float* bias, const float* r1, const float* r2, float* out,
+                   int M, int N, int K, int lda, int ldo, int ldr, int act, hipStream_t s) {
+    X3Args p{a, (const float*)w, bias, r1, r2, out, M, N, K, lda, ldo, ldr, act, 0, 0, 0, 1, 1, 0, 0, 0};
+    return dispatch<false>(p, s);
+}
+
+int gemm_x3_conv3x3(const float* x, const void* w, const float* bias, float* out, int B, int Hin, int Win, int Cin,
+                    int Cout, int up, int relu, int out_nchw, hipStream_t s, int zero_pad) {
+    const int Hout = Hin << up, Wout = Win << up;
+    X3Args p{x, (const float*)w, bias, nullptr, nullptr, out, B * Hout * Wout, Cout, 9 * Cin, 0, Cout, 0,
+             relu ? MASTER_ACT_RELU : MASTER_ACT_NONE, Hin, Win, Cin, Hout, Wout, up, out_nchw, zero_pad};
+    return dispatch<true>(p, s);
+}

@@ -82,7 +82,9 @@ class GraphedTrainStep:
 
     Inputs must keep one shape; the optimizer must be FusedAdam(capturable=True) (its step count and learning rate live in device
     memory; a changed `param_groups[i]["lr"]` is pushed before the next replay).  Gradients are in `param.grad` after a call, as after
-    an eager step."""
+    an eager step: every captured k owns its gradient buffers (they live in that graph's memory pool), and a replay re-binds
+    `param.grad` to the buffers the replayed graph just wrote - so gradient clipping, logging or a data-parallel all-reduce between two
+    calls read THIS step's gradients whichever k ran before."""
 
     def __init__(self, model, loss_fn, optimizer, capture: bool = True):
         from .optim import FusedAdam
@@ -90,7 +92,7 @@ class GraphedTrainStep:
             raise ValueError("GraphedTrainStep needs FusedAdam(capturable=True)")
         self.model, self.loss_fn, self.opt, self.capture = model, loss_fn, optimizer, bool(capture)
         self.content = self.style = None
-        self.graphs, self.totals, self.seen = {}, {}, {}
+        self.graphs, self.totals, self.seen, self.grads = {}, {}, {}, {}
         self._params = [p for g in optimizer.param_groups for p in g["params"]]
 
     def _eager(self, k: int) -> Tensor:
@@ -114,12 +116,17 @@ class GraphedTrainStep:
             total = self._eager(k).detach()
             self.seen[k] = self.seen.get(k, 0) + 1
             if self.capture and self.seen[k] >= 1:
-                self._capture(k)
+                eager_grads = [(p_, p_.grad) for p_ in self._params]
+                self._capture(k)                          # leaves param.grad on the graph's (not yet written) buffers
+                for p_, g_ in eager_grads:                # this call's gradients are the eager step's
+                    p_.grad = g_
             return total
         self.opt.push_hypers()
         g.replay()
         from .optim import _mark_written
         _mark_written(self._params)                       # the replay wrote the parameters behind torch's back
+        for p_, g_ in self.grads[k]:                      # ... and THIS graph's gradient buffers: param.grad may still point at another k's
+            p_.grad = g_
         return self.totals[k]
 
     def _capture(self, k: int) -> None:
@@ -130,3 +137,4 @@ class GraphedTrainStep:
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             total = self._eager(k)
         self.graphs[k], self.totals[k] = g, total.detach()
+        self.grads[k] = [(p_, p_.grad) for p_ in self._params]

@@ -150,14 +150,24 @@ class MasterStyleTransferModel(nn.Module):
             decoder_exclude_MLP_after_Fcs_self_MHA=self.style_decoder_exclude_MLP_after_Fcs_self_MHA)
         self.style_transformer.load_state_dict(sd)
 
-    def set_compute_dtype(self, dtype: torch.dtype) -> "MasterStyleTransferModel":
-        """torch.float32: exact-fp32 matrix cores, parity mode.  torch.bfloat16: bf16 MFMA, throughput mode."""
+    def set_compute_dtype(self, dtype, split_bf16: bool = False) -> "MasterStyleTransferModel":
+        """torch.float32: exact-fp32 matrix cores, parity mode.  torch.bfloat16: bf16 MFMA, throughput mode.
+        torch.float32 with split_bf16=True (or the string "bf16x3"): the FAST parity mode - fp32 storage, norms, softmax and epilogues
+        as in the fp32 mode, every Linear / convolution as three bf16 MFMAs per product on operands split into bf16 hi + lo
+        (csrc/gemm_x3.hip); meets the 1e-3 max-abs bar of the fp32 mode (measured 1.2e-4) at several times its throughput.
+        Inference only."""
+        if dtype == "bf16x3":
+            dtype, split_bf16 = torch.float32, True
         if dtype not in (torch.float32, torch.bfloat16):
-            raise ValueError("compute_dtype must be torch.float32 or torch.bfloat16")
+            raise ValueError("compute_dtype must be torch.float32, torch.bfloat16 or \"bf16x3\"")
+        if split_bf16 and dtype != torch.float32:
+            raise ValueError("split_bf16 is a form of the fp32 mode: set_compute_dtype(torch.float32, split_bf16=True)")
         self.compute_dtype = dtype
+        self.split_weights = bool(split_bf16)
         for m in self.modules():
             if isinstance(m, (_HipModule, SwinEncoder)):
                 m.compute_dtype = dtype
+                m.split_weights = bool(split_bf16)
         # swin_T / swin_S: stage 1 is 96 channels wide and the bf16 GEMMs step K in 64s, so the patch embedding, the two stage-1 blocks
         # and the patch merging stay in fp32 (SwinEncoder.run converts once, after the merge); stage 2, the StyleTransformer and the
         # decoder (192 / 768 / 384 wide) run on the generic bf16 kernels - the fused ones are specialised for swin_B's 128 / 256.

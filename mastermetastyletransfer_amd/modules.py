@@ -40,18 +40,19 @@ def _train_mode(m: nn.Module) -> bool:
     kernels only), whatever torch.is_grad_enabled() says: set the stochastic-depth probabilities to 0 to train without the masks."""
     if not m.training:
         return False
-    if getattr(m, "compute_dtype", torch.float32) != torch.float32:
-        raise NotImplementedError("the train step runs in the fp32 mode: call set_compute_dtype(torch.float32) before .train()")
+    if getattr(m, "compute_dtype", torch.float32) != torch.float32 or getattr(m, "split_weights", False):
+        raise NotImplementedError("the train step runs in the exact-fp32 mode: call set_compute_dtype(torch.float32) before .train()")
     return True
 
 
 class _HipModule(nn.Module):
     """nn.Module with a cache of tensors derived from parameters (fused / repacked / bf16 copies)."""
     compute_dtype = torch.float32
+    split_weights = False          # True: the split-bf16 fast parity mode (ops.F32X3) - fp32 activations, GEMM / conv weights as bf16 hi + lo
 
     def _derived(self, name: str, srcs: Sequence[Tensor], build: Callable[[], Tensor]) -> Tensor:
         cache = self.__dict__.setdefault("_derived_cache", {})
-        key = tuple((s.data_ptr(), s._version, s.dtype, str(s.device)) for s in srcs) + (self.compute_dtype,)
+        key = tuple((s.data_ptr(), s._version, s.dtype, str(s.device)) for s in srcs) + (self.compute_dtype, self.split_weights)
         hit = cache.get(name)
         if hit is None or hit[0] != key:
             with torch.no_grad():
@@ -63,6 +64,8 @@ class _HipModule(nn.Module):
         """weight(s) concatenated along dim 0, contiguous, in the compute dtype"""
         def build():
             w = params[0] if len(params) == 1 else torch.cat(list(params), dim=0)
+            if self.split_weights:
+                return ops.split_weights(w)
             return ops.convert(w.detach().contiguous(), self.compute_dtype)
         return self._derived("w:" + name, params, build)
 
@@ -107,14 +110,18 @@ def _mlp_fwd(owner: _HipModule, name: str, mlp: nn.Sequential, x: Tensor, residu
     bf16 mode: one fused launch (hidden activations stay in registers, LayerNorm folded in);
     fp32 mode: LayerNorm, GEMM+GELU, GEMM+residual."""
     w1, b1 = owner._w(name + ".0", mlp[0].weight), owner._b(name + ".0", mlp[0].bias)
-    w2, b2 = owner._w(name + ".3", mlp[3].weight), owner._b(name + ".3", mlp[3].bias)
+    b2 = owner._b(name + ".3", mlp[3].bias)
     g = owner._b(name + ".ln_w", norm.weight) if norm is not None else None
     b = owner._b(name + ".ln_b", norm.bias) if norm is not None else None
-    if ops.mlp_fused_supported(x, w1.shape[0]):
+    if ops.mlp_fused_supported(x, w1.shape[0], owner.split_weights):
+        # split mode: the fused kernel reads W2 in the k order of a packed accumulator tile (ops.split_weights layout 1)
+        w2f = owner._derived("w:" + name + ".3:acc_k", [mlp[3].weight], lambda: ops.split_weights(mlp[3].weight, layout=1)) \
+            if owner.split_weights else owner._w(name + ".3", mlp[3].weight)
         try:
-            return ops.mlp(x, w1, b1, w2, b2, res=residual, ln_gamma=g, ln_beta=b, eps=norm.eps if norm is not None else EPS)
+            return ops.mlp(x, w1, b1, w2f, b2, res=residual, ln_gamma=g, ln_beta=b, eps=norm.eps if norm is not None else EPS)
         except NotImplementedError:
             pass          # MASTER_ERR_UNSUPPORTED (e.g. a hidden width whose bias vectors do not fit next to the weight ring): unfused path
+    w2 = owner._w(name + ".3", mlp[3].weight)
     if norm is not None:
         x = ops.layernorm(x, g, b, norm.eps)
     h = ops.linear(x, w1, b1, act=ops.ACT_GELU)
@@ -682,6 +689,8 @@ class Decoder(_HipModule):
                 w = conv.weight.detach()
                 if (co, ci) != tuple(w.shape[:2]):
                     w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, ci - w.shape[1], 0, co - w.shape[0]))
+                if self.split_weights and co > 4:          # the 3-channel last layer runs on the direct fp32 kernel in both fp32 modes
+                    return ops.split_weights(w.permute(0, 2, 3, 1).contiguous())
                 return ops.convert(w.permute(0, 2, 3, 1).contiguous(), self.compute_dtype)
             return self._derived(f"conv{i}", [conv.weight], build)
 

@@ -15,13 +15,13 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MASTER_HIP_LIB") or os.path.join(_HERE, "csrc", "libmaster_hip.so")   # override: A/B runs of two builds
 
-F32, BF16 = 0, 1
+F32, BF16, F32X3 = 0, 1, 2        # F32X3: fp32 activations, weights pre-split into bf16 hi/lo (split_weights), 3 bf16 MFMAs per product
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 K_FAMILIES = ("linear", "conv3x3", "window_attn", "layernorm", "instnorm", "patch_embed", "patch_merge", "convert", "mlp", "decoder_tail", "attn_block",
               "conv_dgrad", "conv_wgrad", "linear_bwd", "window_attn_bwd", "train_misc")
 
 EXPORTS = (
-    "master_version", "master_last_error_string", "master_linear_fwd", "master_conv3x3_reflect_fwd",
+    "master_version", "master_last_error_string", "master_split_weights", "master_linear_fwd", "master_conv3x3_reflect_fwd",
     "master_window_attn_fwd", "master_layernorm_fwd", "master_instnorm_fwd", "master_patch_embed_fwd",
     "master_patch_merge_ln_fwd", "master_patch_merge_linear_fwd", "master_resize_plan", "master_preprocess_fwd", "master_postprocess_fwd", "master_image_to_nhwc_fwd", "master_vgg_conv1_fwd", "master_conv3x3_zero_fwd", "master_maxpool2x2_fwd", "master_channel_stats_fwd", "master_stats_slices", "master_instnorm_distance_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_linear_ln_fwd", "master_attn_block_fwd", "master_window_attn_proj_fwd", "master_linear_group_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
     # train step
@@ -78,6 +78,7 @@ def load_library() -> ctypes.CDLL:
     lib.master_last_error_string.restype = ctypes.c_char_p
     vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
     lib.master_linear_fwd.argtypes = [vp] * 6 + [ci] * 8 + [vp]
+    lib.master_split_weights.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_size_t, ci, vp]
     lib.master_conv3x3_reflect_fwd.argtypes = [vp] * 4 + [ci] * 9 + [vp]
     lib.master_window_attn_fwd.argtypes = [vp] * 4 + [ci] * 3 + [vp] * 3 + [ci] * 2 + [vp] * 3 + [vp] * 2 + [ci] * 6 + [cf, ci, vp]
     lib.master_layernorm_fwd.argtypes = [vp] * 4 + [ci, ci, cf, ci, vp]
@@ -205,6 +206,27 @@ def _dev(*ts):
             raise MasterHipError("the stylization path runs on the GPU only (got a CPU tensor); there is no CPU fallback")
 
 
+def is_split(w: torch.Tensor) -> bool:
+    """True for a weight in the split-bf16 layout of the F32X3 mode: [rows, K/32, 2, 32] bf16 (split_weights)"""
+    return w.dtype == torch.bfloat16 and w.dim() == 4 and w.shape[2] == 2 and w.shape[3] == 32
+
+
+@_on_device
+def split_weights(w: torch.Tensor, layout: int = 0) -> torch.Tensor:
+    """fp32 [rows, K] (or a packed conv weight [Cout,3,3,Cin], flattened) -> bf16 [rows, K/32, 2, 32]: per 32-wide k chunk the 32 bf16
+    hi = bf16(w) then the 32 bf16 lo = bf16(w - hi) - what master_linear_fwd / master_conv3x3_reflect_fwd take as `w` with MASTER_F32X3.
+    layout=1: k order 0-3, 8-11, 4-7, 12-15 inside every group of 16 (the second Linear of the fused MLP, master_mlp_fwd)"""
+    _dev(w)
+    w = w.detach().float().contiguous()
+    rows = w.shape[0]
+    K = w.numel() // rows
+    if K % 32:
+        raise MasterHipError(f"split_weights: K = {K} is not a multiple of 32")
+    out = torch.empty((rows, K // 32, 2, 32), dtype=torch.bfloat16, device=w.device)
+    _check(load_library().master_split_weights(_p(w), _p(out), rows, K, layout, _stream()), "master_split_weights")
+    return out
+
+
 @_on_device
 def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, r1: Optional[torch.Tensor] = None,
            r2: Optional[torch.Tensor] = None, act: int = ACT_NONE, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -212,7 +234,8 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     _dev(a, w)
     M, K = a.shape
     N = w.shape[0]
-    assert w.shape[1] == K and a.stride(1) == 1 and w.is_contiguous()
+    x3 = is_split(w)
+    assert (w.shape[1] * 32 == K and a.dtype == torch.float32 if x3 else w.shape[1] == K) and a.stride(1) == 1 and w.is_contiguous()
     if out is None:
         out = torch.empty((M, N), dtype=a.dtype, device=a.device)
     ldr = 0
@@ -229,7 +252,7 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         _count("linear", flops=2.0 * M * N * K,
                bytes=es * (M * K + N * K + M * N * (1 + (r1 is not None) + (r2 is not None))))
     _check(load_library().master_linear_fwd(_p(a), _p(w), _p(bias), _p(r1), _p(r2), _p(out), M, N, K, a.stride(0),
-                                             out.stride(0), ldr, act, _dt(a), _stream()), "master_linear_fwd")
+                                             out.stride(0), ldr, act, F32X3 if x3 else _dt(a), _stream()), "master_linear_fwd")
     return out
 
 
@@ -275,18 +298,23 @@ def linear_group(xs: Sequence[torch.Tensor], ws: Sequence[torch.Tensor], biases:
     return outs
 
 
-def mlp_fused_supported(x: torch.Tensor, hidden: int) -> bool:
+def mlp_fused_supported(x: torch.Tensor, hidden: int, split: bool = False) -> bool:
+    if split:          # F32X3: fp32 tokens, split weights (mlp_x3.hip); MASTER_MLP_X3=0 falls back to two GEMM launches (A/B runs)
+        return x.dtype == torch.float32 and x.shape[1] in (128, 256) and hidden % 64 == 0 and os.environ.get("MASTER_MLP_X3", "1") != "0"
     return x.dtype == torch.bfloat16 and x.shape[1] in (128, 256) and hidden % 128 == 0
 
 
 @_on_device
 def mlp(x: torch.Tensor, w1, b1, w2, b2, res: Optional[torch.Tensor] = None, ln_gamma=None, ln_beta=None,
         eps: float = 1e-5) -> torch.Tensor:
-    """res + fc2(gelu(fc1(LN?(x)))) in one launch (bf16 mode)."""
+    """res + fc2(gelu(fc1(LN?(x)))) in one launch (bf16 mode; F32X3 mode with w1 = split_weights(W1), w2 = split_weights(W2, layout=1))."""
     _dev(x, w1, w2)
     M, C = x.shape
     HID = w1.shape[0]
-    assert x.stride(1) == 1 and w1.is_contiguous() and w2.is_contiguous() and w1.shape == (HID, C) and w2.shape == (C, HID)
+    x3 = is_split(w1)
+    assert x.stride(1) == 1 and w1.is_contiguous() and w2.is_contiguous()
+    assert (is_split(w2) and w1.shape[1] * 32 == C and w2.shape[:2] == (C, HID // 32) and x.dtype == torch.float32) if x3 else \
+        (w1.shape == (HID, C) and w2.shape == (C, HID))
     assert b1.dtype == torch.float32 and b2.dtype == torch.float32
     out = torch.empty((M, C), dtype=x.dtype, device=x.device)
     if _COUNT_ON:
@@ -295,7 +323,7 @@ def mlp(x: torch.Tensor, w1, b1, w2, b2, res: Optional[torch.Tensor] = None, ln_
         _count("mlp", flops=4.0 * M * C * HID, bytes=x.element_size() * (M * C * (2 + extra_res) + 2 * C * HID))
     _check(load_library().master_mlp_fwd(_p(x), _p(ln_gamma), _p(ln_beta), _p(w1), _p(b1), _p(w2), _p(b2), _p(res), _p(out),
                                           M, C, HID, x.stride(0), res.stride(0) if res is not None else 0, out.stride(0),
-                                          eps, _dt(x), _stream()), "master_mlp_fwd")
+                                          eps, F32X3 if x3 else _dt(x), _stream()), "master_mlp_fwd")
     return out
 
 
@@ -306,7 +334,9 @@ def conv3x3_reflect(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor,
     _dev(x, w_packed)
     B, H, W, Cin = x.shape
     Cout = w_packed.shape[0]
+    x3 = is_split(w_packed)
     assert x.is_contiguous() and w_packed.is_contiguous() and bias.dtype == torch.float32
+    assert not x3 or (x.dtype == torch.float32 and w_packed.shape[1] * 32 == 9 * Cin)
     Ho, Wo = (H * 2, W * 2) if upsample else (H, W)
     if out_nchw:
         out = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
@@ -316,7 +346,7 @@ def conv3x3_reflect(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor,
         _count("conv3x3", flops=2.0 * B * Ho * Wo * Cout * 9 * Cin,
                bytes=x.element_size() * (x.numel() + w_packed.numel()) + out.element_size() * out.numel())
     _check(load_library().master_conv3x3_reflect_fwd(_p(x), _p(w_packed), _p(bias), _p(out), B, H, W, Cin, Cout,
-                                                      int(upsample), int(relu), int(out_nchw), _dt(x), _stream()),
+                                                      int(upsample), int(relu), int(out_nchw), F32X3 if x3 else _dt(x), _stream()),
            "master_conv3x3_reflect_fwd")
     return out
 

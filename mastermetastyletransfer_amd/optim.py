@@ -125,7 +125,20 @@ class FusedAdam(torch.optim.Optimizer):
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
+        # a captured graph (GraphedTrainStep) holds the ADDRESSES of the moment buffers: torch's load_state_dict replaces the tensors, and
+        # the graph would go on updating the old ones.  With capturable=True the loaded values are therefore copied INTO the existing
+        # buffers (same shape and device), which stay the optimizer's state.
+        old = {p: (st.get("exp_avg"), st.get("exp_avg_sq")) for p, st in self.state.items()} if self.capturable else {}
         super().load_state_dict(state_dict)
+        for p_, (m_old, v_old) in old.items():
+            st = self.state.get(p_)
+            if not st:
+                continue
+            for name, keep in (("exp_avg", m_old), ("exp_avg_sq", v_old)):
+                new = st.get(name)
+                if keep is not None and new is not None and keep is not new and keep.shape == new.shape and keep.device == new.device:
+                    keep.copy_(new)
+                    st[name] = keep
         for gi, group in enumerate(self.param_groups):
             d = self._dev.get(gi)
             steps = {int(self.state[p]["step"]) for p in group["params"] if self.state.get(p)}

@@ -1,13 +1,15 @@
 """fp32 (exact-fp32 MFMA) GEMM / implicit-GEMM convolution rates on the shapes of the parity mode (bs=32 forward), BASELINE config 5 and the
 train step (config 4).  Run on the GPU box; select the kernel with MASTER_GEMM_F32=reg|dma (read once per process).
-usage: python profiles/tools/gemm_f32_shapes.py [check]"""
+usage: python profiles/tools/gemm_f32_shapes.py [check] [x3]      x3: the split-bf16 kernels (gemm_x3.hip; MASTER_X3_TILE=1..3 forces a tile)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from mastermetastyletransfer_amd import ops
 
 dev = torch.device("cuda:0")
-check = len(sys.argv) > 1 and sys.argv[1] == "check"
+check = "check" in sys.argv[1:]
+X3 = "x3" in sys.argv[1:]
+prep = (lambda w: ops.split_weights(w)) if X3 else (lambda w: w)
 
 
 def timeit(fn, reps=10):
@@ -23,7 +25,7 @@ def timeit(fn, reps=10):
 
 
 print(f"variant MASTER_GEMM_F32={os.environ.get('MASTER_GEMM_F32', '(default dma)')} SMALL={os.environ.get('MASTER_GEMM_F32_SMALL', '(default 1)')}")
-print("--- linear fp32: M N K act res | us | TFLOP/s")
+print(f"--- linear {'x3 (MASTER_X3_TILE=' + os.environ.get('MASTER_X3_TILE', '0') + ')' if X3 else 'fp32'}: M N K act res | us | TFLOP/s")
 tot_f = tot_t = 0.0
 for M, N, K, act, res in [(262144, 384, 128, 0, 0), (262144, 128, 128, 0, 1), (262144, 512, 128, 1, 0), (262144, 128, 512, 0, 1),
                           (65536, 256, 512, 0, 0), (65536, 768, 256, 0, 0), (65536, 256, 256, 0, 1), (65536, 1024, 256, 1, 0), (65536, 256, 1024, 0, 1),
@@ -32,7 +34,8 @@ for M, N, K, act, res in [(262144, 384, 128, 0, 0), (262144, 128, 128, 0, 1), (2
     a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) / K ** 0.5
     b = torch.randn(N, device=dev); r = torch.randn(M, N, device=dev) if res else None
     out = torch.empty(M, N, device=dev)
-    us = timeit(lambda: ops.linear(a, w, b, r2=r, act=act, out=out))
+    wk = prep(w)
+    us = timeit(lambda: ops.linear(a, wk, b, r2=r, act=act, out=out))
     tot_f += 2.0 * M * N * K; tot_t += us
     line = f"{M:7d} {N:5d} {K:5d} {act} {res} | {us:8.1f} | {2.0*M*N*K/us/1e6:8.1f}"
     if check and M <= 65536:
@@ -54,10 +57,13 @@ for B, H, Cin, Cout, up, zero in convs:
     x = torch.randn(B, H, H, Cin, device=dev); w = torch.randn(Cout, 3, 3, Cin, device=dev) / (3 * Cin ** .5)
     b = torch.randn(Cout, device=dev)
     Ho = H * 2 if up else H
+    if X3 and (zero or Cout == 3):
+        continue
+    wk = prep(w)
     if zero:
         fn = lambda: ops.conv3x3_zero(x, w, b, relu=True)
     else:
-        fn = lambda: ops.conv3x3_reflect(x, w, b, bool(up), True, out_nchw=(Cout == 3))
+        fn = lambda: ops.conv3x3_reflect(x, wk, b, bool(up), True, out_nchw=(Cout == 3))
     us = timeit(fn, reps=5)
     fl = 2.0 * B * Ho * Ho * Cout * 9 * Cin
     tot_f += fl; tot_t += us

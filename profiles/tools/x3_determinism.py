@@ -1,0 +1,46 @@
+"""Bitwise repeatability of every split-bf16 (F32X3) kernel at the sizes of the bs = 32 forward: each op runs REPS times on the same inputs
+under load (no host sync between launches) and all outputs must be identical.  A race between LDS-DMA / ds_write / ds_read phases of a
+kernel shows up here long before it shows up in a tolerance test.  usage: python profiles/tools/x3_determinism.py [reps]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from mastermetastyletransfer_amd import ops
+
+dev = torch.device("cuda:0")
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 6
+bad = 0
+
+
+def check(name, fn):
+    global bad
+    outs = [fn() for _ in range(REPS)]
+    torch.cuda.synchronize()
+    n = sum(0 if torch.equal(outs[0], o) else 1 for o in outs[1:])
+    if n:
+        d = max(float((outs[0] - o).abs().max()) for o in outs[1:])
+        cnt = max(int((outs[0] != o).sum()) for o in outs[1:])
+        bad += 1
+        print(f"NONDETERMINISTIC {name}: {n} of {REPS - 1} repeats differ, max |d| {d:.3e}, up to {cnt} elements", flush=True)
+    else:
+        print(f"ok {name}", flush=True)
+
+
+g = torch.Generator(device="cpu").manual_seed(0)
+for M, N, K, act, res in [(262144, 384, 128, 0, 0), (262144, 128, 128, 0, 1), (65536, 256, 512, 0, 0), (65536, 768, 256, 0, 0), (65536, 256, 256, 0, 1),
+                          (32768, 768, 256, 0, 0), (32768, 512, 256, 0, 0), (32768, 256, 256, 0, 1), (32768, 1024, 256, 1, 0), (32768, 256, 1024, 0, 1)]:
+    a = torch.randn(M, K, device=dev); w = ops.split_weights(torch.randn(N, K, device=dev) / K ** 0.5)
+    b = torch.randn(N, device=dev); r = torch.randn(M, N, device=dev) if res else None
+    check(f"linear {M}x{N}x{K} act{act} res{res}", lambda: ops.linear(a, w, b, r2=r, act=act))
+for B, H, Cin, Cout, up in [(32, 32, 256, 128, 0), (32, 32, 128, 128, 1), (32, 64, 128, 128, 0), (32, 64, 128, 64, 0), (32, 64, 64, 64, 1), (32, 128, 64, 32, 0),
+                            (32, 128, 32, 32, 1)]:
+    x = torch.randn(B, H, H, Cin, device=dev); w = ops.split_weights(torch.randn(Cout, 3, 3, Cin, device=dev) / (3 * Cin ** .5))
+    b = torch.randn(Cout, device=dev)
+    check(f"conv {B}x{H}x{H} {Cin}->{Cout} up{up}", lambda: ops.conv3x3_reflect(x, w, b, bool(up), True))
+for M, C, ln in [(32768, 256, 0), (32768, 256, 1), (65536, 256, 1), (262144, 128, 1), (262144, 128, 0)]:
+    x = torch.randn(M, C, device=dev)
+    w1 = ops.split_weights(torch.randn(4 * C, C, device=dev) / C ** 0.5); w2 = ops.split_weights(torch.randn(C, 4 * C, device=dev) / (4 * C) ** 0.5, layout=1)
+    b1 = torch.randn(4 * C, device=dev) * 0.1; b2 = torch.randn(C, device=dev) * 0.1
+    lg = torch.ones(C, device=dev) if ln else None; lb = torch.zeros(C, device=dev) if ln else None
+    check(f"mlp M={M} C={C} ln{ln}", lambda: ops.mlp(x, w1, b1, w2, b2, res=x, ln_gamma=lg, ln_beta=lb))
+print("FAILED" if bad else "all repeatable")
+sys.exit(1 if bad else 0)

@@ -497,7 +497,18 @@ def test_graphed_train_step_matches_the_eager_step(cuda):
         out = m1(c, s_, k); t1 = l1(c, s_, out); o1.zero_grad(); t1.backward(); o1.step()
         t2 = step2(c, s_, k)
         assert abs(float(t2) - float(t1)) <= 1e-4 * abs(float(t1)), (i, k, float(t1), float(t2))
+        # param.grad after the call is THIS step's gradient, whichever k was captured or replayed last (each captured k owns its
+        # gradient buffers; a replay re-binds param.grad to them)
+        for (n, p1), (_, p2) in zip(m1.decoder.named_parameters(), m2.decoder.named_parameters()):
+            if n in ("decoder.0.weight", "decoder.19.bias"):
+                check(f"grad {n} after step {i} (k={k})", p2.grad, p1.grad, 2e-2)
+        g1, g2 = m1.style_transformer.decoder.last_MLP[3].weight.grad, m2.style_transformer.decoder.last_MLP[3].weight.grad
+        check(f"grad last_MLP.3.weight after step {i} (k={k})", g2, g1, 2e-2)
     assert set(step2.graphs) == {1, 2}                             # both layer counts were captured and replayed
+    # loading an optimizer state after the captures keeps the moment buffers the graphs write to (values copied in place)
+    addr = {p: o2.state[p]["exp_avg"].data_ptr() for g_ in o2.param_groups for p in g_["params"] if o2.state.get(p)}
+    o2.load_state_dict(o2.state_dict())
+    assert all(o2.state[p]["exp_avg"].data_ptr() == a for p, a in addr.items())
     for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         if p1.requires_grad:
             check(n, p2, p1, 2e-4)
