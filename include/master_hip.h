@@ -53,7 +53,15 @@ enum master_dtype {
  * the output buffer (dw and dbias / out / dgb) instead of overwriting it - the gradient of a tensor used several times in one graph (the k
  * StyleTransformer layers share their weights, style_transformer.py:1239) is summed by the kernel's own slab reduce instead of by one
  * autograd add launch per use.  Needs the workspace (at least one output-sized slab). */
-enum master_flags { MASTER_ACCUMULATE = 0x100 };
+enum master_flags {
+    MASTER_ACCUMULATE = 0x100,
+    /* OR-ed into MASTER_F32X3 for master_linear_fwd / master_conv3x3_reflect_fwd: the activation operand (a / x) is already in the SPLIT
+     * layout - per row (token / pixel) and 32-wide channel chunk 32 bf16 hi | 32 bf16 lo, the layout master_split_weights produces, the
+     * same bytes and row stride as the fp32 matrix - and / or the OUTPUT is written in it (N, ldo % 32 == 0; NHWC).  A chain of
+     * convolutions (decoder.py:24-54) then hands its maps on in the form the next layer's LDS-DMA pieces copy: no split arithmetic and
+     * no LDS stores in the consumer's loop.  hi + lo reproduces the fp32 value to 2^-17 relative. */
+    MASTER_A_SPLIT = 0x200, MASTER_OUT_SPLIT = 0x400
+};
 enum master_act { MASTER_ACT_NONE = 0, MASTER_ACT_GELU = 1 /* exact erf */, MASTER_ACT_RELU = 2 };
 
 int master_version(void);

@@ -104,8 +104,10 @@ int mlp_c128_bf16(const bf16_t*, const float*, const float*, const bf16_t*, cons
 int gemm_x3_split_weights(const float*, void*, size_t, size_t, int, hipStream_t);
 int mlp_x3(const float*, const float*, const float*, const void*, const float*, const void*, const float*, const float*, float*, int, int, int, int, int, int,
            float, hipStream_t);
-int gemm_x3_linear(const float*, const void*, const float*, const float*, const float*, float*, int, int, int, int, int, int, int, hipStream_t);
-int gemm_x3_conv3x3(const float*, const void*, const float*, float*, int, int, int, int, int, int, int, int, hipStream_t, int zero_pad);
+int gemm_x3_linear(const float*, const void*, const float*, const float*, const float*, float*, int, int, int, int, int, int, int, hipStream_t,
+                   int a_split, int out_split);
+int gemm_x3_conv3x3(const float*, const void*, const float*, float*, int, int, int, int, int, int, int, int, hipStream_t, int zero_pad, int a_split,
+                    int out_split);
 
 // ---- error string -------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -514,13 +516,18 @@ int master_linear_fwd(const void* a, const void* w, const void* bias, const void
     REQUIRE(M > 0 && N > 0 && K > 0 && K % 32 == 0, "linear: need M,N>0 and K%%32==0 (M=%d N=%d K=%d)", M, N, K);
     REQUIRE(lda >= K && ldo >= N && ((r1 == nullptr && r2 == nullptr) || ldr >= N), "linear: bad leading dims");
     REQUIRE(act >= MASTER_ACT_NONE && act <= MASTER_ACT_RELU, "linear: bad act %d", act);
+    const int io = dtype & (MASTER_A_SPLIT | MASTER_OUT_SPLIT);
+    dtype &= ~(MASTER_A_SPLIT | MASTER_OUT_SPLIT);
+    REQUIRE(io == 0 || dtype == MASTER_F32X3, "linear: MASTER_A_SPLIT / MASTER_OUT_SPLIT go with MASTER_F32X3");
+    REQUIRE(!(io & MASTER_A_SPLIT) || lda % 32 == 0, "linear: a split A operand has whole 32-wide chunks per row (lda %% 32 == 0)");
+    REQUIRE(!(io & MASTER_OUT_SPLIT) || (N % 32 == 0 && ldo % 32 == 0 && al16(out)), "linear: a split output needs N, ldo %% 32 == 0");
     const int ea = dtype == MASTER_BF16 ? 8 : 4;   // elements per 16 B
     REQUIRE(al16(a) && al16(w) && lda % ea == 0, "linear: a/w must be 16-byte aligned, lda%%%d==0", ea);
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_LINEAR, s);
     if (dtype == MASTER_F32X3)
         return gemm_x3_linear((const float*)a, w, (const float*)bias, (const float*)r1, (const float*)r2, (float*)out, M, N, K, lda, ldo,
-                              ldr, act, s);
+                              ldr, act, s, (io & MASTER_A_SPLIT) != 0, (io & MASTER_OUT_SPLIT) != 0);
     if (dtype == MASTER_F32)
         return gemm_f32_linear((const float*)a, (const float*)w, (const float*)bias, (const float*)r1,
                                (const float*)r2, (float*)out, M, N, K, lda, ldo, ldr, act, s);
@@ -652,10 +659,15 @@ int master_conv3x3_reflect_fwd(const void* x, const void* w, const void* bias, v
     REQUIRE(upsample == 0 || upsample == 1, "conv3x3: upsample must be 0/1");
     REQUIRE((Hin << upsample) >= 2 && (Win << upsample) >= 2, "conv3x3: reflect pad needs H,W >= 2");
     REQUIRE(al16(x) && al16(w), "conv3x3: x/w must be 16-byte aligned");
+    const int io = dtype & (MASTER_A_SPLIT | MASTER_OUT_SPLIT);
+    dtype &= ~(MASTER_A_SPLIT | MASTER_OUT_SPLIT);
+    REQUIRE(io == 0 || dtype == MASTER_F32X3, "conv3x3: MASTER_A_SPLIT / MASTER_OUT_SPLIT go with MASTER_F32X3");
+    REQUIRE(!(io & MASTER_OUT_SPLIT) || (Cout % 32 == 0 && !out_nchw && al16(out)), "conv3x3: a split output is NHWC with Cout %% 32 == 0");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_CONV, s);
     if (dtype == MASTER_F32X3)
-        return gemm_x3_conv3x3((const float*)x, w, (const float*)bias, (float*)out, B, Hin, Win, Cin, Cout, upsample, relu, out_nchw, s, 0);
+        return gemm_x3_conv3x3((const float*)x, w, (const float*)bias, (float*)out, B, Hin, Win, Cin, Cout, upsample, relu, out_nchw, s, 0,
+                               (io & MASTER_A_SPLIT) != 0, (io & MASTER_OUT_SPLIT) != 0);
     if (dtype == MASTER_F32)
         return gemm_f32_conv3x3((const float*)x, (const float*)w, (const float*)bias, (float*)out, B, Hin, Win, Cin,
                                 Cout, upsample, relu, out_nchw, s);

@@ -36,6 +36,7 @@ struct X3Args {
     const float* a; const float* w; const float* bias; const float* r1; const float* r2; float* out;      // w: split weights, addressed in 4-byte units
     int M, N, K, lda, ldo, ldr, act;
     int Hin, Win, Cin, Hout, Wout, up, out_nchw, zero_pad;
+    int out_split;      // the output goes out in the split layout (per row and 32-wide chunk 32 bf16 hi | 32 bf16 lo: what the next GEMM's A operand takes by LDS-DMA); N % 32 == 0
 };
 
 __device__ __attribute__((aligned(16))) float g_zero_row_x3[512];          // never written: zero-initialised by the loader
@@ -54,6 +55,125 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, u32x4& 
         const unsigned q = pack_bf16x2(x1[2 * j], x1[2 * j + 1]);
         hi[2 + j] = q;
         lo[2 + j] = pack_bf16x2(x1[2 * j] - __uint_as_float(q << 16), x1[2 * j + 1] - __uint_as_float(q & 0xffff0000u));
+    }
+}
+
+#ifdef X3_CLOCK_PROBE
+#define XPROBE_MARK() do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); probe_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define XPROBE_ADD(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); probe_sec[i] += t_ - probe_last; probe_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define XPROBE_MARK() do {} while (0)
+#define XPROBE_ADD(i) do {} while (0)
+#endif
+
+// ---- epilogue shared by the two kernels: the row form of gemm_f32.hip (accumulators through the idle ring as the [BM][BN] fp32 tile, whole
+// 16-byte row pieces out: coalesced bias / r1 / r2 loads, float4 stores), or - out_split - the same pieces split into bf16 hi | lo and
+// stored in the split layout (8 + 8 bytes per piece); element-wise fallback for outputs the row form cannot address (NCHW, N % 4).
+template <int BM, int BN, int WM, int WN, bool CONV, int RING_BYTES>
+__device__ __forceinline__ void x3_epilogue(const X3Args& p, f32x16 (&acc)[WM / 32][WN / 32], unsigned char* ring, int m0, int n0, int wm, int wn) {
+    constexpr int NWN = BN / WN;
+    constexpr int NWAVES = (BM / WM) * NWN;
+    constexpr int NT = NWAVES * 64;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+    // ---- epilogue (the row form of gemm_f32.hip) ---------------------------------------------------------------------------------------
+    const bool vec_ok = (p.N & 3) == 0 && !(CONV && p.out_nchw) && (p.ldo & 3) == 0 && (((uintptr_t)p.out) & 15) == 0 &&
+                        (!p.bias || (((uintptr_t)p.bias) & 15) == 0) &&
+                        ((!p.r1 && !p.r2) || ((p.ldr & 3) == 0 && ((((uintptr_t)p.r1) | ((uintptr_t)p.r2)) & 15) == 0));
+    if (vec_ok) {
+        constexpr int VPR = BN / 4;                                       // float4 pieces per tile row
+        constexpr int PIECES = BM * VPR / NT;
+        static_assert((BM * VPR) % NT == 0, "row pieces must divide over the threads");
+        static_assert(BM * BN * 4 <= RING_BYTES, "the output tile must fit in the ring");
+        float* tile = (float*)ring;
+        __builtin_amdgcn_s_barrier();                                      // every wave has left the main loop: the ring is free
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    tile[(wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * BN + wn + jn * 32 + r] = acc[i][jn][e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int c4 = tid % VPR, row0 = tid / VPR;
+        int n = n0 + c4 * 4;
+        const bool n_ok = n < p.N;
+        n = n_ok ? n : p.N - 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *(const f32x4*)(p.bias + n);
+        constexpr int BATCH = PIECES < 4 ? PIECES : 4;
+#pragma unroll
+        for (int b0 = 0; b0 < PIECES; b0 += BATCH) {
+            f32x4 v[BATCH], a1[BATCH], a2[BATCH];
+            size_t orow[BATCH];
+            bool ok[BATCH];
+#pragma unroll
+            for (int it = 0; it < BATCH; ++it) {
+                const int row = row0 + (b0 + it) * (NT / VPR);
+                int m = m0 + row;
+                ok[it] = n_ok && m < p.M;
+                m = m < p.M ? m : p.M - 1;
+                orow[it] = (size_t)m;
+                v[it] = *(const f32x4*)(tile + row * BN + c4 * 4);
+                if (p.r1) a1[it] = *(const f32x4*)(p.r1 + (size_t)m * p.ldr + n);
+                if (p.r2) a2[it] = *(const f32x4*)(p.r2 + (size_t)m * p.ldr + n);
+            }
+#pragma unroll
+            for (int it = 0; it < BATCH; ++it) {
+                f32x4 x = v[it] + bv;
+                if (p.act == MASTER_ACT_GELU) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[c] = gelu_erf(x[c]);
+                } else if (p.act == MASTER_ACT_RELU) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[c] = fmaxf(x[c], 0.0f);
+                }
+                if (p.r1) x *= a1[it];
+                if (p.r2) x += a2[it];
+                if (p.out_split) {
+                    if (ok[it]) {
+                        const unsigned h0 = pack_bf16x2(x[0], x[1]), h1 = pack_bf16x2(x[2], x[3]);
+                        const unsigned l0 = pack_bf16x2(x[0] - __uint_as_float(h0 << 16), x[1] - __uint_as_float(h0 & 0xffff0000u));
+                        const unsigned l1 = pack_bf16x2(x[2] - __uint_as_float(h1 << 16), x[3] - __uint_as_float(h1 & 0xffff0000u));
+                        // row of N values = N / 32 chunks of 128 B; value n of the row: hi at (n >> 5) * 128 + (n & 31) * 2, lo 64 B further
+                        unsigned char* dst = (unsigned char*)(p.out + orow[it] * p.ldo) + (n >> 5) * 128 + (n & 31) * 2;
+                        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+                        *(u32x2_t*)dst = u32x2_t{h0, h1};
+                        *(u32x2_t*)(dst + 64) = u32x2_t{l0, l1};
+                    }
+                } else if (ok[it]) *(f32x4*)(p.out + orow[it] * p.ldo + n) = x;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
+    const int hw_out = p.Hout * p.Wout;
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int n = n0 + wn + jn * 32 + r;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m >= p.M) continue;
+                float v = acc[i][jn][e] + bv;
+                if (p.act == MASTER_ACT_GELU) v = gelu_erf(v);
+                else if (p.act == MASTER_ACT_RELU) v = fmaxf(v, 0.0f);
+                if (p.r1) v *= p.r1[(size_t)m * p.ldr + n];
+                if (p.r2) v += p.r2[(size_t)m * p.ldr + n];
+                if (CONV && p.out_nchw) {
+                    const int b = m / hw_out, pix = m - b * hw_out;
+                    p.out[((size_t)b * p.N + n) * hw_out + pix] = v;
+                } else {
+                    p.out[(size_t)m * p.ldo + n] = v;
+                }
+            }
+        }
     }
 }
 
@@ -81,11 +201,17 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3_kernel(X3A
     const int r = lane & 31, h = lane >> 5;
     static_assert(WPIECES >= NWAVES, "every wave issues WPW weight pieces per chunk");
 
+    // XCD-aware order (workgroup id % 8 = XCD under round-robin placement).  Linear: the N tiles of an M tile share id % 8 and are adjacent
+    // in time, so the A panel is fetched into one L2 once.  Convolution: an XCD takes a CONTIGUOUS eighth of the M tiles, in order - its 32
+    // concurrent workgroups then cover ~2 whole images whose rows (each read by 3 vertical taps of up to 3 neighbouring tiles) stay in
+    // that XCD's 4-MB L2; with consecutive tiles dealt round-robin over the XCDs every tap re-read came from the Infinity Cache at
+    // ~30 GB/s per CU (r04: the 128 -> 128 layer ran at 3 300 clocks per chunk for 1 536 of MFMA with either form of the A path).
     const int MT = (p.M + BM - 1) / BM, NTN = (p.N + BN - 1) / BN;
     const int id = blockIdx.x;
     const int j8 = id >> 3;
-    const int mt = (j8 / NTN) * 8 + (id & 7), nt = j8 % NTN;           // XCD-aware order: the N tiles of an M tile share id % 8
-    if (mt >= MT) return;
+    const int per_xcd = (MT + 7) >> 3;
+    const int mt = CONV ? (id & 7) * per_xcd + j8 / NTN : (j8 / NTN) * 8 + (id & 7), nt = j8 % NTN;
+    if (mt >= MT || (CONV && j8 / NTN >= per_xcd)) return;
     const int m0 = mt * BM, n0 = nt * BN;
     const int nk = p.K / BK;
 
@@ -226,14 +352,25 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3_kernel(X3A
     store_a(0, ra0);
 
     int s_cur = 0, s_nxt = 1, s_nn = 2;                                    // ring slots of chunks kt, kt + 1, kt + 2
+#ifdef X3_CLOCK_PROBE     // diagnostic build only (profiles/probes/gemm_x3_probe.hip): s_memtime sections of every wave 0, written to a buffer of their own
+    unsigned long long probe_sec[6] = {0, 0, 0, 0, 0, 0}, probe_last = 0;            // vmcnt wait, barrier, issue, compute, A wait, split + store
+    const unsigned long long probe_t0 = __builtin_amdgcn_s_memtime();
+#endif
     auto body = [&](int kt, f32x4 (&nxt)[APASS][2], f32x4 (&fre)[APASS][2]) __attribute__((always_inline)) {
+        XPROBE_MARK();
         wait_vmcnt<PER>();                                                 // W(kt) has landed: only the group of chunk kt + 1 is still in flight
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // this wave's A(kt) stores
+        XPROBE_ADD(0);
         __builtin_amdgcn_s_barrier();
+        XPROBE_ADD(1);
         load_a(kt + 2, fre); issue_w(kt + 2, s_nn);
+        XPROBE_ADD(2);
         compute(s_cur);
+        XPROBE_ADD(3);
         wait_regs(nxt);                                                    // A(kt + 1): W(kt + 1) and the group of chunk kt + 2 stay in flight
+        XPROBE_ADD(4);
         store_a(s_nxt, nxt);
+        XPROBE_ADD(5);
         asm volatile("" ::: "memory");
         const int t = s_cur; s_cur = s_nxt; s_nxt = s_nn; s_nn = t;
     };
@@ -244,94 +381,217 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3_kernel(X3A
     // the two look-ahead groups past the end and this wave's last (look-ahead) A stores must have landed before the barrier below lets
     // other waves write the output tile over the ring (a store still in flight would land on top of it)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef X3_CLOCK_PROBE
+    if (tid == 0 && g_probe) {
+        unsigned long long* dst = g_probe + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < 6; ++i) dst[i] = probe_sec[i];
+        dst[6] = __builtin_amdgcn_s_memtime() - probe_t0;
+    }
+#endif
 
-    // ---- epilogue (the row form of gemm_f32.hip) ---------------------------------------------------------------------------------------
-    const bool vec_ok = (p.N & 3) == 0 && !(CONV && p.out_nchw) && (p.ldo & 3) == 0 && (((uintptr_t)p.out) & 15) == 0 &&
-                        (!p.bias || (((uintptr_t)p.bias) & 15) == 0) &&
-                        ((!p.r1 && !p.r2) || ((p.ldr & 3) == 0 && ((((uintptr_t)p.r1) | ((uintptr_t)p.r2)) & 15) == 0));
-    if (vec_ok) {
-        constexpr int VPR = BN / 4;                                       // float4 pieces per tile row
-        constexpr int PIECES = BM * VPR / NT;
-        static_assert((BM * VPR) % NT == 0, "row pieces must divide over the threads");
-        static_assert(BM * BN * 4 <= NSTAGE * STAGE, "the output tile must fit in the ring");
-        float* tile = (float*)ring;
-        __builtin_amdgcn_s_barrier();                                      // every wave has left the main loop: the ring is free
+    x3_epilogue<BM, BN, WM, WN, CONV, NSTAGE * STAGE>(p, acc, ring, m0, n0, wm, wn);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same product with the A operand ALREADY in the split layout (written by the previous kernel's out_split epilogue): both tiles
+// reach LDS by LDS-DMA, nothing is staged through registers, no split arithmetic and no ds_write in the loop.  In-kernel clocks of the
+// fp32-input form (profiles/r04_gemm_x3_probe_mi355x.txt, 128 -> 128 convolution at 64^2): per chunk and wave 525 clocks to issue the
+// look-ahead (4 loads, tap arithmetic, 2 pieces), 856 to split and store 16 values per thread (the 32 ds_write_b128 of the eight waves
+// queue on the LDS store path) next to 768 of MFMA - with two waves per SIMD in lockstep the vector work, not the matrix core, bounded it.
+// Ring, k order, waits and epilogue as above; per chunk a wave issues BM / 8 / NWAVES pieces of A (8 rows x 128 B, per-lane row
+// pointers: the convolution gather moves them when the tap changes) and BN / 8 / NWAVES of W.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool CONV>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3s_kernel(X3Args p) {
+    constexpr int NWN = BN / WN;
+    constexpr int NWAVES = (BM / WM) * NWN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int APW = BM / 8 / NWAVES, WPW = BN / 8 / NWAVES;          // 1-KB pieces per wave and chunk
+    constexpr int PER = APW + WPW;
+    constexpr int NSTAGE = 3;
+    constexpr int STAGE = (BM + BN) * 128;
+    static_assert((BM / 8) % NWAVES == 0 && (BN / 8) % NWAVES == 0 && WPW >= 1, "pieces must divide over the waves");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave / NWN) * WM, wn = (wave % NWN) * WN;
+    const int r = lane & 31, h = lane >> 5;
+
+    // XCD-aware order (workgroup id % 8 = XCD under round-robin placement).  Linear: the N tiles of an M tile share id % 8 and are adjacent
+    // in time, so the A panel is fetched into one L2 once.  Convolution: an XCD takes a CONTIGUOUS eighth of the M tiles, in order - its 32
+    // concurrent workgroups then cover ~2 whole images whose rows (each read by 3 vertical taps of up to 3 neighbouring tiles) stay in
+    // that XCD's 4-MB L2; with consecutive tiles dealt round-robin over the XCDs every tap re-read came from the Infinity Cache at
+    // ~30 GB/s per CU (r04: the 128 -> 128 layer ran at 3 300 clocks per chunk for 1 536 of MFMA with either form of the A path).
+    const int MT = (p.M + BM - 1) / BM, NTN = (p.N + BN - 1) / BN;
+    const int id = blockIdx.x;
+    const int j8 = id >> 3;
+    const int per_xcd = (MT + 7) >> 3;
+    const int mt = CONV ? (id & 7) * per_xcd + j8 / NTN : (j8 / NTN) * 8 + (id & 7), nt = j8 % NTN;
+    if (mt >= MT || (CONV && j8 / NTN >= per_xcd)) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int nk = p.K / BK;
+
+    const int prow = lane >> 3, ppos = lane & 7;
+    const float* a_src[APW];
+    int cy[CONV ? APW : 1], cx[CONV ? APW : 1], cimg[CONV ? APW : 1], csw[CONV ? APW : 1];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int jn = 0; jn < TN; ++jn)
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    tile[(wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * BN + wn + jn * 32 + r] = acc[i][jn][e];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const int c4 = tid % VPR, row0 = tid / VPR;
-        int n = n0 + c4 * 4;
-        const bool n_ok = n < p.N;
-        n = n_ok ? n : p.N - 4;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bv = *(const f32x4*)(p.bias + n);
-        constexpr int BATCH = PIECES < 4 ? PIECES : 4;
-#pragma unroll
-        for (int b0 = 0; b0 < PIECES; b0 += BATCH) {
-            f32x4 v[BATCH], a1[BATCH], a2[BATCH];
-            size_t orow[BATCH];
-            bool ok[BATCH];
-#pragma unroll
-            for (int it = 0; it < BATCH; ++it) {
-                const int row = row0 + (b0 + it) * (NT / VPR);
-                int m = m0 + row;
-                ok[it] = n_ok && m < p.M;
-                m = m < p.M ? m : p.M - 1;
-                orow[it] = (size_t)m;
-                v[it] = *(const f32x4*)(tile + row * BN + c4 * 4);
-                if (p.r1) a1[it] = *(const f32x4*)(p.r1 + (size_t)m * p.ldr + n);
-                if (p.r2) a2[it] = *(const f32x4*)(p.r2 + (size_t)m * p.ldr + n);
-            }
-#pragma unroll
-            for (int it = 0; it < BATCH; ++it) {
-                f32x4 x = v[it] + bv;
-                if (p.act == MASTER_ACT_GELU) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) x[c] = gelu_erf(x[c]);
-                } else if (p.act == MASTER_ACT_RELU) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) x[c] = fmaxf(x[c], 0.0f);
-                }
-                if (p.r1) x *= a1[it];
-                if (p.r2) x += a2[it];
-                if (ok[it]) *(f32x4*)(p.out + orow[it] * p.ldo + n) = x;
-            }
-            __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j < APW; ++j) {
+        const int row = (wave * APW + j) * 8 + prow;
+        const int sw = (ppos ^ ((row >> 1) & 7)) * 4;                  // 4-byte offset of the lane's source unit within the 128-byte chunk
+        int m = m0 + row; m = m < p.M ? m : p.M - 1;
+        if (CONV) {
+            const int hw = p.Hout * p.Wout;
+            const int b = m / hw, pix = m - b * hw;
+            cy[j] = pix / p.Wout; cx[j] = pix - cy[j] * p.Wout; cimg[j] = b * p.Hin * p.Win; csw[j] = sw;
+            a_src[j] = p.a;
+        } else {
+            a_src[j] = p.a + (size_t)m * p.lda + sw;
         }
+    }
+    const float* w_src[WPW];
+#pragma unroll
+    for (int j = 0; j < WPW; ++j) {
+        const int row = (wave * WPW + j) * 8 + prow;
+        int n = n0 + row; n = n < p.N ? n : p.N - 1;
+        w_src[j] = p.w + (size_t)n * p.K + (ppos ^ ((row >> 1) & 7)) * 4;
+    }
+    auto set_tap = [&](int tap) __attribute__((always_inline)) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const int Hs = p.Hin << p.up, Ws = p.Win << p.up;
+#pragma unroll
+        for (int j = 0; j < APW; ++j) {
+            const int yy = cy[j] + dy, xx = cx[j] + dx;
+            const int sy = reflect1(yy, Hs) >> p.up, sx = reflect1(xx, Ws) >> p.up;
+            const bool outside = p.zero_pad && ((unsigned)yy >= (unsigned)Hs || (unsigned)xx >= (unsigned)Ws);
+            a_src[j] = outside ? (const float*)g_zero_row_x3 + csw[j]
+                               : p.a + ((size_t)(cimg[j] + sy * p.Win + sx)) * p.Cin + csw[j];
+        }
+    };
+    int i_tap = 0, i_c0 = 0;
+    if (CONV) set_tap(0);
+#ifdef X3_ABLATE_SAMEDATA
+#pragma unroll
+    for (int j = 0; j < APW; ++j) a_src[j] = p.a + (size_t)((wave * APW + j) * 8 + prow) * 32 + (ppos ^ ((((wave * APW + j) * 8 + prow) >> 1) & 7)) * 4;
+#endif
+    // One look-ahead chunk = APW pieces of A and WPW of W per wave.  They are NOT issued as a burst behind the barrier (every wave of the
+    // CU then sits in the memory-issue queue at the same time, ~150 clocks per piece, with the matrix cores idle - measured on the MLP
+    // kernel: 72 k of 264 k clocks) but one at a time between the MFMA groups of the chunk being computed: begin_issue() fixes the chunk's
+    // slot and k offset, piece(q) issues piece q = 0 .. PER - 1 (A pieces first), end_issue() advances the convolution's tap state.
+    unsigned char* is_slot = nullptr; int is_kc = 0, is_ka = 0;
+    auto begin_issue = [&](int kt, int slot_i) __attribute__((always_inline)) {       // chunks past the end re-read the last one (uniform vmcnt bookkeeping)
+        is_slot = ring + slot_i * STAGE;
+        is_kc = (kt < nk ? kt : nk - 1) * BK;
+        is_ka = CONV ? i_c0 : is_kc;
+#ifdef X3_ABLATE_SAMEDATA       // probe builds: every chunk of every workgroup re-reads the same 48 KB (L2-resident): what is left is the CU's own time
+        is_kc = 0; is_ka = 0;
+#endif
+    };
+    auto piece = [&](int q) __attribute__((always_inline)) {
+        if (q < APW)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[q] + is_ka),
+                                             (__attribute__((address_space(3))) void*)(is_slot + (wave * APW + q) * 1024), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[q - APW] + is_kc),
+                                             (__attribute__((address_space(3))) void*)(is_slot + BM * 128 + (wave * WPW + q - APW) * 1024), 16, 0, 0);
+    };
+    auto end_issue = [&]() __attribute__((always_inline)) {
+#ifdef X3_ABLATE_SAMEDATA
         return;
-    }
-    const int hw_out = p.Hout * p.Wout;
-#pragma unroll
-    for (int jn = 0; jn < TN; ++jn) {
-        const int n = n0 + wn + jn * 32 + r;
-        if (n >= p.N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m >= p.M) continue;
-                float v = acc[i][jn][e] + bv;
-                if (p.act == MASTER_ACT_GELU) v = gelu_erf(v);
-                else if (p.act == MASTER_ACT_RELU) v = fmaxf(v, 0.0f);
-                if (p.r1) v *= p.r1[(size_t)m * p.ldr + n];
-                if (p.r2) v += p.r2[(size_t)m * p.ldr + n];
-                if (CONV && p.out_nchw) {
-                    const int b = m / hw_out, pix = m - b * hw_out;
-                    p.out[((size_t)b * p.N + n) * hw_out + pix] = v;
-                } else {
-                    p.out[(size_t)m * p.ldo + n] = v;
-                }
-            }
+#endif
+        if (CONV && !(i_tap == 8 && i_c0 == p.Cin - BK)) {
+            i_c0 += BK;
+            if (i_c0 == p.Cin) { i_c0 = 0; ++i_tap; set_tap(i_tap); }
         }
+    };
+    auto issue = [&](int kt, int slot_i) __attribute__((always_inline)) {
+        begin_issue(kt, slot_i);
+#pragma unroll
+        for (int q = 0; q < PER; ++q) piece(q);
+        end_issue();
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.0f;
+
+    const int fsw = (r >> 1) & 7;
+    issue(0, 0); issue(1, 1);
+    int s_cur = 0, s_nxt = 1, s_nn = 2;
+    constexpr int NG = 2 * TM * TN;                                        // MFMA groups (3 MFMAs on one accumulator tile) per chunk
+#ifdef X3_CLOCK_PROBE
+    unsigned long long probe_sec[6] = {0, 0, 0, 0, 0, 0}, probe_last = 0;            // vmcnt wait, barrier, -, compute + pieces, -, -
+    const unsigned long long probe_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    for (int kt = 0; kt < nk; ++kt) {
+        XPROBE_MARK();
+        wait_vmcnt<PER>();                                                 // chunk kt has landed (this wave's pieces): only chunk kt + 1's are in flight
+        XPROBE_ADD(0);
+        __builtin_amdgcn_s_barrier();
+        XPROBE_ADD(1);
+        begin_issue(kt + 2, s_nn);
+        const unsigned char* ab = ring + s_cur * STAGE + (wm + r) * 128;
+        const unsigned char* wb = ring + s_cur * STAGE + BM * 128 + (wn + r) * 128;
+        int g = 0, q = 0;                                                  // compile-time after unrolling
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int ohi = ((2 * s + h) ^ fsw) << 4, olo = ohi ^ 64;
+            bf16x8_t ah[TM], al[TM], wh[TN], wl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *(const bf16x8_t*)(ab + i * 32 * 128 + ohi);
+                al[i] = *(const bf16x8_t*)(ab + i * 32 * 128 + olo);
+            }
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+                wh[jn] = *(const bf16x8_t*)(wb + jn * 32 * 128 + ohi);
+                wl[jn] = *(const bf16x8_t*)(wb + jn * 32 * 128 + olo);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) {
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], wh[jn], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wl[jn], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wh[jn], acc[i][jn], 0, 0, 0);
+                    // pieces due after this group: piece q goes behind group floor(q * NG / PER)
+                    ++g;
+#pragma unroll
+                    for (int z = 0; z < PER; ++z)
+                        if (q < PER && (q * NG) / PER < g) { __builtin_amdgcn_sched_barrier(0); piece(q); __builtin_amdgcn_sched_barrier(0); ++q; }
+                }
+        }
+        end_issue();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // this wave's fragment reads of slot s_cur are done before it passes the next barrier
+        XPROBE_ADD(3);
+        const int t = s_cur; s_cur = s_nxt; s_nxt = s_nn; s_nn = t;
     }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");            // the two look-ahead groups past the end: the ring is reused below
+#ifdef X3_CLOCK_PROBE
+    if (tid == 0 && g_probe) {
+        unsigned long long* dst = g_probe + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < 6; ++i) dst[i] = probe_sec[i];
+        dst[6] = __builtin_amdgcn_s_memtime() - probe_t0;
+    }
+#endif
+    x3_epilogue<BM, BN, WM, WN, CONV, NSTAGE * STAGE>(p, acc, ring, m0, n0, wm, wn);
+}
+
+template <int BM, int BN, int WM, int WN, bool CONV>
+int launch_s(const X3Args& p, hipStream_t s) {
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    const int MT = (p.M + BM - 1) / BM, NTN = (p.N + BN - 1) / BN;
+    const int grid = ((MT + 7) / 8) * 8 * NTN;
+    const size_t lds = (size_t)3 * (BM + BN) * 128;
+    static LdsLimit lds_limit;
+    lds_limit.ensure((const void*)gemm_x3s_kernel<BM, BN, WM, WN, CONV>, (int)lds);
+    hipLaunchKernelGGL((gemm_x3s_kernel<BM, BN, WM, WN, CONV>), dim3(grid), dim3(NT), lds, s, p);
+    return master_check_launch("gemm_x3s");
 }
 
 template <int BM, int BN, int WM, int WN, bool CONV>
@@ -369,6 +629,17 @@ int dispatch(const X3Args& p, hipStream_t s) {
     return launch<128, 32, 32, 32, CONV>(p, s);
 }
 
+template <bool CONV>
+int dispatch_s(const X3Args& p, hipStream_t s) {
+    if (p.N > 64) {
+        const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 127) / 128);
+        if (t256 < 512) return launch_s<128, 128, 32, 64, CONV>(p, s);
+        return launch_s<256, 128, 64, 64, CONV>(p, s);
+    }
+    if (p.N > 32) return launch_s<256, 64, 64, 32, CONV>(p, s);
+    return launch_s<128, 32, 32, 32, CONV>(p, s);
+}
+
 // ---- weight split: fp32 [rows, K] -> per row and 32-wide chunk: 32 bf16 hi, 32 bf16 lo (same byte size and row stride as the fp32 matrix) ----
 // layout 1 (the second Linear of the fused MLP, mlp_x3.hip): inside every group of 16 k the order is 0-3, 8-11, 4-7, 12-15 - the k order
 // of a packed 32x32 accumulator tile used as an MFMA operand (lane half h holds rows 4h + 0..3 and 8 + 4h + 0..3 of each group).
@@ -393,15 +664,15 @@ int gemm_x3_split_weights(const float* w, void* out, size_t rows, size_t K, int 
 }
 
 int gemm_x3_linear(const float* a, const void* w, const float* bias, const float* r1, const float* r2, float* out,
-                   int M, int N, int K, int lda, int ldo, int ldr, int act, hipStream_t s) {
-    X3Args p{a, (const float*)w, bias, r1, r2, out, M, N, K, lda, ldo, ldr, act, 0, 0, 0, 1, 1, 0, 0, 0};
-    return dispatch<false>(p, s);
+                   int M, int N, int K, int lda, int ldo, int ldr, int act, hipStream_t s, int a_split, int out_split) {
+    X3Args p{a, (const float*)w, bias, r1, r2, out, M, N, K, lda, ldo, ldr, act, 0, 0, 0, 1, 1, 0, 0, 0, out_split};
+    return a_split ? dispatch_s<false>(p, s) : dispatch<false>(p, s);
 }
 
 int gemm_x3_conv3x3(const float* x, const void* w, const float* bias, float* out, int B, int Hin, int Win, int Cin,
-                    int Cout, int up, int relu, int out_nchw, hipStream_t s, int zero_pad) {
+                    int Cout, int up, int relu, int out_nchw, hipStream_t s, int zero_pad, int a_split, int out_split) {
     const int Hout = Hin << up, Wout = Win << up;
     X3Args p{x, (const float*)w, bias, nullptr, nullptr, out, B * Hout * Wout, Cout, 9 * Cin, 0, Cout, 0,
-             relu ? MASTER_ACT_RELU : MASTER_ACT_NONE, Hin, Win, Cin, Hout, Wout, up, out_nchw, zero_pad};
-    return dispatch<true>(p, s);
+             relu ? MASTER_ACT_RELU : MASTER_ACT_NONE, Hin, Win, Cin, Hout, Wout, up, out_nchw, zero_pad, out_split};
+    return a_split ? dispatch_s<true>(p, s) : dispatch<true>(p, s);
 }

@@ -13,6 +13,7 @@ by the attention kernel, and a zero-padded slot's key/value row is the projectio
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -707,8 +708,12 @@ class Decoder(_HipModule):
                 # bf16 mode: Upsample + Conv(32->32) + ReLU + Conv(32->3) in one launch, intermediate kept in LDS
                 return ops.decoder_tail(x, packed(prev), self._b(f"conv{prev}", conv.bias), packed(last),
                                         self._b(f"conv{last}", self.decoder[last].bias))
+            # split mode: the maps between two x3 convolutions travel in the split layout (the consumer's LDS-DMA pieces copy them as they
+            # lie: no split arithmetic, no LDS stores in its loop); the layer in front of the 3-channel last one writes fp32 for the direct kernel
+            nxt = self.CONV_IDX[self.CONV_IDX.index(i) + 1] if i != last else None
+            out_split = bool(self.split_weights and nxt is not None and nxt != last and os.environ.get("MASTER_X3_SPLIT_ACT", "1") != "0")
             x = ops.conv3x3_reflect(x, packed(i), bias(i), upsample=i in self.UPSAMPLE_BEFORE,
-                                    relu=i != last, out_nchw=i == last)
+                                    relu=i != last, out_nchw=i == last, out_split=out_split)
         return x
 
     def forward(self, x: Tensor) -> Tensor:

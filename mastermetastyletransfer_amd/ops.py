@@ -15,7 +15,9 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MASTER_HIP_LIB") or os.path.join(_HERE, "csrc", "libmaster_hip.so")   # override: A/B runs of two builds
 
-F32, BF16, F32X3 = 0, 1, 2        # F32X3: fp32 activations, weights pre-split into bf16 hi/lo (split_weights), 3 bf16 MFMAs per product
+F32, BF16, F32X3 = 0, 1, 2
+A_SPLIT, OUT_SPLIT = 0x200, 0x400        # OR-ed into F32X3: activation operand / output in the split layout (include/master_hip.h)
+
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 K_FAMILIES = ("linear", "conv3x3", "window_attn", "layernorm", "instnorm", "patch_embed", "patch_merge", "convert", "mlp", "decoder_tail", "attn_block",
               "conv_dgrad", "conv_wgrad", "linear_bwd", "window_attn_bwd", "train_misc")
@@ -211,6 +213,11 @@ def is_split(w: torch.Tensor) -> bool:
     return w.dtype == torch.bfloat16 and w.dim() == 4 and w.shape[2] == 2 and w.shape[3] == 32
 
 
+def is_split_act(x: torch.Tensor) -> bool:
+    """True for an NHWC activation map in the split layout [B, H, W, C/32, 2, 32] bf16 (written by a convolution with out_split=True)"""
+    return x.dtype == torch.bfloat16 and x.dim() == 6 and x.shape[4] == 2 and x.shape[5] == 32
+
+
 @_on_device
 def split_weights(w: torch.Tensor, layout: int = 0) -> torch.Tensor:
     """fp32 [rows, K] (or a packed conv weight [Cout,3,3,Cin], flattened) -> bf16 [rows, K/32, 2, 32]: per 32-wide k chunk the 32 bf16
@@ -329,24 +336,33 @@ def mlp(x: torch.Tensor, w1, b1, w2, b2, res: Optional[torch.Tensor] = None, ln_
 
 @_on_device
 def conv3x3_reflect(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, upsample: bool, relu: bool,
-                    out_nchw: bool = False) -> torch.Tensor:
-    """x NHWC [B,H,W,Cin]; w_packed [Cout,3,3,Cin]; returns NHWC, or fp32 NCHW when out_nchw."""
+                    out_nchw: bool = False, out_split: bool = False) -> torch.Tensor:
+    """x NHWC [B,H,W,Cin]; w_packed [Cout,3,3,Cin]; returns NHWC, or fp32 NCHW when out_nchw.
+    F32X3 mode (w_packed = split_weights(...)): x may be an activation map in the split layout (is_split_act: the output of a previous
+    call with out_split=True), and out_split=True writes this call's output in it ([B,Ho,Wo,Cout/32,2,32] bf16, Cout % 32 == 0)."""
     _dev(x, w_packed)
-    B, H, W, Cin = x.shape
+    a_split = is_split_act(x)
+    B, H, W = x.shape[:3]
+    Cin = x.shape[3] * 32 if a_split else x.shape[3]
     Cout = w_packed.shape[0]
     x3 = is_split(w_packed)
     assert x.is_contiguous() and w_packed.is_contiguous() and bias.dtype == torch.float32
-    assert not x3 or (x.dtype == torch.float32 and w_packed.shape[1] * 32 == 9 * Cin)
+    assert not x3 or ((a_split or x.dtype == torch.float32) and w_packed.shape[1] * 32 == 9 * Cin)
+    assert x3 or not (a_split or out_split), "split activations belong to the F32X3 mode"
     Ho, Wo = (H * 2, W * 2) if upsample else (H, W)
     if out_nchw:
         out = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    elif out_split:
+        assert Cout % 32 == 0
+        out = torch.empty((B, Ho, Wo, Cout // 32, 2, 32), dtype=torch.bfloat16, device=x.device)
     else:
-        out = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+        out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32 if a_split else x.dtype, device=x.device)
     if _COUNT_ON:
         _count("conv3x3", flops=2.0 * B * Ho * Wo * Cout * 9 * Cin,
                bytes=x.element_size() * (x.numel() + w_packed.numel()) + out.element_size() * out.numel())
+    dt = (F32X3 | (A_SPLIT if a_split else 0) | (OUT_SPLIT if out_split else 0)) if x3 else _dt(x)
     _check(load_library().master_conv3x3_reflect_fwd(_p(x), _p(w_packed), _p(bias), _p(out), B, H, W, Cin, Cout,
-                                                      int(upsample), int(relu), int(out_nchw), F32X3 if x3 else _dt(x), _stream()),
+                                                      int(upsample), int(relu), int(out_nchw), dt, _stream()),
            "master_conv3x3_reflect_fwd")
     return out
 
@@ -374,6 +390,8 @@ def attn_block(x, ln_gamma, ln_beta, wqkv, bqkv, wproj, bproj, bias64, src, regi
 
 
 def decoder_tail_supported(x: torch.Tensor, cout_mid: int) -> bool:
+    if x.dim() != 4:              # a map in the split layout of the F32X3 mode
+        return False
     B, H, W, C = x.shape
     return x.dtype == torch.bfloat16 and C == 32 and cout_mid == 32 and (2 * H) % 16 == 0 and (2 * W) % 32 == 0
 

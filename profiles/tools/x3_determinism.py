@@ -36,6 +36,12 @@ for B, H, Cin, Cout, up in [(32, 32, 256, 128, 0), (32, 32, 128, 128, 1), (32, 6
     x = torch.randn(B, H, H, Cin, device=dev); w = ops.split_weights(torch.randn(Cout, 3, 3, Cin, device=dev) / (3 * Cin ** .5))
     b = torch.randn(Cout, device=dev)
     check(f"conv {B}x{H}x{H} {Cin}->{Cout} up{up}", lambda: ops.conv3x3_reflect(x, w, b, bool(up), True))
+for B, H, Cin, Cout, up in [(32, 32, 128, 128, 1), (32, 64, 128, 64, 0), (32, 64, 64, 64, 1), (32, 128, 64, 32, 0), (32, 128, 32, 32, 1)]:
+    x0 = torch.randn(B, H, H, 32, device=dev); w0 = ops.split_weights(torch.randn(Cin, 3, 3, 32, device=dev) / 17)
+    xs = ops.conv3x3_reflect(x0, w0, torch.zeros(Cin, device=dev), False, True, out_split=True)           # a map in the split layout
+    w = ops.split_weights(torch.randn(Cout, 3, 3, Cin, device=dev) / (3 * Cin ** .5)); b = torch.randn(Cout, device=dev)
+    check(f"conv split-in {B}x{H}x{H} {Cin}->{Cout} up{up}", lambda: ops.conv3x3_reflect(xs, w, b, bool(up), True, out_split=Cout % 32 == 0 and up == 0).view(torch.int16)
+          if (Cout % 32 == 0 and up == 0) else ops.conv3x3_reflect(xs, w, b, bool(up), True))
 for M, C, ln in [(32768, 256, 0), (32768, 256, 1), (65536, 256, 1), (262144, 128, 1), (262144, 128, 0)]:
     x = torch.randn(M, C, device=dev)
     w1 = ops.split_weights(torch.randn(4 * C, C, device=dev) / C ** 0.5); w2 = ops.split_weights(torch.randn(C, 4 * C, device=dev) / (4 * C) ** 0.5, layout=1)

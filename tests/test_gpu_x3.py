@@ -145,6 +145,35 @@ def test_split_weights_layout1(cuda):
     assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
 
 
+def test_conv_chain_in_split_layout(cuda):
+    """two convolutions handing the map over in the split layout (MASTER_OUT_SPLIT -> MASTER_A_SPLIT) against the same two through fp32:
+    hi + lo carries the map to 2^-17, so the chains agree to the kernel tolerance; the split map itself is checked element by element"""
+    from mastermetastyletransfer_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, H, W = 2, 12, 20
+    x = torch.randn(B, H, W, 64, generator=g).to(cuda)
+    w1 = torch.randn(96, 3, 3, 64, generator=g) / 24; w2 = torch.randn(32, 3, 3, 96, generator=g) / 30
+    b1, b2 = torch.randn(96, generator=g).to(cuda), torch.randn(32, generator=g).to(cuda)
+    s1, s2 = ops.split_weights(w1.to(cuda)), ops.split_weights(w2.to(cuda))
+    mid32 = ops.conv3x3_reflect(x, s1, b1, True, True)
+    mid = ops.conv3x3_reflect(x, s1, b1, True, True, out_split=True)
+    assert ops.is_split_act(mid) and mid.shape == (B, 2 * H, 2 * W, 3, 2, 32)
+    hi = mid32.bfloat16(); lo = (mid32 - hi.float()).bfloat16()
+    ref_mid = torch.stack([hi.view(B, 2 * H, 2 * W, 3, 32), lo.view(B, 2 * H, 2 * W, 3, 32)], dim=4)
+    assert torch.equal(mid.view(torch.int16), ref_mid.view(torch.int16))
+    out_a = ops.conv3x3_reflect(mid, s2, b2, False, True)
+    out_b = ops.conv3x3_reflect(mid32, s2, b2, False, True)
+    assert out_a.dtype == torch.float32 and rel_err(out_a, out_b.double().cpu()) < X3_KERNEL_TOL
+    # split in AND out, and the big-tile configuration
+    xb = torch.randn(4, 64, 64, 128, generator=g).to(cuda)
+    wb = ops.split_weights((torch.randn(128, 3, 3, 128, generator=g) / 34).to(cuda)); bb = torch.randn(128, generator=g).to(cuda)
+    m1 = ops.conv3x3_reflect(xb, wb, bb, False, True, out_split=True)
+    o1 = ops.conv3x3_reflect(m1, wb, bb, False, True, out_split=True)
+    o2 = ops.conv3x3_reflect(ops.conv3x3_reflect(xb, wb, bb, False, True), wb, bb, False, True)
+    o1f = (o1[..., 0, :].float() + o1[..., 1, :].float()).reshape(4, 64, 64, 128)
+    assert rel_err(o1f, o2.double().cpu()) < X3_KERNEL_TOL
+
+
 def full_model(dev, seed=31):
     from mastermetastyletransfer_amd import MasterStyleTransferModel
     with warnings.catch_warnings():
