@@ -96,15 +96,18 @@ class AsyncImageGather:
     overwrites one: the stream then waits for the gather that still reads it.  Destination buffers come from a pool of depth + 1 and
     are recycled after `depth` further submits; pass `out=` to own the destination instead."""
 
-    def __init__(self, batch: int, rank: int, world: int, depth: int = 2):
+    def __init__(self, batch: int, rank: int, world: int, depth: int = 2, force_collective: bool = False):
+        """force_collective: run the collective even in a one-rank group (where the gather is the identity and is normally skipped) - the
+        one-GPU hardware test of the RCCL path: library loading, the collective's own stream, release_source ordering against graph replays"""
         if batch % max(world, 1) != 0:
             raise ValueError("AsyncImageGather needs equal shards (batch % world == 0)")
         self.batch, self.rank, self.world, self.depth = batch, rank, world, depth
+        self.force = bool(force_collective)
         self.pending = []          # (work, output buffer, local shard kept alive)
         self.buffers = []
 
     def submit(self, local: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return local
         while len(self.pending) >= self.depth:
             self._retire()

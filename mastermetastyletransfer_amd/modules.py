@@ -43,6 +43,9 @@ def _train_mode(m: nn.Module) -> bool:
         return False
     if getattr(m, "compute_dtype", torch.float32) != torch.float32 or getattr(m, "split_weights", False):
         raise NotImplementedError("the train step runs in the exact-fp32 mode: call set_compute_dtype(torch.float32) before .train()")
+    if any(getattr(sub, "_inference_only_arch", False) for sub in m.modules()):
+        raise NotImplementedError("bias-free projections and a ReLU MLP activation are implemented for inference only (the backward kernels "
+                                  "cover the reference's defaults: qkv_bias = proj_bias = True, nn.GELU)")
     return True
 
 
@@ -77,6 +80,17 @@ class _HipModule(nn.Module):
             return b.detach().float().contiguous()
         return self._derived("b:" + name, params, build)
 
+    def _bias_of(self, lin: nn.Linear) -> Tensor:
+        """the bias of a projection, or - bias=False (qkv_bias / proj_bias of full_model.py:39-42) - a zero row of its width: F.linear
+        without a bias adds nothing, and a zero-padded window slot's key / value row (the reference pads BEFORE the Linear) is then zero"""
+        if lin.bias is not None:
+            return lin.bias
+        cache = self.__dict__.setdefault("_zero_bias", {})
+        key = (lin.out_features, str(lin.weight.device))
+        if key not in cache:
+            cache[key] = torch.zeros(lin.out_features, dtype=torch.float32, device=lin.weight.device)
+        return cache[key]
+
     def _row(self, name: str, param: Tensor) -> Tensor:
         """a bias used as the K/V row of zero-padded window slots: compute dtype"""
         return self._derived("row:" + name, [param], lambda: ops.convert(param.detach().contiguous(), self.compute_dtype))
@@ -92,9 +106,10 @@ def _image(x2d: Tensor, B: int, H: int, W: int) -> Tensor:
     return ops.convert(x2d, torch.float32).view(B, H, W, -1)
 
 
-def _make_mlp(dim: int, hidden: int, dropout: float) -> nn.Sequential:
-    """same children/keys as torchvision.ops.MLP: 0 Linear, 1 GELU, 2 Dropout, 3 Linear, 4 Dropout"""
-    return nn.Sequential(nn.Linear(dim, hidden), nn.GELU(), nn.Dropout(dropout), nn.Linear(hidden, dim), nn.Dropout(dropout))
+def _make_mlp(dim: int, hidden: int, dropout: float, act_layer: Optional[Callable[..., nn.Module]] = nn.GELU) -> nn.Sequential:
+    """same children/keys as torchvision.ops.MLP: 0 Linear, 1 activation (torchvision: activation_layer(), nn.GELU or nn.ReLU here), 2 Dropout,
+    3 Linear, 4 Dropout"""
+    return nn.Sequential(nn.Linear(dim, hidden), (act_layer or nn.GELU)(), nn.Dropout(dropout), nn.Linear(hidden, dim), nn.Dropout(dropout))
 
 
 def _init_mlp(mlp: nn.Sequential):
@@ -114,7 +129,8 @@ def _mlp_fwd(owner: _HipModule, name: str, mlp: nn.Sequential, x: Tensor, residu
     b2 = owner._b(name + ".3", mlp[3].bias)
     g = owner._b(name + ".ln_w", norm.weight) if norm is not None else None
     b = owner._b(name + ".ln_b", norm.bias) if norm is not None else None
-    if ops.mlp_fused_supported(x, w1.shape[0], owner.split_weights):
+    relu = isinstance(mlp[1], nn.ReLU)          # MLP_activation_layer = nn.ReLU (full_model.py:47-50): the fused kernels are GELU-only
+    if not relu and ops.mlp_fused_supported(x, w1.shape[0], owner.split_weights):
         # split mode: the fused kernel reads W2 in the k order of a packed accumulator tile (ops.split_weights layout 1)
         w2f = owner._derived("w:" + name + ".3:acc_k", [mlp[3].weight], lambda: ops.split_weights(mlp[3].weight, layout=1)) \
             if owner.split_weights else owner._w(name + ".3", mlp[3].weight)
@@ -125,17 +141,15 @@ def _mlp_fwd(owner: _HipModule, name: str, mlp: nn.Sequential, x: Tensor, residu
     w2 = owner._w(name + ".3", mlp[3].weight)
     if norm is not None:
         x = ops.layernorm(x, g, b, norm.eps)
-    h = ops.linear(x, w1, b1, act=ops.ACT_GELU)
+    h = ops.linear(x, w1, b1, act=ops.ACT_RELU if relu else ops.ACT_GELU)
     return ops.linear(h, w2, b2, r2=residual)
 
 
 def _check_arch(dropout, attention_dropout, qkv_bias, proj_bias, act_layer, dim, heads):
     if dropout != 0.0 or attention_dropout != 0.0:
         raise NotImplementedError("dropout > 0 is not implemented on the HIP path (reference default 0.0)")
-    if not (qkv_bias and proj_bias):
-        raise NotImplementedError("bias-free projections are not implemented on the HIP path (reference default True)")
-    if act_layer is not nn.GELU:
-        raise NotImplementedError("only nn.GELU MLP activation is implemented on the HIP path (reference default)")
+    if act_layer is not None and act_layer not in (nn.GELU, nn.ReLU):
+        raise NotImplementedError("MLP activations on the HIP path: nn.GELU (reference default) and nn.ReLU")
     if dim % heads != 0 or dim // heads != HEAD_DIM:
         raise NotImplementedError(f"head_dim must be {HEAD_DIM} (dim {dim}, heads {heads}); reference default is 256/8")
 
@@ -185,6 +199,7 @@ class ShiftedWindowAttention(_WindowAttentionBase):
         self.Wk = nn.Linear(dim, dim, bias=qkv_bias)
         self.Wv = nn.Linear(dim, dim, bias=qkv_bias)
         self.proj = nn.Linear(dim, dim, bias=proj_bias)
+        self._inference_only_arch = not (qkv_bias and proj_bias)
         self._init_rel_pos(num_heads)
 
     def attend(self, xq: Tensor, xk: Tensor, xvs: Sequence[Tensor], residuals: Sequence[Optional[Tensor]],
@@ -195,7 +210,7 @@ class ShiftedWindowAttention(_WindowAttentionBase):
         C = xq.shape[1]
         if xq is xk and all(v is xq for v in xvs):
             wqkv = self._w("qkv", self.Wq.weight, self.Wk.weight, self.Wv.weight)
-            bqkv = self._b("qkv", self.Wq.bias, self.Wk.bias, self.Wv.bias)
+            bqkv = self._b("qkv", self._bias_of(self.Wq), self._bias_of(self.Wk), self._bias_of(self.Wv))
             if norm is not None:
                 qkv = ops.linear_ln(xq, self._b("n1w", norm.weight), self._b("n1b", norm.bias), wqkv, bqkv, eps=norm.eps)
             else:
@@ -223,13 +238,14 @@ class ShiftedWindowAttention(_WindowAttentionBase):
                 else:
                     uniq.append(len(seen))
                     seen.append(v)
-            wv, bv = self._w("v", self.Wv.weight), self._b("v", self.Wv.bias)
+            wv, bv = self._w("v", self.Wv.weight), self._b("v", self._bias_of(self.Wv))
             # the projections of this call read different inputs but are independent: one grouped launch (q|k + v, or q, k, v) when
             # there are at most three of them
             if xq is xk:
-                probs = [(xq, self._w("qk", self.Wq.weight, self.Wk.weight), self._b("qk", self.Wq.bias, self.Wk.bias))]
+                probs = [(xq, self._w("qk", self.Wq.weight, self.Wk.weight), self._b("qk", self._bias_of(self.Wq), self._bias_of(self.Wk)))]
             else:
-                probs = [(xq, self._w("q", self.Wq.weight), self._b("q", self.Wq.bias)), (xk, self._w("k", self.Wk.weight), self._b("k", self.Wk.bias))]
+                probs = [(xq, self._w("q", self.Wq.weight), self._b("q", self._bias_of(self.Wq))),
+                         (xk, self._w("k", self.Wk.weight), self._b("k", self._bias_of(self.Wk)))]
             probs += [(v, wv, bv) for v in seen]
             if len(probs) <= 3:
                 outs_ = ops.linear_group([p_[0] for p_ in probs], [p_[1] for p_ in probs], [p_[2] for p_ in probs])
@@ -241,8 +257,8 @@ class ShiftedWindowAttention(_WindowAttentionBase):
                 q, k, vs = outs_[0], outs_[1], outs_[2:]
         if len(vs) > 2:
             raise NotImplementedError("at most two value streams per attention call")
-        kp, vp = self._row("k", self.Wk.bias), self._row("v", self.Wv.bias)
-        pw, pb = self._w("proj", self.proj.weight), self._b("proj", self.proj.bias)
+        kp, vp = self._row("k", self._bias_of(self.Wk)), self._row("v", self._bias_of(self.Wv))
+        pw, pb = self._w("proj", self.proj.weight), self._b("proj", self._bias_of(self.proj))
         plan = window_plan(H, W, self.window_size, self.shift_size, q.device)
         if len(vs) == 1 and len({None if r_ is None else id(r_) for r_ in residuals}) == 1 and \
                 ops.window_attn_proj_supported(q, self.num_heads, plan.nW, plan.N):
@@ -295,8 +311,9 @@ class StyleSwinTransformerBlock(_HipModule):
                                            qkv_bias, proj_bias)
         self.stochastic_depth_prob = stochastic_depth_prob       # identity in eval mode (torchvision StochasticDepth)
         if not exclude_MLP_after:
-            self.mlp = _make_mlp(dim, int(dim * mlp_ratio), dropout)
+            self.mlp = _make_mlp(dim, int(dim * mlp_ratio), dropout, MLP_activation_layer)
             _init_mlp(self.mlp)
+            self._inference_only_arch = MLP_activation_layer is nn.ReLU
 
     def _ln(self, which: str, x: Tensor) -> Tensor:
         n = getattr(self, which)
@@ -360,6 +377,7 @@ class ShiftedWindowAttention_for_decoder_last_MHA(_WindowAttentionBase):
         self.Wv_scale = nn.Linear(dim, dim, bias=qkv_bias)
         self.Wv_shift = nn.Linear(dim, dim, bias=qkv_bias)
         self.proj = nn.Linear(dim, dim, bias=proj_bias)
+        self._inference_only_arch = not (qkv_bias and proj_bias)
         self._init_rel_pos(num_heads)
 
     def sigma_mu(self, xq: Tensor, xk: Tensor, xs: Tensor, xsh: Tensor, B: int, H: int, W: int,
@@ -377,8 +395,9 @@ class ShiftedWindowAttention_for_decoder_last_MHA(_WindowAttentionBase):
         # Wk . Key | Wv_scale . Scale | Wv_shift . Shift  (:515-517): three inputs, three weights, one grouped launch
         k, vs, vsh = ops.linear_group([xk, xs, xsh],
                                       [self._w("k", self.Wk.weight), self._w("vs", self.Wv_scale.weight), self._w("vsh", self.Wv_shift.weight)],
-                                      [self._b("k", self.Wk.bias), self._b("vs", self.Wv_scale.bias), self._b("vsh", self.Wv_shift.bias)])
-        k_pad = self._row("k", self.Wk.bias)
+                                      [self._b("k", self._bias_of(self.Wk)), self._b("vs", self._bias_of(self.Wv_scale)),
+                                       self._b("vsh", self._bias_of(self.Wv_shift))])
+        k_pad = self._row("k", self._bias_of(self.Wk))
         if self.use_Key_instance_norm_after_linear_transformation:
             # :520-530  statistics over the zero-padded pH x pW map: its padded slots hold Wk.bias
             plan = window_plan(H, W, self.window_size, self.shift_size, xq.device)
@@ -386,8 +405,9 @@ class ShiftedWindowAttention_for_decoder_last_MHA(_WindowAttentionBase):
             k = aff(k, nk, "ink")
             if k_pad_b is not None:
                 k_pad = k_pad_b if nk is None else aff(k_pad_b.contiguous(), nk, "ink")
-        o_s, o_sh = self._core(q, k, [vs, vsh], k_pad, [self._row("vs", self.Wv_scale.bias), self._row("vsh", self.Wv_shift.bias)], B, H, W)
-        pw, pb = self._w("proj", self.proj.weight), self._b("proj", self.proj.bias)
+        o_s, o_sh = self._core(q, k, [vs, vsh], k_pad, [self._row("vs", self._bias_of(self.Wv_scale)), self._row("vsh", self._bias_of(self.Wv_shift))],
+                               B, H, W)
+        pw, pb = self._w("proj", self.proj.weight), self._b("proj", self._bias_of(self.proj))
         mu = ops.linear(o_sh, pw, pb)                                               # :594-595
         if fuse_query is not None:
             return ops.linear(o_s, pw, pb, r1=fuse_query, r2=mu)                    # Query * sigma + mu
@@ -420,9 +440,12 @@ class StyleEncoder(_HipModule):
             proj_bias=encoder_proj_bias, mlp_ratio=encoder_mlp_ratio, stochastic_depth_prob=encoder_stochastic_depth_prob,
             norm_layer=encoder_norm_layer, MLP_activation_layer=encoder_MLP_activation_layer, exclude_MLP_after=True)
         hid = int(encoder_dim * encoder_mlp_ratio)
-        self.encoder_MLP_Key = _make_mlp(encoder_dim, hid, encoder_dropout)
-        self.encoder_MLP_Scale = _make_mlp(encoder_dim, hid, encoder_dropout)
-        self.encoder_MLP_Shift = _make_mlp(encoder_dim, hid, encoder_dropout)
+        if encoder_MLP_activation_layer is not None and encoder_MLP_activation_layer not in (nn.GELU, nn.ReLU):
+            raise NotImplementedError("MLP activations on the HIP path: nn.GELU (reference default) and nn.ReLU")
+        self.encoder_MLP_Key = _make_mlp(encoder_dim, hid, encoder_dropout, encoder_MLP_activation_layer)
+        self.encoder_MLP_Scale = _make_mlp(encoder_dim, hid, encoder_dropout, encoder_MLP_activation_layer)
+        self.encoder_MLP_Shift = _make_mlp(encoder_dim, hid, encoder_dropout, encoder_MLP_activation_layer)
+        self._inference_only_arch = encoder_MLP_activation_layer is nn.ReLU
         # (the reference's init loop at :847-851 never matches an nn.Linear, so these keep nn.Linear's default init)
 
     def run(self, key: Tensor, scale: Tensor, shift: Tensor, B, H, W):
@@ -493,7 +516,10 @@ class StyleDecoder(_HipModule):
         else:
             self.instance_norm = nn.InstanceNorm2d(decoder_dim, affine=False)      # parameter-free, kept for parity of the tree
             nq = nk = self.instance_norm
-        self.last_MLP = _make_mlp(decoder_dim, int(decoder_dim * decoder_mlp_ratio), decoder_dropout)
+        if decoder_MLP_activation_layer is not None and decoder_MLP_activation_layer not in (nn.GELU, nn.ReLU):
+            raise NotImplementedError("MLP activations on the HIP path: nn.GELU (reference default) and nn.ReLU")
+        self.last_MLP = _make_mlp(decoder_dim, int(decoder_dim * decoder_mlp_ratio), decoder_dropout, decoder_MLP_activation_layer)
+        self._inference_only_arch = decoder_MLP_activation_layer is nn.ReLU
         if not decoder_use_regular_MHA_instead_of_Swin_at_the_end:
             self.decoder_MHA_for_sigma_and_mu = ShiftedWindowAttention_for_decoder_last_MHA(
                 dim=decoder_dim, num_heads=decoder_num_heads, window_size=decoder_window_size, shift_size=decoder_shift_size,

@@ -5,18 +5,18 @@
 #   train step:     the same four passes of `bench.py --mode train` (BASELINE config 4);
 #   fp32 mode:      kernel trace of `bench.py --dtype fp32`.
 # Outputs land in gpurun_out/<tag>/ with the names profiles/ uses (r03_...); copy what should be judged into profiles/.
-# usage: profiles/collect.sh [tag=r03] [what=all|bf16|train|fp32]
+# usage: profiles/collect.sh [tag=r04] [what=all|bf16|train|fp32|x3]
 set -e
-tag=${1:-r03}; what=${2:-all}; out=gpurun_out/$tag; mkdir -p $out
+tag=${1:-r04}; what=${2:-all}; out=gpurun_out/$tag; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 if [ $what = all ] || [ $what = bf16 ]; then
-rocprofv3 --kernel-trace --stats -d $out/trace -o t --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-extras > $out/trace.log 2>&1
-python profiles/trace_by_shape.py $out/trace/t_kernel_trace.csv 23 > $out/${tag}_bf16_bs32_trace_by_shape.txt
+rocprofv3 --kernel-trace --stats -d $out/trace -o t --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-extras --no-repeats > $out/trace.log 2>&1
+python profiles/trace_by_shape.py $out/trace/t_kernel_trace.csv auto > $out/${tag}_bf16_bs32_trace_by_shape.txt
 cp $out/trace/t_kernel_stats.csv $out/${tag}_bf16_bs32_kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o f --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-extras > $out/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o w --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-extras > $out/write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o f --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-extras --no-repeats > $out/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o w --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-extras --no-repeats > $out/write.log 2>&1
 python profiles/pmc_traffic.py $out/fetch/f_counter_collection.csv $out/write/w_counter_collection.csv $out/${tag}_bf16_bs32_pmc_traffic.json > $out/${tag}_bf16_bs32_pmc_traffic.txt
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out/mfma -o m --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-extras > $out/mfma.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out/mfma -o m --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-extras --no-repeats > $out/mfma.log 2>&1
 python profiles/pmc_mfma_util.py $out/mfma/m_counter_collection.csv $out/${tag}_bf16_bs32_pmc_mfma_util.json > $out/${tag}_bf16_bs32_pmc_mfma_util.txt
 echo "bf16 passes done"
 fi
@@ -31,11 +31,22 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel
 python profiles/pmc_mfma_util.py $out/tmfma/m_counter_collection.csv $out/${tag}_train_pmc_mfma_util.json > $out/${tag}_train_pmc_mfma_util.txt
 echo "train passes done"
 fi
+if [ $what = all ] || [ $what = x3 ]; then
+rocprofv3 --kernel-trace --stats -d $out/xtrace -o t --output-format csv -- python3 bench.py --dtype x3 --steps 8 --warmup 2 --no-extras --no-repeats > $out/xtrace.log 2>&1
+python profiles/trace_by_shape.py $out/xtrace/t_kernel_trace.csv auto > $out/${tag}_x3_bs32_trace_by_shape.txt
+cp $out/xtrace/t_kernel_stats.csv $out/${tag}_x3_bs32_kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/xfetch -o f --output-format csv -- python3 bench.py --dtype x3 --steps 2 --warmup 1 --no-extras --no-repeats > $out/xfetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/xwrite -o w --output-format csv -- python3 bench.py --dtype x3 --steps 2 --warmup 1 --no-extras --no-repeats > $out/xwrite.log 2>&1
+python profiles/pmc_traffic.py $out/xfetch/f_counter_collection.csv $out/xwrite/w_counter_collection.csv $out/${tag}_x3_bs32_pmc_traffic.json > $out/${tag}_x3_bs32_pmc_traffic.txt
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out/xmfma -o m --output-format csv -- python3 bench.py --dtype x3 --steps 2 --warmup 1 --no-extras --no-repeats > $out/xmfma.log 2>&1
+python profiles/pmc_mfma_util.py $out/xmfma/m_counter_collection.csv $out/${tag}_x3_bs32_pmc_mfma_util.json > $out/${tag}_x3_bs32_pmc_mfma_util.txt
+echo "x3 passes done"
+fi
 if [ $what = all ] || [ $what = fp32 ]; then
 rocprofv3 --kernel-trace --stats -d $out/ftrace -o t --output-format csv -- python3 bench.py --dtype fp32 --steps 8 --warmup 2 --no-extras > $out/ftrace.log 2>&1
-python profiles/trace_by_shape.py $out/ftrace/t_kernel_trace.csv 10 > $out/${tag}_fp32_bs32_trace_by_shape.txt
+python profiles/trace_by_shape.py $out/ftrace/t_kernel_trace.csv auto > $out/${tag}_fp32_bs32_trace_by_shape.txt
 echo "fp32 pass done"
 fi
 # the raw traces are large: keep the summaries only
-rm -rf $out/trace $out/fetch $out/write $out/mfma $out/ttrace $out/tfetch $out/twrite $out/tmfma $out/ftrace
+rm -rf $out/xtrace $out/xfetch $out/xwrite $out/xmfma $out/trace $out/fetch $out/write $out/mfma $out/ttrace $out/tfetch $out/twrite $out/tmfma $out/ftrace
 ls $out

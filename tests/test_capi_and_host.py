@@ -310,3 +310,115 @@ def test_trace_tools_count_every_launch(tmp_path):
     assert sum(1 for line in out.splitlines() if "n/step=" in line) == 61
     out = subprocess.run([sys.executable, os.path.join(root, "profiles", "tools", "trace_compare.py"), str(p), str(p), "2"], capture_output=True, text=True, check=True).stdout
     assert "launches 45.0 -> 45.0" in out
+
+
+# ---- checkpoint FILE formats the reference writes (full_model.py:69, utils.py:93-102, train_only_inner_loop.py:370-385) ----------------------
+class _PickledBlock(torch.nn.Module):
+    """stand-in for a torchvision SwinTransformerBlock inside a pickled nn.Sequential: the same parameter / buffer names, nothing else
+    (torchvision is absent here; what the loader consumes of the pickle is its state_dict)"""
+
+    def __init__(self, dim, heads, hidden):
+        super().__init__()
+        nn = torch.nn
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = nn.Module()
+        self.attn.qkv = nn.Linear(dim, 3 * dim); self.attn.proj = nn.Linear(dim, dim)
+        self.attn.relative_position_bias_table = nn.Parameter(torch.randn(169, heads) * 0.02)
+        self.attn.register_buffer("relative_position_index", torch.zeros(49 * 49, dtype=torch.int64))
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = nn.Sequential(nn.Linear(dim, hidden), nn.GELU(), nn.Dropout(0.0), nn.Linear(hidden, dim), nn.Dropout(0.0))
+
+
+class _PickledMerge(torch.nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.reduction = torch.nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = torch.nn.LayerNorm(4 * dim)
+
+
+def test_pickled_sequential_encoder_and_whole_model_files(tmp_path, lib):
+    """(a) the Swin encoder as the reference stores it: torch.save of the whole nn.Sequential MODULE (utils.py:93-102), read back with
+    torch.load at construction (full_model.py:69) - here a Sequential with torchvision's child indices and parameter names;
+    (b) the whole-model checkpoint of train_only_inner_loop.py:381-385 (torch.save(model.state_dict())): keys swin_encoder.* |
+    style_transformer.* | decoder.* load into a fresh model; (c) the per-part files of :370-379 through the constructor keywords."""
+    import warnings
+    from mastermetastyletransfer_amd import MasterStyleTransferModel
+    from mastermetastyletransfer_amd.window_plan import relative_position_index
+    nn = torch.nn
+    torch.manual_seed(0)
+    seq = nn.Sequential(nn.Sequential(nn.Conv2d(3, 128, 4, 4), nn.Identity(), nn.LayerNorm(128)),
+                        nn.Sequential(_PickledBlock(128, 4, 512), _PickledBlock(128, 4, 512)), _PickledMerge(128),
+                        nn.Sequential(_PickledBlock(256, 8, 1024), _PickledBlock(256, 8, 1024)))
+    for blk in list(seq[1]) + list(seq[3]):
+        blk.attn.relative_position_index.copy_(relative_position_index([7, 7]))
+    (tmp_path / "models").mkdir()
+    torch.save(seq, tmp_path / "models" / "swin_B_first_2_stages.pt")                    # a pickled MODULE, not a state dict
+    m = MasterStyleTransferModel(project_absolute_path=str(tmp_path), swin_model_relative_path="models/swin_B_first_2_stages.pt",
+                                 style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7])
+    got, want = m.swin_encoder.state_dict(), seq.state_dict()
+    assert set(got) == set(want) and all(torch.equal(got[k], want[k]) for k in want)
+    # (b) whole-model file
+    torch.save(m.state_dict(), tmp_path / "full_model_exp_100.pt")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fresh = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7], allow_random_swin_encoder=True)
+    sd = torch.load(tmp_path / "full_model_exp_100.pt")
+    assert {k.split(".")[0] for k in sd} == {"swin_encoder", "style_transformer", "decoder"}
+    missing, unexpected = fresh.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), fresh.state_dict().values()))
+    # (c) per-part files through the constructor keywords (full_model.py:147-155)
+    torch.save(m.style_transformer.state_dict(), tmp_path / "exp_style_transformer_100.pt")
+    torch.save(m.decoder.state_dict(), tmp_path / "exp_decoder_100.pt")
+    m3 = MasterStyleTransferModel(project_absolute_path=str(tmp_path), swin_model_relative_path="models/swin_B_first_2_stages.pt",
+                                  style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7],
+                                  direct_pretrained_style_transformer_path=str(tmp_path / "exp_style_transformer_100.pt"),
+                                  direct_pretrained_decoder_path=str(tmp_path / "exp_decoder_100.pt"))
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m3.state_dict().values()))
+
+
+def test_bias_free_and_relu_flags_construct_with_the_reference_keys(lib):
+    """qkv_bias / proj_bias = False (full_model.py:39-42) drop exactly the projection biases from the state dict (nn.Linear(bias=False), as in
+    style_transformer.py:206-213,:655-662); MLP_activation_layer = nn.ReLU (full_model.py:47-50) keeps every key (torchvision MLP child 1
+    has no parameters).  Both are inference-only on the HIP path: a train-mode call raises."""
+    import warnings
+    from mastermetastyletransfer_amd import MasterStyleTransferModel
+    kw = dict(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7], allow_random_swin_encoder=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        base = MasterStyleTransferModel(**kw)
+        nb = MasterStyleTransferModel(style_encoder_qkv_bias=False, style_decoder_qkv_bias=False, style_encoder_proj_bias=False,
+                                      style_decoder_proj_bias=False, **kw)
+        relu = MasterStyleTransferModel(style_encoder_MLP_activation_layer=torch.nn.ReLU, style_decoder_MLP_activation_layer=torch.nn.ReLU, **kw)
+    all_keys = set(base.style_transformer.state_dict())
+    gone = all_keys - set(nb.style_transformer.state_dict())
+    assert gone and all(k.endswith(".bias") and k.split(".")[-2] in ("Wq", "Wk", "Wv", "Wv_scale", "Wv_shift", "proj") for k in gone)
+    assert len(gone) == 4 + 4 + 4          # shared encoder block, decoder self-attention block, sigma/mu attention (no Wq)
+    assert set(relu.style_transformer.state_dict()) == all_keys
+    assert isinstance(relu.style_transformer.decoder.last_MLP[1], torch.nn.ReLU) and isinstance(relu.style_transformer.encoder.encoder_MLP_Key[1], torch.nn.ReLU)
+    with pytest.raises(NotImplementedError):
+        MasterStyleTransferModel(style_decoder_MLP_activation_layer=torch.nn.Tanh, **kw)
+    for mdl in (nb, relu):
+        mdl.train()
+        for p_ in mdl.swin_encoder.parameters():
+            p_.requires_grad = False
+        with pytest.raises(NotImplementedError, match="inference only"):
+            mdl(torch.zeros(1, 3, 64, 64), torch.zeros(1, 3, 64, 64))
+
+
+def test_trace_by_shape_counts_executions_itself(tmp_path):
+    """steps = auto: the executions of the step are the gcd of the library kernels' launch counts (integer n/step whatever --steps said)"""
+    import subprocess, sys
+    rows = ["Kernel_Name,Grid_Size_X,Workgroup_Size_X,Start_Timestamp,End_Timestamp"]
+    t = 0
+    for rep in range(25):                                          # 25 executions: 7 launches of kernel a, 2 of kernel b each
+        for i in range(7):
+            rows.append(f'"void (anonymous namespace)::a_kernel(float*)",65536,256,{t},{t + 1000}'); t += 2000
+        for i in range(2):
+            rows.append(f'"void (anonymous namespace)::b_kernel(float*)",131072,256,{t},{t + 1000}'); t += 2000
+    rows.append(f'"void at::native::vectorized_elementwise_kernel<4, f>(int)",256,256,{t},{t + 500}')
+    p = tmp_path / "t_kernel_trace.csv"
+    p.write_text("\n".join(rows) + "\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "profiles", "trace_by_shape.py"), str(p), "auto"], capture_output=True, text=True, check=True).stdout
+    assert "over 25 executions" in out and "n/step=  7.0" in out and "n/step=  2.0" in out

@@ -19,13 +19,18 @@ pytestmark = pytest.mark.gpu
 ABS_TOL = 1e-3            # BASELINE.json: <= 1e-3 max-abs vs the CPU path, fp32
 
 
-def assert_close(got, ref, name, tol=ABS_TOL):
+def assert_close(got, ref, name, tol=ABS_TOL, absolute=False):
+    """kernel / module tests: tol relative to max(1, max|ref|).  absolute=True (the full-forward tests): the north star's bar as written,
+    |d| <= tol (1e-3) ABSOLUTE, wherever the stylized image is O(1) (max|ref| <= 10: every k = 1 case); an output in the thousands (the
+    seeded weights at k = 3) cannot carry an absolute 1e-3 in fp32 at all, there the bar is 1e-4 of max|ref| (r04, VERDICT r03 item 2:
+    measured errors are 1.3e-5 ... 8.5e-5, so the literal bar holds with room)."""
     got = got.detach().float().cpu()
     ref = ref if isinstance(ref, torch.Tensor) else torch.from_numpy(ref)
     assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
     assert torch.isfinite(got).all(), f"{name}: non-finite output"
     err = (got - ref).abs().max().item()
-    bound = tol * max(1.0, ref.abs().max().item())
+    top = ref.abs().max().item()
+    bound = (tol if top <= 10.0 else 0.1 * tol * top) if absolute else tol * max(1.0, top)
     assert err <= bound, f"{name}: max|d| = {err:.3e} > {bound:.3e}"
     return err
 
@@ -282,7 +287,7 @@ def test_full_forward_odd_feature_map(cuda):
         got = m(c.to(cuda), s.to(cuda), 1)
         ref = O.full_forward(c, s, 1, swin_sd, st_sd, dec_sd)
     assert got.shape == ref.shape == (1, 3, 264, 136)
-    assert_close(got, ref, "full forward 260x132")
+    assert_close(got, ref, "full forward 260x132", absolute=True)
 
 
 @pytest.mark.parametrize("B,S,k", [(1, 256, 1), (2, 256, 1), (1, 256, 3), (1, 512, 1), (1, 64, 1), (1, 200, 1)])
@@ -295,7 +300,7 @@ def test_full_forward_vs_oracle(cuda, B, S, k):
         got = m(c.to(cuda), s.to(cuda), k)
         ref = O.full_forward(c, s, k, swin_sd, st_sd, dec_sd)
     assert got.shape == (B, 3, S, S) and got.dtype == torch.float32
-    err = assert_close(got, ref, f"full forward B{B} S{S} k{k}")
+    err = assert_close(got, ref, f"full forward B{B} S{S} k{k}", absolute=True)
     print(f"full forward B={B} S={S} k={k}: max|d| = {err:.2e}, ref max {ref.abs().max():.2f}")
 
 
@@ -318,11 +323,32 @@ def test_full_batch_32_properties(cuda, mode):
         for i in (5, 31):
             ref = O.full_forward(c[i:i + 1].cpu(), s[i:i + 1].cpu(), 1, swin_sd, st_sd, dec_sd)
             if mode == "fp32":
-                assert_close(full[i:i + 1], ref, f"sample {i} of the bs=32 batch")
+                assert_close(full[i:i + 1], ref, f"sample {i} of the bs=32 batch", absolute=True)
             else:
                 l2 = float((full[i:i + 1].cpu() - ref).norm() / ref.norm())
                 mx = float((full[i:i + 1].cpu() - ref).abs().max() / ref.abs().max())
                 assert l2 < 2.5e-2 and mx < 0.05, (i, l2, mx)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "x3"])
+def test_config5_full_size(cuda, mode):
+    """BASELINE configs[4] at its own size: bs = 16, 512 x 512, fp32 (exact-fp32 mode, and the split-bf16 fast parity mode) - bitwise
+    determinism, per-sample batch independence, and two samples of the batch against the CPU oracle at the literal 1e-3 max-abs
+    (r03 covered this configuration at B = 1 only)."""
+    m, (swin_sd, st_sd, dec_sd) = full_model(cuda)
+    m.set_compute_dtype(torch.float32 if mode == "fp32" else "bf16x3")
+    c = seeded_input("c5", (16, 3, 512, 512), 12, kind="image").to(cuda)
+    s = seeded_input("s5", (16, 3, 512, 512), 13, kind="image").to(cuda)
+    with torch.no_grad():
+        full = m(c, s, 1)
+        assert full.shape == (16, 3, 512, 512) and full.dtype == torch.float32
+        assert torch.equal(full, m(c, s, 1)), "forward is not deterministic"
+        for i in (0, 15):
+            assert torch.equal(m(c[i:i + 1], s[i:i + 1], 1), full[i:i + 1]), f"sample {i} depends on its batch"
+        for i in (3, 15):
+            ref = O.full_forward(c[i:i + 1].cpu(), s[i:i + 1].cpu(), 1, swin_sd, st_sd, dec_sd)
+            err = assert_close(full[i:i + 1], ref, f"sample {i} of the bs=16 512x512 batch ({mode})", absolute=True)
+            print(f"config 5 {mode} sample {i}: max|d| = {err:.2e}, ref max {ref.abs().max():.2f}")
 
 
 @pytest.mark.gpu
@@ -532,3 +558,61 @@ def test_regular_mha_with_affine_norm_raises_like_the_reference(cuda):
     with pytest.raises(ValueError, match="to match num_features"):
         with torch.no_grad():
             m(torch.zeros(2, 8, 8, 64, device=cuda), torch.zeros(2, 8, 8, 64, device=cuda), 1)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "x3"])
+def test_bias_free_projections_equal_zero_biases(cuda, mode):
+    """qkv_bias = proj_bias = False (full_model.py:39-42): F.linear without a bias adds nothing and a zero-padded window slot's key /
+    value row is then zero - the same kernels with a zero bias row: the bias-free model equals, bit for bit, the default model whose
+    projection biases are zero and whose other weights are the same."""
+    from mastermetastyletransfer_amd import StyleTransformer
+    torch.manual_seed(2)
+    nb = StyleTransformer(256, 256, 8, 8, [7, 7], [7, 7], [4, 4], [4, 4], encoder_qkv_bias=False, decoder_qkv_bias=False,
+                          encoder_proj_bias=False, decoder_proj_bias=False)
+    wb = StyleTransformer(256, 256, 8, 8, [7, 7], [7, 7], [4, 4], [4, 4])
+    sd = wb.state_dict()
+    for k, v in nb.state_dict().items():
+        sd[k] = v.clone()
+    for k in sd:
+        if k.endswith(".bias") and k.split(".")[-2] in ("Wq", "Wk", "Wv", "Wv_scale", "Wv_shift", "proj"):
+            sd[k] = torch.zeros_like(sd[k])
+    wb.load_state_dict(sd)
+    nb, wb = nb.to(cuda).eval(), wb.to(cuda).eval()
+    for m in (nb, wb):
+        for sub in m.modules():
+            if hasattr(sub, "compute_dtype"):
+                sub.compute_dtype = torch.bfloat16 if mode == "bf16" else torch.float32
+                sub.split_weights = mode == "x3"
+    g = torch.Generator().manual_seed(3)
+    fc, fs = torch.randn(2, 19, 23, 256, generator=g).to(cuda), torch.randn(2, 19, 23, 256, generator=g).to(cuda)       # padded map: pad rows matter
+    with torch.no_grad():
+        a, b = nb(fc, fs, 2), wb(fc, fs, 2)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_relu_mlp_activation(cuda):
+    """MLP_activation_layer = nn.ReLU (full_model.py:47-50; torchvision MLP(activation_layer=...)): block output = attention half + W2 relu(W1
+    LN2(.) + b1) + b2, composed here from the same block without its MLP and torch arithmetic"""
+    from mastermetastyletransfer_amd import StyleSwinTransformerBlock
+    from torch import nn
+    torch.manual_seed(4)
+    blk = StyleSwinTransformerBlock(256, 8, [7, 7], [4, 4], MLP_activation_layer=nn.ReLU)
+    half = StyleSwinTransformerBlock(256, 8, [7, 7], [4, 4], exclude_MLP_after=True)
+    half.load_state_dict({k: v for k, v in blk.state_dict().items() if k in half.state_dict()})
+    blk, half = blk.to(cuda).eval(), half.to(cuda).eval()
+    x = torch.randn(2, 14, 14, 256, generator=torch.Generator().manual_seed(5)).to(cuda)
+    with torch.no_grad():
+        got = blk(x, x, x)
+        a = half(x, x, x).cpu().double()
+        w = {k: v.cpu().double() for k, v in blk.state_dict().items()}
+        h = F.relu(F.linear(F.layer_norm(a, (256,), w["norm2.weight"], w["norm2.bias"], 1e-5), w["mlp.0.weight"], w["mlp.0.bias"]))
+        ref = a + F.linear(h, w["mlp.3.weight"], w["mlp.3.bias"])
+    assert_close(got, ref.float(), "block with a ReLU MLP", 1e-4)
+    for mode in ("bf16", "x3"):
+        for sub in blk.modules():
+            if hasattr(sub, "compute_dtype"):
+                sub.compute_dtype = torch.bfloat16 if mode == "bf16" else torch.float32
+                sub.split_weights = mode == "x3"
+        with torch.no_grad():
+            got = blk(x, x, x)
+        assert_close(got, ref.float(), f"block with a ReLU MLP ({mode})", 3e-2 if mode == "bf16" else 1e-4)
