@@ -44,9 +44,10 @@ enum master_dtype {
     MASTER_F32 = 0, MASTER_BF16 = 1,
     /* fp32 storage, contractions as three bf16 MFMAs per product on split operands (x = hi + lo, a*w = a_lo*w_hi + a_hi*w_lo +
      * a_hi*w_hi, fp32 accumulation): the parity-grade FAST mode - 1.2e-4 max-abs on the stylized image against the fp32 CPU path
-     * (bar 1e-3) at 5.3x the matrix-core rate of the exact-fp32 form.  Accepted by master_linear_fwd and
-     * master_conv3x3_reflect_fwd; activations, bias, residuals and outputs are fp32 exactly as with MASTER_F32, the WEIGHT operand
-     * must have gone through master_split_weights.  Every other kernel of this mode runs with MASTER_F32. */
+     * (bar 1e-3) at 5.3x the matrix-core rate of the exact-fp32 form.  Accepted by master_linear_fwd, master_conv3x3_reflect_fwd and
+     * master_mlp_fwd (activations, bias, residuals and outputs fp32 exactly as with MASTER_F32, the WEIGHT operand must have gone through
+     * master_split_weights) and by master_window_attn_fwd (all operands fp32: Q, K, V and the probabilities are split in registers).
+     * Every other kernel of this mode runs with MASTER_F32. */
     MASTER_F32X3 = 2
 };
 /* OR-ed into the `dtype` argument of master_linear_wgrad / master_colsum / master_layernorm_bwd: the parameter gradient is ADDED to

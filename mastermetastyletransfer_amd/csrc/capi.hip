@@ -69,7 +69,7 @@ int stats_slices(int HW);
 template <typename T> int in_dist_launch(const void*, const float*, const float*, float*, int, int, int, int, float, int, hipStream_t);
 int window_attn_f32(const float*, const float*, const float*, const float*, int, int, int, const float*, const float*,
                     const float*, int, int, const float*, const int32_t*, const uint8_t*, float*, float*, int, int,
-                    int, int, int, int, float, hipStream_t);
+                    int, int, int, int, float, hipStream_t, int x3 = 0);
 int gemm_bf16_linear(const bf16_t*, const bf16_t*, const float*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int,
                      int, int, int, int, hipStream_t);
 int gemm_bf16_conv3x3(const bf16_t*, const bf16_t*, const float*, void*, int, int, int, int, int, int, int, int,
@@ -763,16 +763,16 @@ int master_window_attn_fwd(const void* q, const void* k, const void* v0, const v
     REQUIRE(k_pad && v0_pad, "window_attn: pad rows are required (pass the projection bias)");
     REQUIRE((v1 == nullptr) == (out1 == nullptr) && (v1 == nullptr || v1_pad), "window_attn: v1/out1/v1_pad must come together");
     REQUIRE(B > 0 && T > 0 && heads > 0 && nW > 0 && N > 0 && N <= 64, "window_attn: window of %d tokens unsupported (max 64)", N);
-    const int ea = dtype == MASTER_F32 ? 4 : 8;
+    const int ea = dtype == MASTER_BF16 ? 8 : 4;
     REQUIRE(ldq % ea == 0 && ldk % ea == 0 && ldv % ea == 0 && ldo % ea == 0, "window_attn: leading dims must be multiples of %d", ea);
     REQUIRE(al16(q) && al16(k) && al16(v0) && al16(out0) && al16(k_pad) && al16(bias), "window_attn: operands must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_ATTN, s);
-    if (dtype == MASTER_F32)
+    if (dtype == MASTER_F32 || dtype == MASTER_F32X3)       // F32X3: fp32 tensors, both products as three bf16 MFMAs on split operands
         return window_attn_f32((const float*)q, (const float*)k, (const float*)v0, (const float*)v1, ldq, ldk, ldv,
                                (const float*)k_pad, (const float*)v0_pad, (const float*)v1_pad, k_pad_bstride,
                                v_pad_bstride, bias, src, region, (float*)out0, (float*)out1, ldo, B, T, heads, nW, N,
-                               scale, s);
+                               scale, s, dtype == MASTER_F32X3);
     if (dtype == MASTER_BF16) {
         // persistent window-per-workgroup kernel for 8-head maps (StyleTransformer, Swin stage 2); one-problem-per-wave otherwise
         const int rc = window_attn_pw_bf16((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v0, (const bf16_t*)v1, ldq, ldk, ldv,

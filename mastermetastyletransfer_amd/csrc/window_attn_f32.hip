@@ -10,6 +10,13 @@
 // is a per-window gather table; zero-padded slots take the projection bias as their K/V row because
 // the reference pads before the Linear.  Outputs are written back un-windowed, for real tokens only
 // (reverse partition/roll/un-pad, :160-168).
+//
+// X3 (the split-bf16 fast parity mode, MASTER_F32X3; r04): the same dataflow with both products on v_mfma_f32_32x32x16_bf16 - every
+// operand split in registers into bf16 hi + lo, three MFMAs per product (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi), fp32 accumulation:
+// 24 + 24 MFMAs of 32 clocks per problem instead of 64 + 64 of 64 clocks (the exact-fp32 form spends ~40 % of its time in the matrix
+// pipe).  The channel k order (lane half h holds channels 16h + 8s' + j for k-step s') is the same for K and Q, so it cancels; the
+// packed probability tile IS the B fragment of the second product, whose k order (keys 16s + 4h + 0..3, 16s + 8 + 4h + 0..3) is the
+// order the V^T registers already have.  Softmax, bias, mask and the normalisation stay fp32.
 #include "common.h"
 
 namespace {
@@ -29,7 +36,21 @@ struct AttnArgs {
 
 constexpr float LOG2E = 1.4426950408889634f;
 
-template <bool DUAL>
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+union FragX { u32x4 u; bf16x8_t b; };
+
+// 8 fp32 -> the bf16 hi and lo fragments (round to nearest even both times)
+__device__ __forceinline__ void split_frag(const float (&x)[8], FragX& hi, FragX& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned a = pack_bf16x2(x[2 * j], x[2 * j + 1]);
+        hi.u[j] = a;
+        lo.u[j] = pack_bf16x2(x[2 * j] - __uint_as_float(a << 16), x[2 * j + 1] - __uint_as_float(a & 0xffff0000u));
+    }
+}
+
+template <bool DUAL, bool X3>
 __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -116,6 +137,32 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
                 }
         }
     }
+    if constexpr (X3) {
+        FragX kh[2][2], kl[2][2], qh[2][2], ql[2][2];                     // [tile][k-step s']: channels 16h + 8s' .. +8
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                float kx[8], qx[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    kx[j] = kv[t][2 * sp + (j >> 2)][j & 3];
+                    qx[j] = qv[t][2 * sp + (j >> 2)][j & 3] * p.scale_log2e;
+                }
+                split_frag(kx, kh[t][sp], kl[t][sp]);
+                split_frag(qx, qh[t][sp], ql[t][sp]);
+            }
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    st[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[kt][sp].b, qh[qt][sp].b, st[kt][qt], 0, 0, 0);
+                    st[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[kt][sp].b, ql[qt][sp].b, st[kt][qt], 0, 0, 0);
+                    st[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[kt][sp].b, qh[qt][sp].b, st[kt][qt], 0, 0, 0);
+                }
+    } else {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -126,6 +173,7 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
                 for (int qt = 0; qt < 2; ++qt)
                     st[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[kt][c][e], qv[qt][c][e] * p.scale_log2e,
                                                                       st[kt][qt], 0, 0, 0);
+    }
 
     if constexpr (DUAL) load_v(p.v1, p.v1_pad, vv1);      // second value stream: requested once the Q / K registers are free, lands under the softmax
 
@@ -154,12 +202,46 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
 
     // ---- O^T[d][q] = sum_key V^T[d][key] P^T[key][q]; k-step (kt, reg) covers keys
     //      kt*32 + (reg&3) + 8*(reg>>2) + 4*half, exactly the rows the accumulator register holds.
+    // X3: the probabilities as bf16 hi / lo B fragments, built once (both value streams use them): fragment (kt, qt, s) = registers
+    // 8s .. 8s+7 of st[kt][qt]
+    FragX ph[2][2][2], pl[2][2][2];
+    if constexpr (X3) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    float px[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) px[j] = st[kt][qt][8 * sp + j];
+                    split_frag(px, ph[kt][qt][sp], pl[kt][qt][sp]);
+                }
+    }
     auto pv = [&](const float (&vv)[2][16], float* out) {
         f32x16 o[2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[qt][e] = 0.0f;
+        if constexpr (X3) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    float vx[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) vx[j] = vv[kt][8 * sp + j];
+                    FragX vh, vl;
+                    split_frag(vx, vh, vl);
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) {
+                        o[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl.b, ph[kt][qt][sp].b, o[qt], 0, 0, 0);
+                        o[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh.b, pl[kt][qt][sp].b, o[qt], 0, 0, 0);
+                        o[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh.b, ph[kt][qt][sp].b, o[qt], 0, 0, 0);
+                    }
+                }
+        } else {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -167,6 +249,7 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt)
                     o[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[kt][e], st[kt][qt][e], o[qt], 0, 0, 0);
+        }
         // o[qt][e]: query = qt*32 + r (lane), channel d = (e&3) + 8*(e>>2) + 4*h  -> 4 x 16-B stores
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
@@ -191,12 +274,17 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
 int window_attn_f32(const float* q, const float* k, const float* v0, const float* v1, int ldq, int ldk, int ldv,
                     const float* k_pad, const float* v0_pad, const float* v1_pad, int k_pad_bs, int v_pad_bs,
                     const float* bias, const int32_t* src, const uint8_t* region, float* out0, float* out1, int ldo,
-                    int B, int T, int heads, int nW, int N, float scale, hipStream_t s) {
+                    int B, int T, int heads, int nW, int N, float scale, hipStream_t s, int x3) {
     AttnArgs p{q, k, v0, v1, ldq, ldk, ldv, k_pad, v0_pad, v1_pad, k_pad_bs, v_pad_bs, bias, src, region,
                out0, out1, ldo, B, T, heads, nW, N, scale * LOG2E};
     const int total = B * nW * heads;
     const int grid = (total + 3) / 4;
-    if (v1) hipLaunchKernelGGL(window_attn_f32_kernel<true>, dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(window_attn_f32_kernel<false>, dim3(grid), dim3(256), 0, s, p);
+    if (x3) {
+        if (v1) hipLaunchKernelGGL((window_attn_f32_kernel<true, true>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((window_attn_f32_kernel<false, true>), dim3(grid), dim3(256), 0, s, p);
+    } else {
+        if (v1) hipLaunchKernelGGL((window_attn_f32_kernel<true, false>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((window_attn_f32_kernel<false, false>), dim3(grid), dim3(256), 0, s, p);
+    }
     return master_check_launch("window_attn_f32");
 }

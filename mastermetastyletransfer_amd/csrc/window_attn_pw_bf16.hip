@@ -41,6 +41,11 @@ struct PwArgs {
 
 union Frag { u32x4 u; bf16x8_t b; };
 
+#ifdef PW_CLOCK_PROBE     // diagnostic build only (profiles/tools/pw_probe.py): s_memtime around the QK^T MFMAs of every (window, head), per wave
+__device__ unsigned long long* g_pw_probe = nullptr;           // [grid * 4 waves][6]: QK^T clocks, QK^T + bias clocks, windows, wave clocks, wave time (100 MHz ticks), -
+#define PW_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
+
 template <bool DUAL>
 __global__ __launch_bounds__(HPW * 64, 2) void window_attn_pw_kernel(PwArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // Q | K | V0 | (V1) tiles, then src[nW][64] i32, region[nW][64] u8
@@ -136,6 +141,11 @@ __global__ __launch_bounds__(HPW * 64, 2) void window_attn_pw_kernel(PwArgs p) {
     if (win < nwin) gather(win);
 
     const int g16 = (lane >> 4) & 1, i16 = lane & 15;
+#ifdef PW_CLOCK_PROBE
+    unsigned long long pw_qk = 0, pw_qkb = 0, pw_n = 0, pw_t0, pw_t1, pw_t2, pw_k0;
+    const unsigned long long pw_r0 = __builtin_amdgcn_s_memrealtime();
+    PW_STAMP(pw_k0);
+#endif
     const float mask_raw = -100.0f * LOG2E / p.scale_log2e;              // the -100 of the shift mask in raw q.k units
     Frag ones; ones.u = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // bf16 1.0 x 8
     for (; win < nwin; win += wstride) {
@@ -180,6 +190,36 @@ __global__ __launch_bounds__(HPW * 64, 2) void window_attn_pw_kernel(PwArgs p) {
 
         // ---- 2. S^T[key][query] = K Q^T, scaled, + bias + shift mask -----------------------------------------------------
         f32x16 st[2][2];
+#ifdef PW_CLOCK_PROBE
+        // the named GEMM alone: the 8 MFMAs of S^T = K Q^T (4 tiles x 2 k-steps) back to back, a dependent read of the last accumulator
+        // register (issue stalls until the last MFMA has written it), stamp; then the 8 bias-through-identity MFMAs the same way
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) st[k2][q2][e] = 0.f;
+        PW_STAMP(pw_t0);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    st[k2][q2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[k2][s].b, qf[q2][s].b, st[k2][q2], 0, 0, 0);
+        { float sink; asm volatile("v_mov_b32 %0, %1" : "=v"(sink) : "v"(st[1][1][15])); asm volatile("" :: "v"(sink)); }
+        PW_STAMP(pw_t1);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    st[k2][q2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][q2][ks].b, idf[ks].b, st[k2][q2], 0, 0, 0);
+        { float sink; asm volatile("v_mov_b32 %0, %1" : "=v"(sink) : "v"(st[1][1][15])); asm volatile("" :: "v"(sink)); }
+        PW_STAMP(pw_t2);
+        pw_qk += pw_t1 - pw_t0; pw_qkb += pw_t2 - pw_t0; ++pw_n;
+#else
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
@@ -193,6 +233,7 @@ __global__ __launch_bounds__(HPW * 64, 2) void window_attn_pw_kernel(PwArgs p) {
                 for (int ks = 0; ks < 2; ++ks)                             // + bias / scale, through the identity
                     st[k2][q2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[k2][q2][ks].b, idf[ks].b, st[k2][q2], 0, 0, 0);
             }
+#endif
         // the shift mask only bites in windows that straddle a region boundary: when all 64 slots carry the same region id
         // (interior windows) nothing is masked and the per-element test is skipped (wave-uniform branch)
         bool mixed = false;
@@ -280,9 +321,20 @@ __global__ __launch_bounds__(HPW * 64, 2) void window_attn_pw_kernel(PwArgs p) {
         pv_store(vf0, p.out0);
         if (DUAL) pv_store(vf1, p.out1);
     }
+#ifdef PW_CLOCK_PROBE
+    if (lane == 0 && g_pw_probe) {
+        unsigned long long pw_k1; PW_STAMP(pw_k1);
+        unsigned long long* dst = g_pw_probe + ((size_t)blockIdx.x * HPW + wave) * 6;
+        dst[0] = pw_qk; dst[1] = pw_qkb; dst[2] = pw_n; dst[3] = pw_k1 - pw_k0; dst[4] = __builtin_amdgcn_s_memrealtime() - pw_r0;
+    }
+#endif
 }
 
 }  // namespace
+
+#ifdef PW_CLOCK_PROBE
+extern "C" int master_pw_probe_buffer(void* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_pw_probe), &buf, sizeof(buf)) == hipSuccess ? 0 : -1; }
+#endif
 
 // returns MASTER_ERR_UNSUPPORTED when the geometry is outside this kernel (caller falls back to window_attn_bf16)
 int window_attn_pw_bf16(const bf16_t* q, const bf16_t* k, const bf16_t* v0, const bf16_t* v1, int ldq, int ldk, int ldv,

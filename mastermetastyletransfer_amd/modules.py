@@ -180,7 +180,7 @@ class _WindowAttentionBase(_HipModule):
         v1 = vs[1] if len(vs) > 1 else None
         o0, o1 = ops.window_attn(q, k, vs[0], v1, k_pad, v_pads[0], v_pads[1] if v1 is not None else None,
                                  self._bias64(), plan.src, plan.region, B, H * W, self.num_heads, plan.nW, plan.N,
-                                 HEAD_DIM ** -0.5)
+                                 HEAD_DIM ** -0.5, x3=self.split_weights)
         return [o0] if v1 is None else [o0, o1]
 
 

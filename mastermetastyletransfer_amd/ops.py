@@ -412,8 +412,9 @@ def decoder_tail(x: torch.Tensor, w8, b8, w9, b9) -> torch.Tensor:
 
 @_on_device
 def window_attn(q, k, v0, v1, k_pad, v0_pad, v1_pad, bias64, src, region, B: int, T: int, heads: int, nW: int, N: int,
-                scale: float):
-    """q/k/v*: [B*T, heads*32] views (row stride free).  Returns out0 (and out1 when v1 is given), [B*T, heads*32]."""
+                scale: float, x3: bool = False):
+    """q/k/v*: [B*T, heads*32] views (row stride free).  Returns out0 (and out1 when v1 is given), [B*T, heads*32].
+    x3 (fp32 tensors): both products as three bf16 MFMAs on operands split in registers (the F32X3 fast parity mode)."""
     _dev(q, k, v0)
     C = heads * 32
     out0 = torch.empty((B * T, C), dtype=q.dtype, device=q.device)
@@ -427,7 +428,8 @@ def window_attn(q, k, v0, v1, k_pad, v0_pad, v1_pad, bias64, src, region, B: int
                bytes=q.element_size() * B * T * C * (2 + 2 * nv))
     _check(load_library().master_window_attn_fwd(
         _p(q), _p(k), _p(v0), _p(v1), q.stride(0), k.stride(0), v0.stride(0), _p(k_pad), _p(v0_pad), _p(v1_pad),
-        kbs, vbs, _p(bias64), _p(src), _p(region), _p(out0), _p(out1), C, B, T, heads, nW, N, float(scale), _dt(q),
+        kbs, vbs, _p(bias64), _p(src), _p(region), _p(out0), _p(out1), C, B, T, heads, nW, N, float(scale),
+        F32X3 if (x3 and q.dtype == torch.float32 and os.environ.get("MASTER_ATTN_X3", "1") != "0") else _dt(q),
         _stream()), "master_window_attn_fwd")
     return out0, out1
 

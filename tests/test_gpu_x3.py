@@ -145,6 +145,31 @@ def test_split_weights_layout1(cuda):
     assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
 
 
+@pytest.mark.parametrize("dual", [False, True])
+@pytest.mark.parametrize("H,W,shift", [(14, 14, (4, 4)), (9, 11, (4, 4)), (7, 7, (4, 4)), (32, 32, (3, 3))])
+def test_window_attention_x3_vs_exact_fp32(cuda, H, W, shift, dual):
+    """master_window_attn_fwd with MASTER_F32X3 (split-bf16 products, fp32 softmax) against the exact-fp32 kernel on the same operands:
+    padded windows (bias rows as keys), shift masks, one and two value streams"""
+    from mastermetastyletransfer_amd import ops
+    from mastermetastyletransfer_amd.window_plan import window_plan
+    heads, B = 8, 3
+    C = heads * 32
+    g = torch.Generator().manual_seed(H * 100 + W)
+    T = H * W
+    qkv = (torch.randn(B * T, 4 * C, generator=g) * 1.5).to(cuda)
+    pads = (torch.randn(3, C, generator=g)).to(cuda)
+    bias64 = torch.zeros(heads, 64, 64); bias64[:, :, 49:] = -1e30; bias64[:, :49, :49] = torch.randn(heads, 49, 49, generator=g) * 0.5
+    bias64 = bias64.to(cuda)
+    plan = window_plan(H, W, [7, 7], list(shift), cuda)
+    args = (qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:3 * C], qkv[:, 3 * C:] if dual else None, pads[0], pads[1], pads[2] if dual else None,
+            bias64, plan.src, plan.region, B, T, heads, plan.nW, plan.N, 32 ** -0.5)
+    ref = ops.window_attn(*args)
+    got = ops.window_attn(*args, x3=True)
+    for a, b in zip(got, ref):
+        if b is not None:
+            assert rel_err(a, b.double().cpu()) < 5e-5
+
+
 def test_conv_chain_in_split_layout(cuda):
     """two convolutions handing the map over in the split layout (MASTER_OUT_SPLIT -> MASTER_A_SPLIT) against the same two through fp32:
     hi + lo carries the map to 2^-17, so the chains agree to the kernel tolerance; the split map itself is checked element by element"""
