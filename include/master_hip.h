@@ -120,8 +120,9 @@ int master_conv3x3_reflect_fwd(const void* x, const void* w, const void* bias, v
 /* Decoder tail in one launch: nearest x2 upsample -> Conv3x3(32->32, reflect) + ReLU -> Conv3x3(32->3, reflect).
  * x: NHWC [B,Hs,Ws,32]; w8 [32][3][3][32], w9 [3][3][3][32] repacked like master_conv3x3_reflect_fwd; b8, b9 fp32;
  * out: fp32 NCHW [B,3,2Hs,2Ws] (the model output).  The 32-channel full-resolution intermediate never leaves LDS.
- * Replaces the last four layers of decoder.py:47-54.  MASTER_BF16 only, 2Hs % 16 == 0 and 2Ws % 32 == 0
- * (MASTER_ERR_UNSUPPORTED otherwise: callers then use two master_conv3x3_reflect_fwd calls). */
+ * Replaces the last four layers of decoder.py:47-54.  MASTER_BF16: 2Hs % 16 == 0 and 2Ws % 32 == 0.  MASTER_F32X3: x fp32 NHWC or, with
+ * MASTER_A_SPLIT OR-ed in, in the split layout; w8, w9 = master_split_weights of the [32, 288] / [3, 288] matrices; 2Hs % 8 == 0 and
+ * 2Ws % 32 == 0.  (MASTER_ERR_UNSUPPORTED otherwise, and for MASTER_F32: callers then use two master_conv3x3_reflect_fwd calls). */
 int master_decoder_tail_fwd(const void* x, const void* w8, const float* b8, const void* w9, const float* b9, float* out,
                             int B, int Hs, int Ws, int dtype, master_stream_t stream);
 

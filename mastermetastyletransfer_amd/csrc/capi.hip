@@ -102,6 +102,7 @@ int mlp_c128_bf16(const bf16_t*, const float*, const float*, const bf16_t*, cons
                   const bf16_t*, bf16_t*, int, int, int, int, int, int, float, hipStream_t);
 
 int gemm_x3_split_weights(const float*, void*, size_t, size_t, int, hipStream_t);
+int conv_tail_x3(const void*, int, const void*, const float*, const void*, const float*, float*, int, int, int, hipStream_t);
 int mlp_x3(const float*, const float*, const float*, const void*, const float*, const void*, const float*, const float*, float*, int, int, int, int, int, int,
            float, hipStream_t);
 int gemm_x3_linear(const float*, const void*, const float*, const float*, const float*, float*, int, int, int, int, int, int, int, hipStream_t,
@@ -748,6 +749,11 @@ int master_decoder_tail_fwd(const void* x, const void* w8, const float* b8, cons
                             int B, int Hs, int Ws, int dtype, master_stream_t stream) {
     REQUIRE(x && w8 && b8 && w9 && b9 && out, "decoder_tail: null operand");
     REQUIRE(B > 0 && Hs > 0 && Ws > 0 && al16(x) && al16(w8) && al16(w9), "decoder_tail: bad dims/alignment");
+    if ((dtype & ~MASTER_A_SPLIT) == MASTER_F32X3) {           // split-bf16 fast parity mode: x fp32 NHWC, or (MASTER_A_SPLIT) in the split layout
+        hipStream_t s3 = (hipStream_t)stream;
+        ProfScope ps3(MASTER_K_DECODER_TAIL, s3);
+        return conv_tail_x3(x, (dtype & MASTER_A_SPLIT) != 0, w8, b8, w9, b9, out, B, Hs, Ws, s3);
+    }
     if (dtype != MASTER_BF16) { master_set_error("decoder_tail: fused kernel is bf16-only; use master_conv3x3_reflect_fwd in fp32 mode"); return MASTER_ERR_UNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_DECODER_TAIL, s);

@@ -730,9 +730,12 @@ class Decoder(_HipModule):
                                  lambda: torch.nn.functional.pad(conv.bias.detach().float(), (0, co - conv.out_channels)).contiguous())
         for i in self.CONV_IDX:
             conv = self.decoder[i]
-            if i == prev and prev in self.UPSAMPLE_BEFORE and ops.decoder_tail_supported(x, conv.out_channels):
-                # bf16 mode: Upsample + Conv(32->32) + ReLU + Conv(32->3) in one launch, intermediate kept in LDS
-                return ops.decoder_tail(x, packed(prev), self._b(f"conv{prev}", conv.bias), packed(last),
+            if i == prev and prev in self.UPSAMPLE_BEFORE and ops.decoder_tail_supported(x, conv.out_channels, self.split_weights):
+                # bf16 and split modes: Upsample + Conv(32->32) + ReLU + Conv(32->3) in one launch, intermediate kept in LDS
+                w_last = packed(last) if not self.split_weights else self._derived(
+                    f"conv{last}:split", [self.decoder[last].weight],
+                    lambda: ops.split_weights(self.decoder[last].weight.detach().permute(0, 2, 3, 1).contiguous()))
+                return ops.decoder_tail(x, packed(prev), self._b(f"conv{prev}", conv.bias), w_last,
                                         self._b(f"conv{last}", self.decoder[last].bias))
             # split mode: the maps between two x3 convolutions travel in the split layout (the consumer's LDS-DMA pieces copy them as they
             # lie: no split arithmetic, no LDS stores in its loop); the layer in front of the 3-channel last one writes fp32 for the direct kernel

@@ -389,8 +389,11 @@ def attn_block(x, ln_gamma, ln_beta, wqkv, bqkv, wproj, bproj, bias64, src, regi
     return out
 
 
-def decoder_tail_supported(x: torch.Tensor, cout_mid: int) -> bool:
-    if x.dim() != 4:              # a map in the split layout of the F32X3 mode
+def decoder_tail_supported(x: torch.Tensor, cout_mid: int, split: bool = False) -> bool:
+    if split:                     # F32X3 mode: fp32 NHWC [B,H,W,32] or a map in the split layout [B,H,W,1,2,32]; 8 x 32 output tiles
+        ok = (is_split_act(x) and x.shape[3] == 1) or (x.dim() == 4 and x.dtype == torch.float32 and x.shape[3] == 32)
+        return ok and cout_mid == 32 and (2 * x.shape[1]) % 8 == 0 and (2 * x.shape[2]) % 32 == 0 and os.environ.get("MASTER_X3_TAIL", "1") != "0"
+    if x.dim() != 4:
         return False
     B, H, W, C = x.shape
     return x.dtype == torch.bfloat16 and C == 32 and cout_mid == 32 and (2 * H) % 16 == 0 and (2 * W) % 32 == 0
@@ -398,14 +401,22 @@ def decoder_tail_supported(x: torch.Tensor, cout_mid: int) -> bool:
 
 @_on_device
 def decoder_tail(x: torch.Tensor, w8, b8, w9, b9) -> torch.Tensor:
-    """x NHWC [B,Hs,Ws,32] bf16 -> fp32 NCHW [B,3,2Hs,2Ws]: upsample, conv 32->32 + ReLU, conv 32->3 in one launch."""
+    """x NHWC [B,Hs,Ws,32] -> fp32 NCHW [B,3,2Hs,2Ws]: upsample, conv 32->32 + ReLU, conv 32->3 in one launch.  bf16 mode: x, w8, w9 bf16;
+    F32X3 mode: x fp32 or in the split layout, w8 / w9 = split_weights of the packed [32,3,3,32] / [3,3,3,32] weights."""
     _dev(x, w8, w9)
-    B, H, W, C = x.shape
-    assert x.is_contiguous() and w8.is_contiguous() and w9.is_contiguous() and w8.shape == (32, 3, 3, 32) and w9.shape == (3, 3, 3, 32)
+    B, H, W = x.shape[:3]
+    x3 = is_split(w8)
+    assert x.is_contiguous() and w8.is_contiguous() and w9.is_contiguous()
+    if x3:
+        assert is_split(w9) and w8.shape[:2] == (32, 9) and w9.shape[:2] == (3, 9)
+        dt = F32X3 | (A_SPLIT if is_split_act(x) else 0)
+    else:
+        assert w8.shape == (32, 3, 3, 32) and w9.shape == (3, 3, 3, 32)
+        dt = _dt(x)
     out = torch.empty((B, 3, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
     if _COUNT_ON:
-        _count("decoder_tail", flops=2.0 * B * 4 * H * W * 9 * 32 * (32 + 3), bytes=2.0 * x.numel() + 4.0 * out.numel())
-    _check(load_library().master_decoder_tail_fwd(_p(x), _p(w8), _p(b8), _p(w9), _p(b9), _p(out), B, H, W, _dt(x), _stream()),
+        _count("decoder_tail", flops=2.0 * B * 4 * H * W * 9 * 32 * (32 + 3), bytes=(4.0 if x3 else 2.0) * B * H * W * 32 + 4.0 * out.numel())
+    _check(load_library().master_decoder_tail_fwd(_p(x), _p(w8), _p(b8), _p(w9), _p(b9), _p(out), B, H, W, dt, _stream()),
            "master_decoder_tail_fwd")
     return out
 

@@ -48,5 +48,15 @@ for M, C, ln in [(32768, 256, 0), (32768, 256, 1), (65536, 256, 1), (262144, 128
     b1 = torch.randn(4 * C, device=dev) * 0.1; b2 = torch.randn(C, device=dev) * 0.1
     lg = torch.ones(C, device=dev) if ln else None; lb = torch.zeros(C, device=dev) if ln else None
     check(f"mlp M={M} C={C} ln{ln}", lambda: ops.mlp(x, w1, b1, w2, b2, res=x, ln_gamma=lg, ln_beta=lb))
+xt = torch.randn(32, 128, 128, 32, device=dev)
+w8 = ops.split_weights(torch.randn(32, 3, 3, 32, device=dev) / 17); w9 = ops.split_weights(torch.randn(3, 3, 3, 32, device=dev) / 17)
+b8 = torch.randn(32, device=dev) * 0.1; b9 = torch.randn(3, device=dev) * 0.1
+check("decoder tail 32x128x128 -> 256x256", lambda: ops.decoder_tail(xt, w8, b8, w9, b9))
+q = torch.randn(32 * 1024, 1024, device=dev); kp = torch.randn(3, 256, device=dev)
+from mastermetastyletransfer_amd.window_plan import window_plan
+plan = window_plan(32, 32, [7, 7], [4, 4], dev)
+b64 = torch.zeros(8, 64, 64, device=dev); b64[:, :, 49:] = -1e30
+check("window attention x3 dual", lambda: torch.cat(ops.window_attn(q[:, :256], q[:, 256:512], q[:, 512:768], q[:, 768:], kp[0], kp[1], kp[2], b64, plan.src, plan.region,
+                                                                     32, 1024, 8, plan.nW, plan.N, 32 ** -0.5, x3=True)))
 print("FAILED" if bad else "all repeatable")
 sys.exit(1 if bad else 0)

@@ -199,6 +199,29 @@ def test_conv_chain_in_split_layout(cuda):
     assert rel_err(o1f, o2.double().cpu()) < X3_KERNEL_TOL
 
 
+@pytest.mark.parametrize("B,Hs,Ws,split_in", [(2, 8, 16, False), (1, 12, 48, True), (3, 4, 16, True), (1, 64, 64, False)])
+def test_decoder_tail_x3(cuda, B, Hs, Ws, split_in):
+    """master_decoder_tail_fwd with MASTER_F32X3: upsample + conv 32->32 + ReLU + conv 32->3 in one launch against torch in float64; the
+    input map in fp32 and in the split layout; tiles at the image border (both reflect paddings), several tiles per image"""
+    from mastermetastyletransfer_amd import ops
+    g = torch.Generator().manual_seed(Hs * 7 + Ws)
+    x = torch.randn(B, 32, Hs, Ws, generator=g)
+    w8, b8 = torch.randn(32, 32, 3, 3, generator=g) / 17, torch.randn(32, generator=g) * 0.1
+    w9, b9 = torch.randn(3, 32, 3, 3, generator=g) / 17, torch.randn(3, generator=g) * 0.1
+    up = F.interpolate(x.double(), scale_factor=2, mode="nearest")
+    mid = F.relu(F.conv2d(F.pad(up, (1, 1, 1, 1), mode="reflect"), w8.double(), b8.double()))
+    ref = F.conv2d(F.pad(mid, (1, 1, 1, 1), mode="reflect"), w9.double(), b9.double())
+    xd = x.permute(0, 2, 3, 1).contiguous().to(cuda)
+    if split_in:      # a map in the split layout, as a previous convolution with out_split=True leaves it (hi | lo of every 32-channel pixel)
+        hi = xd.bfloat16(); lo = (xd - hi.float()).bfloat16()
+        xd = torch.stack([hi, lo], dim=3).view(B, Hs, Ws, 1, 2, 32).contiguous()
+    out = ops.decoder_tail(xd, ops.split_weights(w8.permute(0, 2, 3, 1).contiguous().to(cuda)), b8.to(cuda),
+                           ops.split_weights(w9.permute(0, 2, 3, 1).contiguous().to(cuda)), b9.to(cuda))
+    assert out.shape == (B, 3, 2 * Hs, 2 * Ws) and out.dtype == torch.float32
+    e = rel_err(out, ref)
+    assert e <= 2 * X3_KERNEL_TOL, f"decoder tail x3: {e:.3e}"
+
+
 def full_model(dev, seed=31):
     from mastermetastyletransfer_amd import MasterStyleTransferModel
     with warnings.catch_warnings():
