@@ -18,6 +18,7 @@
 //     (re-read from memory: exact) and stores are whole rows.
 // C = 256: 4 waves (one per SIMD, ~450 registers), 128 tokens per workgroup.  C = 128: 8 waves (two per SIMD), 256 tokens.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -33,8 +34,6 @@ struct MlpX3Args {
 };
 
 constexpr int SLOT = 32768;      // bytes per ring slot = one step of weights
-constexpr int RING = 4;
-constexpr int AHEAD = 3;         // steps of DMA in flight ahead of the one being consumed
 constexpr int HB = 64;           // hidden units per block
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
@@ -42,8 +41,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // PIPE (C = 256, one wave per SIMD, 512 registers): fragment reads pipelined by hand, the GELU of block hb dealt out between the MFMAs of
 // phase 1 of block hb + 1 (a second accumulator set).  !PIPE (C = 128, two waves per SIMD, 256 registers: no room for either): the
 // compiler schedules the reads, the GELU runs between the two phases, and the partner wave's MFMAs cover what that exposes.
-template <int C, int NW, bool PIPE>
-__global__ __launch_bounds__(NW * 64, 1) void mlp_x3_kernel(MlpX3Args p) {
+// RING slots of 32 KB, AHEAD = RING - 1 steps of DMA in flight.  C = 256: 4 slots, one workgroup per CU.  C = 128 (r04, second form): TWO
+// slots, four waves, 72 KB of LDS and 200 registers: two independent 128-token workgroups per CU (WGPC = 2) - nothing synchronises them, so
+// one's GELU burst, prologue (row loads, LayerNorm, split) and epilogue (transpose, residual, stores) run under the other's MFMAs,
+// which eight waves of ONE workgroup in lockstep at every step barrier could not do (probe: 28.7 k of 126 k clocks in the GELU with the
+// matrix cores idle, 27 k in prologue + epilogue).
+template <int C, int NW, bool PIPE, int RING, int WGPC>
+__global__ __launch_bounds__(NW * 64, WGPC) void mlp_x3_kernel(MlpX3Args p) {
+    constexpr int AHEAD = RING - 1;             // steps of DMA in flight ahead of the one being consumed
     constexpr int KS1 = C / 16;                 // k-steps of phase 1
     constexpr int NT2 = C / 32;                 // output-channel tiles of phase 2
     constexpr int P1 = C / 128;                 // phase-1 steps per hidden block: [64 rows][4 chunks] each
@@ -242,6 +247,13 @@ __global__ __launch_bounds__(NW * 64, 1) void mlp_x3_kernel(MlpX3Args p) {
         }
     };
 
+    // !PIPE forms: the pieces of the look-ahead step behind MFMA group `it` of 8.  With a two-slot ring (one step of look-ahead) a piece
+    // issued late in the step has not landed when the next step begins, so they go out two at a time in the first half of the step.
+    auto early_pieces = [&](int it) __attribute__((always_inline)) {
+        if (RING == 2) { if (2 * it < PPW) dma_piece(2 * it); if (2 * it + 1 < PPW) dma_piece(2 * it + 1); }
+        else if (PPW == 8) dma_piece(it);
+        else if ((it & 1) == 0) dma_piece(it >> 1);
+    };
     auto lds_ptr = [&](unsigned off) { return (const unsigned char*)(__attribute__((address_space(3))) unsigned char*)(size_t)off; };
     auto phase1_step = [&](unsigned slot, int i1, bool pipe) __attribute__((always_inline)) {
         if constexpr (!PIPE) {
@@ -260,7 +272,7 @@ __global__ __launch_bounds__(NW * 64, 1) void mlp_x3_kernel(MlpX3Args p) {
                     hacc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[jt].b, xl[s].b, hacc[jt], 0, 0, 0);
                     hacc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[jt].b, xh[s].b, hacc[jt], 0, 0, 0);
                     hacc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[jt].b, xh[s].b, hacc[jt], 0, 0, 0);
-                    if (jt == 0) { if (PPW == 8) dma_piece(it); else if ((it & 1) == 0) dma_piece(it >> 1); }
+                    if (jt == 0) early_pieces(it);
                 }
             }
             return;
@@ -313,7 +325,7 @@ __global__ __launch_bounds__(NW * 64, 1) void mlp_x3_kernel(MlpX3Args p) {
                     oacc[nt0 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh.b, hfl[jt][sg].b, oacc[nt0 + q], 0, 0, 0);
                     oacc[nt0 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl.b, hfh[jt][sg].b, oacc[nt0 + q], 0, 0, 0);
                     oacc[nt0 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh.b, hfh[jt][sg].b, oacc[nt0 + q], 0, 0, 0);
-                    if (q == 0) { if (PPW == 8) dma_piece(it); else if ((it & 1) == 0) dma_piece(it >> 1); }
+                    if (q == 0) early_pieces(it);
                 }
             }
             return;
@@ -454,13 +466,14 @@ __global__ __launch_bounds__(NW * 64, 1) void mlp_x3_kernel(MlpX3Args p) {
 #endif
 }
 
-template <int C, int NW, bool PIPE>
+template <int C, int NW, bool PIPE, int RING, int WGPC>
 int launch(const MlpX3Args& p, hipStream_t s) {
+    static_assert(NW * 32 * C * 4 <= RING * SLOT, "the epilogue's per-wave [32][C] fp32 tiles must fit in the ring");
     const size_t lds = (size_t)RING * SLOT + (size_t)(p.HID + 3 * C) * sizeof(float) + NW * 1024;
     if (lds > 160 * 1024) { master_set_error("mlp(x3): hidden width %d needs %zu B of LDS", p.HID, lds); return MASTER_ERR_UNSUPPORTED; }
     static LdsLimit lds_limit;
-    lds_limit.ensure((const void*)mlp_x3_kernel<C, NW, PIPE>, (int)lds);
-    hipLaunchKernelGGL((mlp_x3_kernel<C, NW, PIPE>), dim3((p.M + NW * 32 - 1) / (NW * 32)), dim3(NW * 64), lds, s, p);
+    lds_limit.ensure((const void*)mlp_x3_kernel<C, NW, PIPE, RING, WGPC>, (int)lds);
+    hipLaunchKernelGGL((mlp_x3_kernel<C, NW, PIPE, RING, WGPC>), dim3((p.M + NW * 32 - 1) / (NW * 32)), dim3(NW * 64), lds, s, p);
     return master_check_launch("mlp_x3");
 }
 
@@ -470,8 +483,12 @@ int mlp_x3(const float* x, const float* ln_g, const float* ln_b, const void* w1,
            const float* res, float* out, int M, int C, int HID, int ldx, int ldr, int ldo, float eps, hipStream_t s) {
     MlpX3Args p{x, ln_g, ln_b, (const unsigned char*)w1, b1, (const unsigned char*)w2, b2, res, out, M, HID, ldx, ldr, ldo, eps};
     if (HID % HB != 0) { master_set_error("mlp(x3): hidden width must be a multiple of 64 (got %d)", HID); return MASTER_ERR_UNSUPPORTED; }
-    if (C == 256) return launch<256, 4, true>(p, s);
-    if (C == 128) return launch<128, 8, false>(p, s);
+    if (C == 256) return launch<256, 4, true, 4, 1>(p, s);
+    if (C == 128) {
+        static int form = -1;                     // MASTER_MLP_X3_C128 = 8w: the first form (eight waves, 256 tokens, one workgroup per CU) for A/B runs
+        if (form < 0) { const char* e = getenv("MASTER_MLP_X3_C128"); form = (e && e[0] == '8') ? 1 : 0; }
+        return form ? launch<128, 8, false, 4, 1>(p, s) : launch<128, 4, false, 2, 2>(p, s);
+    }
     master_set_error("mlp(x3): channel width %d not built (128, 256)", C);
     return MASTER_ERR_UNSUPPORTED;
 }
