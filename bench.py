@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = the headline metric; train = BASELINE config 4: inner-loop train step bs=8 256x256 (fp32 mode), steps/s")
     ap.add_argument("--eager", action="store_true", help="enqueue kernel by kernel instead of replaying a HIP graph of the forward")
-    ap.add_argument("--loss-dtype", choices=["fp32", "bf16"], default="fp32", help="--mode train: compute dtype of the frozen VGG-19 loss network")
+    ap.add_argument("--loss-dtype", choices=["fp32", "bf16", "x3"], default="fp32", help="--mode train: compute dtype of the frozen VGG-19 loss network")
     ap.add_argument("--train-graph", type=int, default=int(os.environ.get("MASTER_TRAIN_GRAPH", "0")),
                     help="--mode train: 1 = replay one hipGraph per layer count k (graph.GraphedTrainStep), 0 = enqueue launch by launch")
     args = ap.parse_args()
@@ -414,6 +414,10 @@ def extras(model, content, style, k, args, ops):
         try:
             out["train_step"] = train_bench(content.device, steps=5, warmup=2)
             out["train_step"]["gradients_vs_float64_oracle"] = train_grad_check(content.device)
+            alt3 = train_bench(content.device, steps=5, warmup=2, roofline=False, loss_dtype="x3")
+            out["train_step"]["with_x3_loss_network"] = {"value": alt3["value"], "unit": "steps/s", "ms_per_step": alt3["ms_per_step"],
+                                                         "note": "frozen VGG-19 convolutions and data gradients as split-bf16 products on fp32 maps (custom_loss.set_compute_dtype('bf16x3')); "
+                                                                 "model, weight gradients and Adam fp32; its gradients against float64: gradients_vs_float64_oracle.with_x3_loss_network"}
             alt = train_bench(content.device, steps=5, warmup=2, roofline=False, loss_dtype="bf16")
             out["train_step"]["with_bf16_loss_network"] = {"value": alt["value"], "unit": "steps/s", "ms_per_step": alt["ms_per_step"],
                                                            "note": "frozen VGG-19 in bf16 (activations and data gradients); model, weight gradients and Adam fp32"}
@@ -462,7 +466,7 @@ def train_bench(device, steps=10, warmup=3, B=8, S=256, max_layers=4, roofline=T
         if isinstance(m_, torch.nn.Conv2d):
             torch.nn.init.kaiming_normal_(m_.weight, nonlinearity="relu"); torch.nn.init.normal_(m_.bias, std=0.05)
     loss_fn = custom_loss(default_lambda_value=10.0, vgg_state_dict=vgg.state_dict()).to(device)
-    loss_fn.set_compute_dtype(torch.float32 if loss_dtype == "fp32" else torch.bfloat16)     # the frozen loss network only; the model stays fp32
+    loss_fn.set_compute_dtype({"fp32": torch.float32, "bf16": torch.bfloat16, "x3": "bf16x3"}[loss_dtype])     # the frozen loss network only; the model stays fp32
     opt = FusedAdam([{"params": model.style_transformer.parameters()}, {"params": model.decoder.parameters()}], lr=1e-4, capturable=graph)
     content, style = synthetic_batch(B, S, device, seed=11)
     random.seed(0)
@@ -497,7 +501,8 @@ def train_bench(device, steps=10, warmup=3, B=8, S=256, max_layers=4, roofline=T
              + B * FWD_GFLOP["vgg"] + 2 * B * (k * FWD_GFLOP["st_layer"] + FWD_GFLOP["decoder"]) for k in kt)
     res = {"metric": "train steps/sec, inner-loop step (train-mode forward + VGG-19 perceptual loss + backward + Adam), bs=8 256x256",
            "value": round(steps / dt, 3), "unit": "steps/s", "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps, "warmup": warmup,
-           "dtype": "fp32" if loss_dtype == "fp32" else "fp32 model + bf16 frozen VGG-19 loss network", "images_per_s": round(B * steps / dt, 1),
+           "dtype": {"fp32": "fp32", "bf16": "fp32 model + bf16 frozen VGG-19 loss network",
+                     "x3": "fp32 model + split-bf16 (bf16x3, fp32 maps) frozen VGG-19 loss network"}[loss_dtype], "images_per_s": round(B * steps / dt, 1),
            "transformer_layer_counts": kt,
            "alg_tflop_per_step": round(gf / steps / 1e3, 3), "alg_tflops": round(gf / dt / 1e3, 2),
            "frac_of_fp32_mfma_peak": round(gf / dt / 1e3 / PEAK_TFLOPS["fp32"], 4), "final_loss": float(last.detach())}
@@ -558,24 +563,33 @@ def train_grad_check(device, B=8, S=256, k=2):
     for p in m.swin_encoder.parameters():
         p.requires_grad = False
     loss_fn = custom_loss(default_lambda_value=10.0, vgg_state_dict=vgg).to(device)
-    TF.sd_masks.set_masks(swin_masks + masks)
-    try:
-        out = m(c.to(device), s_.to(device), k)
-    finally:
-        TF.sd_masks.set_masks(None)
-    total = loss_fn(c.to(device), s_.to(device), out)
-    total.backward()
     named = [("style_transformer." + n, p) for n, p in m.style_transformer.named_parameters()] + [("decoder." + n, p) for n, p in m.decoder.named_parameters()]
     gscale = max(float(v.abs().max()) for v in ref64.values())
-    errs = []
-    for n, p in named:
-        if n not in ref64 or p.grad is None or float(ref64[n].abs().max()) <= 1e-6 * gscale:      # (three bias gradients are zero in exact arithmetic)
-            continue
-        errs.append((float((p.grad.cpu().double() - ref64[n]).abs().max()) / float(ref64[n].abs().max()), n))
-    errs.sort()
-    return {"config": f"B={B} {S}x{S} k={k}, explicit StochasticDepth masks, lambda 10", "tensors": len(errs), "worst_rel_to_tensor_max": round(errs[-1][0], 6),
-            "worst_tensor": errs[-1][1], "median": round(errs[len(errs) // 2][0], 6), "bound": 5e-3, "pass": bool(errs[-1][0] <= 5e-3),
-            "loss_hip": float(total.detach()), "loss_float64_oracle": float(losses64["total"]), "seconds": round(time.perf_counter() - t0, 1)}
+
+    def run(loss_mode):
+        loss_fn.set_compute_dtype(loss_mode)
+        for _, p in named:
+            p.grad = None
+        TF.sd_masks.set_masks(swin_masks + masks)
+        try:
+            out = m(c.to(device), s_.to(device), k)
+        finally:
+            TF.sd_masks.set_masks(None)
+        total = loss_fn(c.to(device), s_.to(device), out)
+        total.backward()
+        errs = []
+        for n, p in named:
+            if n not in ref64 or p.grad is None or float(ref64[n].abs().max()) <= 1e-6 * gscale:      # (three bias gradients are zero in exact arithmetic)
+                continue
+            errs.append((float((p.grad.cpu().double() - ref64[n]).abs().max()) / float(ref64[n].abs().max()), n))
+        errs.sort()
+        return {"tensors": len(errs), "worst_rel_to_tensor_max": round(errs[-1][0], 6), "worst_tensor": errs[-1][1],
+                "median": round(errs[len(errs) // 2][0], 6), "bound": 5e-3, "pass": bool(errs[-1][0] <= 5e-3), "loss_hip": float(total.detach())}
+    res = {"config": f"B={B} {S}x{S} k={k}, explicit StochasticDepth masks, lambda 10", **run(torch.float32),
+           "loss_float64_oracle": float(losses64["total"])}
+    res["with_x3_loss_network"] = run("bf16x3")
+    res["seconds"] = round(time.perf_counter() - t0, 1)
+    return res
 
 
 TRAIN_PMC_KERNELS = {"conv3x3": ("gemm_f32_dma_kernel<128, 128, 64, 64, true", "gemm_f32_dma_kernel<128, 64, 64, 32, true", "gemm_f32_dma_kernel<256, 32, 64, 32, true",

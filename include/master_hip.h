@@ -221,7 +221,7 @@ int master_patch_merge_linear_fwd(const void* x, const float* gamma, const float
  * master_image_to_nhwc_fwd: fp32 NCHW image [N,3,H,W] -> [N,H,W,Cpad], channels >= 3 zero (the first VGG conv runs with Cin = Cpad = 32
  *   and zero weights on the padding).
  * master_conv3x3_zero_fwd: nn.Conv2d(Cin, Cout, 3, padding=1) (+ReLU): the implicit GEMM of master_conv3x3_reflect_fwd with zero
- *   padding; w = [Cout][3][3][Cin], Cin % 32 == 0.
+ *   padding; w = [Cout][3][3][Cin], Cin % 32 == 0.  dtype = MASTER_F32X3: fp32 maps, w = master_split_weights of [Cout, 9*Cin].
  * master_maxpool2x2_fwd: nn.MaxPool2d(2, 2).
  * master_channel_stats_fwd: mean and BIASED variance over the HW positions of every (image, channel) (two passes, fp32):
  *   x.mean([2,3]); x.std([2,3]) = sqrt(var * HW / (HW-1)); the statistics of nn.InstanceNorm2d.  work = 2 * N * S * C floats of
@@ -354,7 +354,8 @@ int master_window_attn_bwd(const void* q, const void* k, const void* v0, const v
  * wf [Cx][3][3][Cg] (wf[ci][ty][tx][co] = weight[co][ci][2-ty][2-tx]).  full = 0: out [B,H,W,Cx] (zero-padded convolution: VGG-19,
  * loss.py:23-37).  full = 1: out [B,H+2,W+2,Cx] = the gradient on the padded domain (reflect-padded decoder convolutions,
  * decoder.py:24-54), folded back by master_fold_reflect.  Optional epilogue: out = relu_src > 0 ? acc + add : 0  (relu_src, add:
- * [.., Cx] like out; the ReLU backward of the layer below and a gradient joining there).  Cg % 32 == 0. */
+ * [.., Cx] like out; the ReLU backward of the layer below and a gradient joining there).  Cg % 32 == 0.
+ * dtype = MASTER_F32X3 (full = 0 only): g, relu_src, add, out fp32, wf = master_split_weights of the [Cx, 9*Cg] matrix. */
 int master_conv3x3_dgrad(const void* g, const void* wf, void* out, const void* relu_src, const void* add, int B, int H, int W, int Cg,
                          int Cx, int full, int dtype, master_stream_t stream);
 

@@ -109,6 +109,7 @@ int gemm_x3_linear(const float*, const void*, const float*, const float*, const 
                    int a_split, int out_split);
 int gemm_x3_conv3x3(const float*, const void*, const float*, float*, int, int, int, int, int, int, int, int, hipStream_t, int zero_pad, int a_split,
                     int out_split);
+int gemm_x3_conv3x3_dgrad(const float*, const void*, float*, const float*, const float*, int, int, int, int, int, hipStream_t);
 
 // ---- error string -------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -336,6 +337,12 @@ int master_conv3x3_dgrad(const void* g, const void* wf, void* out, const void* r
         hipStream_t sb = (hipStream_t)stream;
         ProfScope psb(MASTER_K_CONV_DGRAD, sb);
         return gemm_bf16_conv3x3_dgrad((const bf16_t*)g, (const bf16_t*)wf, (bf16_t*)out, (const bf16_t*)relu_src, (const bf16_t*)add, B, H, W, Cg, Cx, sb);
+    }
+    if (dtype == MASTER_F32X3) {         // the frozen loss network in split-bf16: fp32 gradients, wf = master_split_weights of the flipped weights
+        REQUIRE(full == 0 && B > 0 && H > 0 && W > 0 && Cg % 32 == 0 && Cx > 0 && al16(g) && al16(wf), "conv3x3_dgrad(x3): zero-padded form, Cg %% 32 == 0");
+        hipStream_t sx = (hipStream_t)stream;
+        ProfScope psx(MASTER_K_CONV_DGRAD, sx);
+        return gemm_x3_conv3x3_dgrad((const float*)g, wf, (float*)out, (const float*)relu_src, (const float*)add, B, H, W, Cg, Cx, sx);
     }
     F32_ONLY("conv3x3_dgrad");
     REQUIRE(B > 0 && H > 0 && W > 0 && Cg > 0 && Cg % 32 == 0 && Cx > 0 && (full == 0 || full == 1), "conv3x3_dgrad: bad dims (Cg=%d)", Cg);
@@ -697,6 +704,8 @@ int master_conv3x3_zero_fwd(const void* x, const void* w, const void* bias, void
         return gemm_f32_conv3x3((const float*)x, (const float*)w, (const float*)bias, (float*)out, B, H, W, Cin, Cout, 0, relu, 0, s, 1);
     if (dtype == MASTER_BF16)
         return gemm_bf16_conv3x3((const bf16_t*)x, (const bf16_t*)w, (const float*)bias, out, B, H, W, Cin, Cout, 0, relu, 0, s, 1);
+    if (dtype == MASTER_F32X3)           // fp32 maps, w = master_split_weights of the packed weights
+        return gemm_x3_conv3x3((const float*)x, w, (const float*)bias, (float*)out, B, H, W, Cin, Cout, 0, relu, 0, s, 1, 0, 0);
     master_set_error("conv3x3_zero: bad dtype %d", dtype);
     return MASTER_ERR_INVALID;
 }

@@ -36,6 +36,7 @@ struct X3Args {
     const float* a; const float* w; const float* bias; const float* r1; const float* r2; float* out;      // w: split weights, addressed in 4-byte units
     int M, N, K, lda, ldo, ldr, act;
     int Hin, Win, Cin, Hout, Wout, up, out_nchw, zero_pad;
+    int mask_relu;      // r1 is a ReLU output whose sign gates the result: out = r1 > 0 ? acc + r2 : 0 (data-gradient chain of the loss network)
     int out_split;      // the output goes out in the split layout (per row and 32-wide chunk 32 bf16 hi | 32 bf16 lo: what the next GEMM's A operand takes by LDS-DMA); N % 32 == 0
 };
 
@@ -130,8 +131,14 @@ __device__ __forceinline__ void x3_epilogue(const X3Args& p, f32x16 (&acc)[WM / 
 #pragma unroll
                     for (int c = 0; c < 4; ++c) x[c] = fmaxf(x[c], 0.0f);
                 }
-                if (p.r1) x *= a1[it];
-                if (p.r2) x += a2[it];
+                if (p.mask_relu) {
+                    if (p.r2) x += a2[it];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[c] = a1[it][c] > 0.0f ? x[c] : 0.0f;
+                } else {
+                    if (p.r1) x *= a1[it];
+                    if (p.r2) x += a2[it];
+                }
                 if (p.out_split) {
                     if (ok[it]) {
                         const unsigned h0 = pack_bf16x2(x[0], x[1]), h1 = pack_bf16x2(x[2], x[3]);
@@ -164,8 +171,13 @@ __device__ __forceinline__ void x3_epilogue(const X3Args& p, f32x16 (&acc)[WM / 
                 float v = acc[i][jn][e] + bv;
                 if (p.act == MASTER_ACT_GELU) v = gelu_erf(v);
                 else if (p.act == MASTER_ACT_RELU) v = fmaxf(v, 0.0f);
-                if (p.r1) v *= p.r1[(size_t)m * p.ldr + n];
-                if (p.r2) v += p.r2[(size_t)m * p.ldr + n];
+                if (p.mask_relu) {
+                    if (p.r2) v += p.r2[(size_t)m * p.ldr + n];
+                    if (!(p.r1[(size_t)m * p.ldr + n] > 0.0f)) v = 0.0f;
+                } else {
+                    if (p.r1) v *= p.r1[(size_t)m * p.ldr + n];
+                    if (p.r2) v += p.r2[(size_t)m * p.ldr + n];
+                }
                 if (CONV && p.out_nchw) {
                     const int b = m / hw_out, pix = m - b * hw_out;
                     p.out[((size_t)b * p.N + n) * hw_out + pix] = v;
@@ -665,7 +677,7 @@ int gemm_x3_split_weights(const float* w, void* out, size_t rows, size_t K, int 
 
 int gemm_x3_linear(const float* a, const void* w, const float* bias, const float* r1, const float* r2, float* out,
                    int M, int N, int K, int lda, int ldo, int ldr, int act, hipStream_t s, int a_split, int out_split) {
-    X3Args p{a, (const float*)w, bias, r1, r2, out, M, N, K, lda, ldo, ldr, act, 0, 0, 0, 1, 1, 0, 0, 0, out_split};
+    X3Args p{a, (const float*)w, bias, r1, r2, out, M, N, K, lda, ldo, ldr, act, 0, 0, 0, 1, 1, 0, 0, 0, 0, out_split};
     return a_split ? dispatch_s<false>(p, s) : dispatch<false>(p, s);
 }
 
@@ -673,6 +685,15 @@ int gemm_x3_conv3x3(const float* x, const void* w, const float* bias, float* out
                     int Cout, int up, int relu, int out_nchw, hipStream_t s, int zero_pad, int a_split, int out_split) {
     const int Hout = Hin << up, Wout = Win << up;
     X3Args p{x, (const float*)w, bias, nullptr, nullptr, out, B * Hout * Wout, Cout, 9 * Cin, 0, Cout, 0,
-             relu ? MASTER_ACT_RELU : MASTER_ACT_NONE, Hin, Win, Cin, Hout, Wout, up, out_nchw, zero_pad, out_split};
+             relu ? MASTER_ACT_RELU : MASTER_ACT_NONE, Hin, Win, Cin, Hout, Wout, up, out_nchw, zero_pad, 0, out_split};
     return a_split ? dispatch_s<true>(p, s) : dispatch<true>(p, s);
+}
+
+// data gradient of a zero-padded 3x3 convolution (the frozen loss network's chain, gemm_f32.hip's gemm_f32_conv3x3_dgrad in split-bf16):
+// g [B,H,W,Cg] fp32, wf = split [Cx][3][3][Cg] flipped weights; out = relu_src > 0 ? conv(g, wf) + add : 0  (relu_src / add optional)
+int gemm_x3_conv3x3_dgrad(const float* g, const void* wf, float* out, const float* relu_src, const float* add, int B, int H, int W,
+                          int Cg, int Cx, hipStream_t s) {
+    X3Args p{g, (const float*)wf, nullptr, relu_src, add, out, B * H * W, Cx, 9 * Cg, 0, Cx, Cx, MASTER_ACT_NONE, H, W, Cg, H, W, 0, 0, 1,
+             relu_src != nullptr, 0};
+    return dispatch<true>(p, s);
 }

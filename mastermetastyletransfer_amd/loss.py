@@ -43,18 +43,22 @@ class VGG19_custom(nn.Module):
             features = nn.Sequential(*layers)
         self.features = features
         self.compute_dtype = torch.float32
+        self.split_weights = False          # fp32 maps, split-bf16 contractions (custom_loss.set_compute_dtype("bf16x3"))
         self._packed: Dict[int, tuple] = {}
+
+    def _convert(self, w: Tensor) -> Tensor:
+        return ops.split_weights(w) if self.split_weights else ops.convert(w, self.compute_dtype)
 
     def _weights(self, i: int):
         conv = self.features[i]
-        key = (conv.weight.data_ptr(), conv.weight._version, self.compute_dtype, str(conv.weight.device))
+        key = (conv.weight.data_ptr(), conv.weight._version, self.compute_dtype, self.split_weights, str(conv.weight.device))
         hit = self._packed.get(i)
         if hit is None or hit[0] != key:
             with torch.no_grad():
                 w = conv.weight.detach().permute(0, 2, 3, 1)                       # [Cout,3,3,Cin]
                 if w.shape[3] % 32:
                     w = torch.nn.functional.pad(w, (0, _CPAD - w.shape[3]))
-                hit = (key, ops.convert(w.contiguous().float(), self.compute_dtype), conv.bias.detach().float().contiguous())
+                hit = (key, self._convert(w.contiguous().float()), conv.bias.detach().float().contiguous())
             self._packed[i] = hit
         return hit[1], hit[2]
 
@@ -62,7 +66,7 @@ class VGG19_custom(nn.Module):
         """weights of conv i for its DATA gradient: [Cin (3 -> 32)][3][3][Cout] with the taps flipped, in the compute dtype; cached
         (the network is frozen, loss.py:173-175)"""
         conv = self.features[i]
-        key = (conv.weight.data_ptr(), conv.weight._version, self.compute_dtype, str(conv.weight.device))
+        key = (conv.weight.data_ptr(), conv.weight._version, self.compute_dtype, self.split_weights, str(conv.weight.device))
         cache = self.__dict__.setdefault("_flip_cache", {})
         hit = cache.get(i)
         if hit is None or hit[0] != key:
@@ -71,7 +75,7 @@ class VGG19_custom(nn.Module):
                 if w.shape[1] % 32:
                     w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, _CPAD - w.shape[1]))
                 wf = w.flip(2, 3).permute(1, 2, 3, 0).contiguous()
-                hit = (key, ops.convert(wf, self.compute_dtype))
+                hit = (key, self._convert(wf))
             cache[i] = hit
         return hit[1]
 
@@ -122,10 +126,20 @@ class custom_loss(nn.Module):
             param.requires_grad = False
         self.set_compute_dtype(compute_dtype)
 
-    def set_compute_dtype(self, dtype: torch.dtype) -> "custom_loss":
+    def set_compute_dtype(self, dtype, split_bf16: bool = False) -> "custom_loss":
+        """torch.float32 (parity mode), torch.bfloat16, or "bf16x3" (= torch.float32 with split_bf16=True): fp32 feature maps, statistics and
+        gradients, the 3x3 convolutions of the frozen network (forward and data gradient) as three bf16 MFMA products of hi/lo operand
+        halves with fp32 accumulation - the parity-grade fast mode of model.set_compute_dtype.  conv1_1 keeps its exact fp32 kernel."""
+        if isinstance(dtype, str):
+            if dtype != "bf16x3":
+                raise ValueError('compute_dtype must be torch.float32, torch.bfloat16 or "bf16x3"')
+            dtype, split_bf16 = torch.float32, True
         if dtype not in (torch.float32, torch.bfloat16):
-            raise ValueError("compute_dtype must be torch.float32 or torch.bfloat16")
+            raise ValueError('compute_dtype must be torch.float32, torch.bfloat16 or "bf16x3"')
+        if split_bf16 and dtype != torch.float32:
+            raise ValueError("split_bf16 goes with torch.float32 maps")
         self.feature_extractor_model.compute_dtype = dtype
+        self.feature_extractor_model.split_weights = bool(split_bf16)
         return self
 
     def forward(self, content_image, style_image, output_image, distance="euclidian", lambda_value=None,

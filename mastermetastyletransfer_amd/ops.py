@@ -605,7 +605,8 @@ def conv3x3_zero(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, re
         lc = Cin if logical_cin is None else logical_cin
         _count("conv3x3", flops=2.0 * B * H * W * Cout * 9 * lc,
                bytes=x.element_size() * (B * H * W * lc + Cout * 9 * lc + out.numel()))
-    _check(load_library().master_conv3x3_zero_fwd(_p(x), _p(w_packed), _p(bias), _p(out), B, H, W, Cin, Cout, int(relu), _dt(x), _stream()),
+    dt = F32X3 if is_split(w_packed) else _dt(x)
+    _check(load_library().master_conv3x3_zero_fwd(_p(x), _p(w_packed), _p(bias), _p(out), B, H, W, Cin, Cout, int(relu), dt, _stream()),
            "master_conv3x3_zero_fwd")
     return out
 

@@ -304,3 +304,112 @@ def test_x3_kernels_repeatable_at_scale(cuda):
     with pytest.raises(SystemExit) as e:
         runpy.run_path(os.path.join(root, "profiles", "tools", "x3_determinism.py"), run_name="__main__")
     assert e.value.code == 0
+
+
+# ---- the frozen loss network of the train step in split-bf16 (custom_loss.set_compute_dtype("bf16x3")) -------------------------------
+@pytest.mark.parametrize("B,H,W,Cg,Cx,mask,add", [(2, 16, 16, 64, 64, True, True), (1, 9, 13, 128, 64, True, False), (2, 8, 8, 512, 256, False, False),
+                                                  (1, 32, 32, 64, 32, False, False), (3, 7, 5, 256, 256, True, True)])
+def test_conv3x3_zero_and_dgrad_x3(cuda, B, H, W, Cg, Cx, mask, add):
+    """master_conv3x3_zero_fwd / master_conv3x3_dgrad with MASTER_F32X3: the zero-padded VGG convolution and its data gradient
+    out = relu_src > 0 ? conv_transpose(g) + add : 0, against float64"""
+    from mastermetastyletransfer_amd import ops
+    from mastermetastyletransfer_amd.ops import _check, _p, _stream, load_library
+    gen = torch.Generator().manual_seed(B * 100 + Cg + Cx)
+    w = torch.randn(Cg, Cx, 3, 3, generator=gen) / (9 * Cx) ** 0.5           # the layer: Conv2d(Cx -> Cg), so its data gradient maps Cg -> Cx
+    bias = torch.randn(Cg, generator=gen)
+    x = torch.randn(B, Cx, H, W, generator=gen)
+    # forward
+    out = ops.conv3x3_zero(x.permute(0, 2, 3, 1).contiguous().to(cuda), ops.split_weights(w.permute(0, 2, 3, 1).contiguous().to(cuda)), bias.to(cuda), relu=True)
+    ref = F.relu(F.conv2d(x.double(), w.double(), bias.double(), padding=1))
+    assert rel_err(out.permute(0, 3, 1, 2), ref) <= X3_KERNEL_TOL
+    # data gradient
+    g = torch.randn(B, Cg, H, W, generator=gen)
+    relu_src = torch.randn(B, Cx, H, W, generator=gen) if mask else None
+    addt = torch.randn(B, Cx, H, W, generator=gen) if add else None
+    wf = ops.split_weights(w.flip(2, 3).permute(1, 2, 3, 0).contiguous().to(cuda))
+    nhwc = lambda t: None if t is None else t.permute(0, 2, 3, 1).contiguous().to(cuda)
+    gd, rd, ad = nhwc(g), nhwc(relu_src), nhwc(addt)
+    dx = torch.empty((B, H, W, Cx), device=cuda)
+    _check(load_library().master_conv3x3_dgrad(_p(gd), _p(wf), _p(dx), _p(rd), _p(ad), B, H, W, Cg, Cx, 0, ops.F32X3, _stream()), "dgrad")
+    r = F.conv_transpose2d(g.double(), w.double(), padding=1)
+    scale = float(r.abs().max())
+    if add:
+        r = r + addt.double()
+    if mask:
+        r = torch.where(relu_src.double() > 0, r, torch.zeros_like(r))
+    got = dx.permute(0, 3, 1, 2).double().cpu()
+    assert float((got - r).abs().max()) <= X3_KERNEL_TOL * max(scale, float(r.abs().max()))
+
+
+@pytest.mark.parametrize("B,H,W,dc,ds", [(2, 64, 64, "euclidian", "euclidian"), (2, 128, 128, "euclidian_squared", "euclidian_squared")])
+def test_perceptual_loss_backward_x3_network(cuda, B, H, W, dc, ds):
+    """the frozen VGG-19 of the loss in split-bf16: loss values and the PER-PIXEL image gradient held to the bounds of the exact fp32
+    network (tests/test_gpu_train.py::test_perceptual_loss_backward) against the float64 oracle - unlike the plain-bf16 network,
+    whose image gradient is only roughly aligned (cosine 0.8-0.9)"""
+    from mastermetastyletransfer_amd import custom_loss
+    from oracle import loss_oracle as L
+    sd = seeded_state_dict(L.vgg19_shapes(), 51)
+    c, s = (seeded_input(f"plb_{n}", (B, 3, H, W), 52 + i, kind="image") for i, n in enumerate("cs"))
+    o = seeded_input("plb_o", (B, 3, H, W), 55, kind="image")
+    o64 = o.double().requires_grad_(True)
+    total, cl, sl = L.overall_loss(c.double(), s.double(), o64, {k_: v.double() for k_, v in sd.items()}, 7.0, dc, ds)
+    total.backward()
+    loss = custom_loss(default_lambda_value=7.0, distance_content=dc, distance_style=ds, vgg_state_dict=sd).to(cuda).set_compute_dtype("bf16x3")
+    od = o.to(cuda).requires_grad_(True)
+    t2, c2, s2 = loss(c.to(cuda), s.to(cuda), od, output_content_and_style_loss=True)
+    assert abs(float(t2.detach()) - float(total)) <= 2e-4 * abs(float(total)) and abs(float(c2.detach()) - float(cl)) <= 2e-4 * abs(float(cl))
+    t2.backward()
+    got, ref = od.grad.cpu().double(), o64.grad
+    l2 = float((got - ref).norm() / ref.norm())
+    worst = float((got - ref).abs().max() / ref.abs().max())
+    print(f"x3 loss network {B}x{H}x{W} {dc}: image gradient relative L2 {l2:.2e}, worst element {worst:.2e} of max")
+    assert l2 <= 1e-3, l2
+    assert worst <= (1e-3 if dc == "euclidian_squared" and ds == "euclidian_squared" else 4e-3), worst
+    # and back: the same module in exact fp32 again (weights re-derived, nothing of the split mode left behind)
+    loss.set_compute_dtype(torch.float32)
+    od2 = o.to(cuda).requires_grad_(True)
+    loss(c.to(cuda), s.to(cuda), od2).backward()
+    assert float((od2.grad.cpu().double() - ref).norm() / ref.norm()) <= 1e-3
+
+
+def test_train_step_with_x3_loss_network(cuda):
+    """whole train step (fp32 model, split-bf16 loss network) against the float64 oracle: every parameter gradient within the bound the
+    all-fp32 step is held to (5e-3 of the tensor's max; test_gpu_train.py::test_full_train_step)"""
+    from mastermetastyletransfer_amd import MasterStyleTransferModel, custom_loss
+    from mastermetastyletransfer_amd import train_forward as TF
+    from oracle import loss_oracle as L, train_oracle as T
+    B, S, k = 4, 128, 1
+    sds = (seeded_state_dict(O.swin_shapes(), 1), seeded_state_dict(O.style_transformer_shapes(), 2), seeded_state_dict(O.decoder_shapes(), 3))
+    vgg = seeded_state_dict(L.vgg19_shapes(), 4)
+    c = seeded_input("bfl_c", (B, 3, S, S), 5, kind="image"); s = seeded_input("bfl_s", (B, 3, S, S), 6, kind="image")
+    g = torch.Generator().manual_seed(7)
+    probs = [p for p in O.SWIN_B_SD_PROBS if p > 0]
+    swin_masks = [torch.empty(B).bernoulli_(1 - p, generator=g).div_(1 - p) for _ in range(2) for p in probs for _ in range(2)]
+    masks = O.SDMasks.draw(O.SD_CALLS_PER_LAYER * k, B, 0.1, g)
+    losses64, ref64 = T.train_step_grads(c.double(), s.double(), k, *sds, vgg, masks, 10.0, swin_masks=swin_masks)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7], allow_random_swin_encoder=True)
+    m.swin_encoder.load_state_dict(sds[0]); m.style_transformer.load_state_dict(sds[1]); m.decoder.load_state_dict(sds[2])
+    m = m.to(cuda).train()
+    for p in m.swin_encoder.parameters():
+        p.requires_grad = False
+    loss_fn = custom_loss(default_lambda_value=10.0, vgg_state_dict=vgg).to(cuda).set_compute_dtype("bf16x3")
+    TF.sd_masks.set_masks(swin_masks + masks)
+    try:
+        out = m(c.to(cuda), s.to(cuda), k)
+    finally:
+        TF.sd_masks.set_masks(None)
+    total = loss_fn(c.to(cuda), s.to(cuda), out)
+    total.backward()
+    assert abs(float(total.detach()) - float(losses64["total"])) <= 2e-4 * abs(float(losses64["total"]))
+    named = [("style_transformer." + n, p) for n, p in m.style_transformer.named_parameters()] + [("decoder." + n, p) for n, p in m.decoder.named_parameters()]
+    gscale = max(float(v.abs().max()) for v in ref64.values())
+    errs = []
+    for n, p in named:
+        if n not in ref64 or p.grad is None or float(ref64[n].abs().max()) <= 1e-6 * gscale:
+            continue
+        errs.append((float((p.grad.cpu().double() - ref64[n]).abs().max()) / float(ref64[n].abs().max()), n))
+    errs.sort()
+    print(f"x3 loss network, B={B} {S}x{S}: worst parameter gradient {errs[-1][0]:.2e} of its tensor's max ({errs[-1][1]}), median {errs[len(errs) // 2][0]:.2e}")
+    assert errs[-1][0] <= 5e-3, errs[-3:]
