@@ -5,7 +5,7 @@
 #   train step:     the same four passes of `bench.py --mode train` (BASELINE config 4);
 #   fp32 mode:      kernel trace of `bench.py --dtype fp32`.
 # Outputs land in gpurun_out/<tag>/ with the names profiles/ uses (r03_...); copy what should be judged into profiles/.
-# usage: profiles/collect.sh [tag=r04] [what=all|bf16|train|fp32|x3]
+# usage: profiles/collect.sh [tag=r04] [what=all|bf16|train|trainx3|fp32|x3]
 set -e
 tag=${1:-r04}; what=${2:-all}; out=gpurun_out/$tag; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
@@ -31,6 +31,12 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel
 python profiles/pmc_mfma_util.py $out/tmfma/m_counter_collection.csv $out/${tag}_train_pmc_mfma_util.json > $out/${tag}_train_pmc_mfma_util.txt
 echo "train passes done"
 fi
+if [ $what = all ] || [ $what = trainx3 ]; then          # the train step with the loss network in split-bf16 (custom_loss.set_compute_dtype("bf16x3"))
+rocprofv3 --kernel-trace --stats -d $out/t3trace -o t --output-format csv -- python3 bench.py --mode train --loss-dtype x3 --steps 6 --warmup 2 --no-extras > $out/t3trace.log 2>&1
+python profiles/trace_by_shape.py $out/t3trace/t_kernel_trace.csv 8 > $out/${tag}_train_x3loss_trace_by_shape.txt
+cp $out/t3trace/t_kernel_stats.csv $out/${tag}_train_x3loss_kernel_stats.csv
+echo "train (x3 loss network) pass done"
+fi
 if [ $what = all ] || [ $what = x3 ]; then
 rocprofv3 --kernel-trace --stats -d $out/xtrace -o t --output-format csv -- python3 bench.py --dtype x3 --steps 8 --warmup 2 --no-extras --no-repeats > $out/xtrace.log 2>&1
 python profiles/trace_by_shape.py $out/xtrace/t_kernel_trace.csv auto > $out/${tag}_x3_bs32_trace_by_shape.txt
@@ -48,5 +54,5 @@ python profiles/trace_by_shape.py $out/ftrace/t_kernel_trace.csv auto > $out/${t
 echo "fp32 pass done"
 fi
 # the raw traces are large: keep the summaries only
-rm -rf $out/xtrace $out/xfetch $out/xwrite $out/xmfma $out/trace $out/fetch $out/write $out/mfma $out/ttrace $out/tfetch $out/twrite $out/tmfma $out/ftrace
+rm -rf $out/t3trace $out/xtrace $out/xfetch $out/xwrite $out/xmfma $out/trace $out/fetch $out/write $out/mfma $out/ttrace $out/tfetch $out/twrite $out/tmfma $out/ftrace
 ls $out

@@ -422,3 +422,15 @@ def test_trace_by_shape_counts_executions_itself(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "profiles", "trace_by_shape.py"), str(p), "auto"], capture_output=True, text=True, check=True).stdout
     assert "over 25 executions" in out and "n/step=  7.0" in out and "n/step=  2.0" in out
+
+
+def test_trace_by_shape_prints_the_whole_grid(tmp_path):
+    """a split-K launch with its splits in grid.y is listed with all of its workgroups (r03's listing showed Grid_Size_X only: 16 for 16x32)"""
+    import subprocess, sys
+    rows = ["Kernel_Name,Grid_Size_X,Grid_Size_Y,Grid_Size_Z,Workgroup_Size_X,Workgroup_Size_Y,Workgroup_Size_Z,Start_Timestamp,End_Timestamp",
+            '"void (anonymous namespace)::t_kernel(float*)",4096,32,1,256,1,1,0,1000', '"void (anonymous namespace)::t_kernel(float*)",4096,1,1,256,1,1,2000,3000']
+    p = tmp_path / "t_kernel_trace.csv"
+    p.write_text("\n".join(rows) + "\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "profiles", "trace_by_shape.py"), str(p), "1"], capture_output=True, text=True, check=True).stdout
+    assert "wgs=    16x32" in out and "wgs=       16 " in out
