@@ -632,6 +632,8 @@ int dispatch(const X3Args& p, hipStream_t s) {
         if (force == 1) return launch<128, 128, 64, 64, CONV>(p, s);
         if (force == 2) return launch<128, 128, 32, 64, CONV>(p, s);
         if (force == 3) return launch<256, 128, 64, 64, CONV>(p, s);
+        if (force == 5) return launch<128, 64, 64, 32, CONV>(p, s);        // 72 KB of LDS, four waves: two workgroups per CU
+        if (force == 6) return launch<128, 64, 32, 32, CONV>(p, s);        // eight waves
         // fewer than two 256-row tiles per CU: 128-row tiles (eight waves: two per SIMD) fill the chip better
         const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 127) / 128);
         if (t256 < 512) return launch<128, 128, 32, 64, CONV>(p, s);

@@ -251,73 +251,99 @@ __global__ __launch_bounds__(256) void instnorm_kernel(const T* __restrict__ x, 
         Vec4<T>::store(pad_out + (size_t)b * C + c0 + cq * 4, (pr - mean) * rstd);
 }
 
-// ---- Swin patch embedding: Conv2d(3,E,4,4) + LayerNorm(E), E = 128 (swin_B) or 96 (swin_T / swin_S).  Block = 64 patches of one
-//      patch row.  Thread (patch p, quarter eq) produces channels [32eq, 32eq+32) of patch p; with E = 96 the fourth thread of a
-//      patch computes nothing and adds zeros to the LayerNorm sums. ---------------------
+__device__ __forceinline__ void store2(float* p, float a, float b) { *(f32x2*)p = f32x2{a, b}; }
+__device__ __forceinline__ void store2(bf16_t* p, float a, float b) { *(unsigned*)p = pack_bf16x2(a, b); }
+
+// ---- Swin patch embedding: Conv2d(3,E,4,4) + LayerNorm(E), E = 128 (swin_B) or 96 (swin_T / swin_S).  A unit of work = 64 patches
+//      of one patch row; a workgroup stages the weights once and loops over units.  Thread (patch group pg, channel group cq) produces
+//      channels [cq*E/16, (cq+1)*E/16) of patches 4pg .. 4pg+3: per k it reads E/16 weights and 4 pixels from LDS for 4*E/16 FMAs.
+//      (r04: the first form gave a thread 1 patch x 32 channels - 132 B of LDS reads per k for 32 FMAs - and re-staged the 24 KB of weights
+//      for every 64 patches through a 48-way bank-conflicted transpose: 74 us per launch at 32 images, against 15 us of HBM time.) -------
 template <typename T, int E>
 __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                           const float* __restrict__ bias, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, T* __restrict__ out, int H, int W,
+                                                          const float* __restrict__ beta, T* __restrict__ out, int B, int H, int W,
                                                           float eps) {
-    constexpr int KP = 48, PSTR = 49;
+    constexpr int KP = 48, PSTR = 49, CPT = E / 16;
+    static_assert(E % 32 == 0 && CPT % 2 == 0, "channel groups of an even number of channels");
     __shared__ __attribute__((aligned(16))) float pix[64 * PSTR];
     __shared__ __attribute__((aligned(16))) float wt[KP * E];   // [k][e]
     const int PW = W >> 2, PH = H >> 2;
     const int chunks = (PW + 63) / 64;
-    int bid = blockIdx.x;
-    const int pc = bid % chunks; bid /= chunks;
-    const int py = bid % PH; const int b = bid / PH;
-    const int px0 = pc * 64;
+    const int units = B * PH * chunks;
     const int tid = threadIdx.x;
 
-    for (int i = tid; i < KP * E; i += 256) {       // w[e][k] -> wt[k][e]
-        const int e = i / KP, k = i - e * KP;
-        wt[k * E + e] = w[i];
+    // w[e][k] -> wt[k][e]: lane <-> e, so the transposed stores walk the banks (the loads are 16 B at a 192-B stride, from L2)
+    for (int i = tid; i < 12 * E; i += 256) {
+        const int e = i % E, k4 = i / E;
+        const f32x4 v = *(const f32x4*)(w + e * KP + k4 * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wt[(k4 * 4 + j) * E + e] = v[j];
     }
-    for (int seg = 0; seg < 12; ++seg) {            // (c, dy) image row segments, 256 contiguous pixels
-        const int c = seg >> 2, dy = seg & 3;
-        const int xx = px0 * 4 + tid;
-        if (xx < W) pix[(tid >> 2) * PSTR + c * 16 + dy * 4 + (tid & 3)] =
-            img[(((size_t)b * 3 + c) * H + py * 4 + dy) * W + xx];
-    }
-    __syncthreads();
+    const int pg = tid >> 4, cq = tid & 15;
+    float bv[CPT], gv[CPT], btv[CPT];
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) { bv[e] = bias[cq * CPT + e]; gv[e] = gamma[cq * CPT + e]; btv[e] = beta[cq * CPT + e]; }
 
-    const int p = tid >> 2, eq = tid & 3;
-    const bool live = eq * 32 < E;
-    float acc[32];
-#pragma unroll
-    for (int e = 0; e < 32; ++e) {
-        acc[e] = live ? bias[eq * 32 + e] : 0.f;
-    }
-    for (int k = 0; live && k < KP; ++k) {
-        const float a = pix[p * PSTR + k];
-        const f32x4* wr = (const f32x4*)(wt + k * E + eq * 32);
-#pragma unroll
-        for (int e4 = 0; e4 < 8; ++e4) {
-            const f32x4 wv = wr[e4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e4 * 4 + e] = fmaf(a, wv[e], acc[e4 * 4 + e]);
+    for (int unit = blockIdx.x; unit < units; unit += gridDim.x) {
+        int u = unit;
+        const int pc = u % chunks; u /= chunks;
+        const int py = u % PH; const int b = u / PH;
+        const int px0 = pc * 64;
+        __syncthreads();                                 // the previous unit's pixels are consumed (first pass: the weights are staged)
+        for (int seg = 0; seg < 12; ++seg) {            // (c, dy) image row segments, 256 contiguous pixels
+            const int c = seg >> 2, dy = seg & 3;
+            const int xx = px0 * 4 + tid;
+            pix[(tid >> 2) * PSTR + c * 16 + dy * 4 + (tid & 3)] = xx < W ? img[(((size_t)b * 3 + c) * H + py * 4 + dy) * W + xx] : 0.f;
         }
-    }
-    float s = 0.f;
+        __syncthreads();
+
+        float acc[4][CPT];
 #pragma unroll
-    for (int e = 0; e < 32; ++e) s += acc[e];
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
-    const float mean = s / (float)E;
-    float sq = 0.f;
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int e = 0; e < 32; ++e) { const float d = acc[e] - mean; sq += live ? d * d : 0.f; }
-    sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64);
-    const float rstd = rsqrtf(sq / (float)E + eps);
-    if (live && px0 + p < PW) {
-        T* op = out + ((((size_t)b * PH + py) * PW + px0 + p) * E) + eq * 32;
+            for (int e = 0; e < CPT; ++e) acc[j][e] = bv[e];
+#pragma unroll 4
+        for (int k = 0; k < KP; ++k) {
+            float wv[CPT];
+            const f32x2* wr = (const f32x2*)(wt + k * E + cq * CPT);
 #pragma unroll
-        for (int e4 = 0; e4 < 8; ++e4) {
-            const f32x4 g = *(const f32x4*)(gamma + eq * 32 + e4 * 4), bt = *(const f32x4*)(beta + eq * 32 + e4 * 4);
-            f32x4 o;
+            for (int e2 = 0; e2 < CPT / 2; ++e2) { const f32x2 t = wr[e2]; wv[2 * e2] = t[0]; wv[2 * e2 + 1] = t[1]; }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (acc[e4 * 4 + e] - mean) * rstd * g[e] + bt[e];
-            Vec4<T>::store(op + e4 * 4, o);
+            for (int j = 0; j < 4; ++j) {
+                const float a = pix[(pg * 4 + j) * PSTR + k];
+#pragma unroll
+                for (int e = 0; e < CPT; ++e) acc[j][e] = fmaf(a, wv[e], acc[j][e]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) s += acc[j][e];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+            const float mean = s / (float)E;
+            float sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) { const float d = acc[j][e] - mean; sq += d * d; }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sq += __shfl_xor(sq, o, 64);
+            const float rstd = rsqrtf(sq / (float)E + eps);
+            const int p = pg * 4 + j;
+            if (px0 + p < PW) {
+                T* op = out + ((((size_t)b * PH + py) * PW + px0 + p) * E) + cq * CPT;
+                float o_[CPT];
+#pragma unroll
+                for (int e = 0; e < CPT; ++e) o_[e] = (acc[j][e] - mean) * rstd * gv[e] + btv[e];
+                if constexpr (CPT % 4 == 0) {
+#pragma unroll
+                    for (int e4 = 0; e4 < CPT / 4; ++e4) Vec4<T>::store(op + e4 * 4, f32x4{o_[4 * e4], o_[4 * e4 + 1], o_[4 * e4 + 2], o_[4 * e4 + 3]});
+                } else {
+#pragma unroll
+                    for (int e2 = 0; e2 < CPT / 2; ++e2) store2(op + 2 * e2, o_[2 * e2], o_[2 * e2 + 1]);
+                }
+            }
         }
     }
 }
@@ -460,12 +486,13 @@ template <typename T>
 int patch_embed_launch(const float* img, const void* w, const void* bias, const void* g, const void* b, void* out,
                        int B, int H, int W, int E, float eps, hipStream_t s) {
     const int PW = W / 4, PH = H / 4, chunks = (PW + 63) / 64;
+    const int units = B * PH * chunks, grid = units < 1024 ? units : 1024;       // four resident workgroups per CU (37 KB of LDS each), looping
     if (E == 128)
-        hipLaunchKernelGGL((patch_embed_kernel<T, 128>), dim3(B * PH * chunks), dim3(256), 0, s, img, (const float*)w,
-                           (const float*)bias, (const float*)g, (const float*)b, (T*)out, H, W, eps);
+        hipLaunchKernelGGL((patch_embed_kernel<T, 128>), dim3(grid), dim3(256), 0, s, img, (const float*)w,
+                           (const float*)bias, (const float*)g, (const float*)b, (T*)out, B, H, W, eps);
     else if (E == 96)
-        hipLaunchKernelGGL((patch_embed_kernel<T, 96>), dim3(B * PH * chunks), dim3(256), 0, s, img, (const float*)w,
-                           (const float*)bias, (const float*)g, (const float*)b, (T*)out, H, W, eps);
+        hipLaunchKernelGGL((patch_embed_kernel<T, 96>), dim3(grid), dim3(256), 0, s, img, (const float*)w,
+                           (const float*)bias, (const float*)g, (const float*)b, (T*)out, B, H, W, eps);
     else { master_set_error("patch_embed: embed dim %d not built (128 = swin_B, 96 = swin_T / swin_S)", E); return MASTER_ERR_UNSUPPORTED; }
     return master_check_launch("patch_embed");
 }
