@@ -80,6 +80,18 @@ class _HipModule(nn.Module):
             return b.detach().float().contiguous()
         return self._derived("b:" + name, params, build)
 
+    def _ln_linear(self, name: str, x: Tensor, norm: nn.LayerNorm, weights: Sequence[Tensor], biases: Sequence[Tensor]) -> Tensor:
+        """LayerNorm(x) @ cat(weights).T + cat(biases).  bf16 mode: one fused launch (ops.linear_ln); fp32 modes: LayerNorm, then Linear - or, split-bf16
+        mode with MASTER_X3_LNFOLD=1, the LayerNorm folded into the product (ops.linear_ln_folded; opt-in: ops.linear_ln_folded_enabled)."""
+        if self.split_weights and ops.linear_ln_folded_enabled() and ops.linear_ln_folded_supported(x, sum(w.shape[0] for w in weights)):
+            def build():
+                w = weights[0] if len(weights) == 1 else torch.cat(list(weights), dim=0)
+                b = biases[0] if len(biases) == 1 else torch.cat(list(biases), dim=0)
+                return ops.fold_layernorm(w, b, norm.weight, norm.bias)
+            ws, colsum, bf = self._derived("lnfold:" + name, list(weights) + list(biases) + [norm.weight, norm.bias], build)
+            return ops.linear_ln_folded(x, ws, colsum, bf, norm.eps)
+        return ops.linear_ln(x, self._b("n1w", norm.weight), self._b("n1b", norm.bias), self._w(name, *weights), self._b(name, *biases), eps=norm.eps)
+
     def _bias_of(self, lin: nn.Linear) -> Tensor:
         """the bias of a projection, or - bias=False (qkv_bias / proj_bias of full_model.py:39-42) - a zero row of its width: F.linear
         without a bias adds nothing, and a zero-padded window slot's key / value row (the reference pads BEFORE the Linear) is then zero"""
@@ -209,11 +221,12 @@ class ShiftedWindowAttention(_WindowAttentionBase):
         norm1) is applied to q, k and v; for q = k = v it is folded into the fused qkv projection."""
         C = xq.shape[1]
         if xq is xk and all(v is xq for v in xvs):
-            wqkv = self._w("qkv", self.Wq.weight, self.Wk.weight, self.Wv.weight)
-            bqkv = self._b("qkv", self._bias_of(self.Wq), self._bias_of(self.Wk), self._bias_of(self.Wv))
             if norm is not None:
-                qkv = ops.linear_ln(xq, self._b("n1w", norm.weight), self._b("n1b", norm.bias), wqkv, bqkv, eps=norm.eps)
+                qkv = self._ln_linear("qkv", xq, norm, [self.Wq.weight, self.Wk.weight, self.Wv.weight],
+                                      [self._bias_of(self.Wq), self._bias_of(self.Wk), self._bias_of(self.Wv)])
             else:
+                wqkv = self._w("qkv", self.Wq.weight, self.Wk.weight, self.Wv.weight)
+                bqkv = self._b("qkv", self._bias_of(self.Wq), self._bias_of(self.Wk), self._bias_of(self.Wv))
                 qkv = ops.linear(xq, wqkv, bqkv)
             q, k, vs = qkv[:, :C], qkv[:, C:2 * C], [qkv[:, 2 * C:]]
             uniq = [0] * len(xvs)
@@ -774,8 +787,7 @@ class _SwinAttention(_WindowAttentionBase):
                                   self._b("qkv", self.qkv.bias), self._w("proj", self.proj.weight), self._b("proj", self.proj.bias),
                                   self._bias64(), plan.src, plan.region, B, H * W, self.num_heads, plan.nW, plan.N,
                                   HEAD_DIM ** -0.5, norm.eps)
-        qkv = ops.linear_ln(x, self._b("n1w", norm.weight), self._b("n1b", norm.bias), self._w("qkv", self.qkv.weight),
-                            self._b("qkv", self.qkv.bias), eps=norm.eps)
+        qkv = self._ln_linear("qkv", x, norm, [self.qkv.weight], [self.qkv.bias])
         rows = self._derived("rows", [self.qkv.bias], lambda: ops.convert(self.qkv.bias.detach().contiguous(), self.compute_dtype))
         plan = window_plan(H, W, self.window_size, self.shift_size, x.device)
         if ops.window_attn_proj_supported(qkv, self.num_heads, plan.nW, plan.N):
