@@ -208,6 +208,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         result.update(extras(model, content, style, k, args, ops))
     if rank == 0:
+        if _PROFILES_READ:
+            result["from_committed_profiles"] = profile_provenance()
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -232,7 +234,22 @@ def latest_profile(suffix):
     """newest committed profiles/rNN_<suffix> (the PMC passes are re-collected every round on the final tree), or None"""
     import glob
     hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    if hits:
+        _PROFILES_READ.add(os.path.relpath(hits[-1], ROOT))
     return hits[-1] if hits else None
+
+
+_PROFILES_READ = set()
+PROFILE_DERIVED_KEYS = ["roofline.traffic", "attn_core.cross_attn_kernel_mfma_busy_pct_pmc", "attn_core.qk_phase_from_committed_probe",
+                        "train_step.roofline.traffic", "train_step.launches_k2_step.torch_from_committed_trace_avg_over_traced_k"]
+
+
+def profile_provenance():
+    """which keys of the line are NOT measured by this run but read from committed rocprofv3 / probe summaries (PMC counters and in-kernel
+    clock probes cannot be collected inside bench.py), and from which files - they describe the tree those files were collected on"""
+    return {"keys": PROFILE_DERIVED_KEYS, "files": sorted(_PROFILES_READ),
+            "note": "everything else in this line is measured live by this process; these keys are per-launch PMC traffic, PMC matrix-core busy, "
+                    "in-kernel clock-probe results and a traced launch count, collected by profiles/collect.sh / profiles/tools on the tree of the named files"}
 
 
 def pmc_traffic(family, args):
@@ -644,6 +661,8 @@ def train_main(args):
                                        "k = random.randint(1, 4) with random.seed(0), Swin encoder frozen, StochasticDepth p = 0.1, "
                                        "custom_loss (VGG-19 relu2_1..5_1, lambda 10), FusedAdam lr 1e-4", "global_batch": 8, "image_size": 256,
                            "parallelism": "dp1"}})
+    if _PROFILES_READ:
+        res["from_committed_profiles"] = profile_provenance()
     print(json.dumps(res), flush=True)
 
 

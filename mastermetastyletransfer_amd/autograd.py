@@ -38,21 +38,28 @@ def _ws(nfloats: int, dev) -> Optional[Tensor]:
 # every backward call but the last ACCUMULATES its contribution into one buffer inside the kernel's own slab reduce
 # (MASTER_ACCUMULATE) and returns None to autograd, and the last call returns the buffer.  Outside a scope, or when a backward meets
 # a graph the registry was not counted for (two forwards before a backward, a second backward through a retained graph), every call
-# returns its own fresh gradient as before.
+# returns its own fresh gradient as before.  The counts belong to the scope object (one per forward), not to the process.
 # ---------------------------------------------------------------------------------------------------------------------------------------
 ACCUMULATE = 0x100            # include/master_hip.h: MASTER_ACCUMULATE
 
 
+class _Scope:
+    """the use counts of ONE forward (r04: they used to live on the process-wide registry, so a second forward - recompute, another model,
+    a forward inside a backward hook - silently discarded the counts an earlier graph's backward still needed); every autograd ctx holds
+    the scope it was recorded in, and a scope dies with the graph that references it"""
+    __slots__ = ("uses", "checked")
+
+    def __init__(self):
+        self.uses = {}                    # id(tensor) -> [remaining uses, buffer or None]
+        self.checked = False              # the end-of-backward verification is queued
+
+
 class _SharedGrads:
     def __init__(self):
-        self.counting = None              # token of the scope whose forward is being recorded (None: not counting)
-        self.graph = None                 # token of the scope the counts in `uses` belong to
-        self.uses = {}                    # id(tensor) -> [remaining uses, buffer or None]
-        self._checked = None
+        self.counting = None              # scope whose forward is being recorded (None: not counting)
 
     def begin(self) -> object:
-        self.counting = self.graph = object()
-        self.uses = {}
+        self.counting = _Scope()
         return self.counting
 
     def end(self, token) -> None:
@@ -65,53 +72,52 @@ class _SharedGrads:
             return None
         for t in ts:
             if t is not None and t.requires_grad:
-                self.uses.setdefault(id(t), [0, None])[0] += 1
+                self.counting.uses.setdefault(id(t), [0, None])[0] += 1
         return self.counting
 
     def deliver(self, token, t, compute):
         """backward: compute(out, accumulate) -> gradient tensor (added into `out` when accumulate).  Returns what the autograd Function
         should return for `t`: None for every use but the last, then the buffer holding the sum."""
-        e = self.uses.get(id(t)) if (token is not None and token is self.graph) else None
+        e = token.uses.get(id(t)) if token is not None else None
         if e is None or (e[0] <= 1 and e[1] is None):
             if e is not None:
-                self.uses.pop(id(t), None)
+                token.uses.pop(id(t), None)
             return compute(None, False)
-        if self._checked is not token:    # once per backward pass: a use that never ran backward would strand its sum - fail loudly
-            self._checked = token
+        if not token.checked:             # once per backward pass: a use that never ran backward would strand its sum - fail loudly
+            token.checked = True
             torch.autograd.Variable._execution_engine.queue_callback(lambda: self._verify(token))
         e[1] = compute(None, False) if e[1] is None else compute(e[1], True)
         e[0] -= 1
         if e[0] == 0:
-            self.uses.pop(id(t), None)
+            token.uses.pop(id(t), None)
             return e[1]
         return None
 
     def slot(self, token, t, alloc):
         """backward, for a launch that writes several gradients at once: -> (buffer to write, accumulate into it?, what to return to
         autograd for `t`: None for every use but the last).  `alloc()` makes the buffer at the first use."""
-        e = self.uses.get(id(t)) if (token is not None and token is self.graph) else None
+        e = token.uses.get(id(t)) if token is not None else None
         if e is None or (e[0] <= 1 and e[1] is None):
             if e is not None:
-                self.uses.pop(id(t), None)
+                token.uses.pop(id(t), None)
             out = alloc()
             return out, False, out
-        if self._checked is not token:
-            self._checked = token
+        if not token.checked:
+            token.checked = True
             torch.autograd.Variable._execution_engine.queue_callback(lambda: self._verify(token))
         acc = e[1] is not None
         if not acc:
             e[1] = alloc()
         e[0] -= 1
         if e[0] == 0:
-            self.uses.pop(id(t), None)
+            token.uses.pop(id(t), None)
             return e[1], acc, e[1]
         return e[1], acc, None
 
     def deliver_pair(self, token, w, b, compute):
         """weight and bias of one Linear (counted together by `note`, so always at the same use):
         compute(out_w, out_b, accumulate, want_w, want_b) -> (dw, db), one launch for both.  Returns (dw, db) as `deliver` would for each."""
-        live = token is not None and token is self.graph
-        ew, eb = (self.uses.get(id(w)), self.uses.get(id(b))) if live else (None, None)
+        ew, eb = (token.uses.get(id(w)), token.uses.get(id(b))) if token is not None else (None, None)
         if ew is None or eb is None or ew[0] != eb[0] or (ew[1] is None) != (eb[1] is None):
             # not counted as a pair (a bias that is also used elsewhere, e.g. as an attention pad row): separate launches
             if ew is None and eb is None:
@@ -120,10 +126,10 @@ class _SharedGrads:
             db = self.deliver(token, b, lambda o, acc: compute(None, o, acc, False, True)[1])
             return dw, db
         if ew[0] <= 1 and ew[1] is None:
-            self.uses.pop(id(w), None); self.uses.pop(id(b), None)
+            token.uses.pop(id(w), None); token.uses.pop(id(b), None)
             return compute(None, None, False, True, True)
-        if self._checked is not token:
-            self._checked = token
+        if not token.checked:
+            token.checked = True
             torch.autograd.Variable._execution_engine.queue_callback(lambda: self._verify(token))
         if ew[1] is None:
             ew[1], eb[1] = compute(None, None, False, True, True)
@@ -131,18 +137,17 @@ class _SharedGrads:
             compute(ew[1], eb[1], True, True, True)
         ew[0] -= 1; eb[0] -= 1
         if ew[0] == 0:
-            self.uses.pop(id(w), None); self.uses.pop(id(b), None)
+            token.uses.pop(id(w), None); token.uses.pop(id(b), None)
             return ew[1], eb[1]
         return None, None
 
     def _verify(self, token) -> None:
-        self._checked = None
-        if token is self.graph:
-            stranded = [k for k, e in self.uses.items() if e[1] is not None]
-            self.uses = {}
-            if stranded:
-                raise ops.MasterHipError(f"{len(stranded)} shared parameter gradient(s) were accumulated but never delivered: a counted use "
-                                         "did not take part in this backward pass (a branch of the forward that does not reach the loss)")
+        token.checked = False
+        stranded = [k for k, e in token.uses.items() if e[1] is not None]
+        token.uses = {}
+        if stranded:
+            raise ops.MasterHipError(f"{len(stranded)} shared parameter gradient(s) were accumulated but never delivered: a counted use "
+                                     "did not take part in this backward pass (a branch of the forward that does not reach the loss)")
 
 
 shared_grads = _SharedGrads()

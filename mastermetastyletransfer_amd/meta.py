@@ -50,22 +50,35 @@ def allreduce_gradients(params: Iterable[nn.Parameter], average: bool = True) ->
     ps = [p for p in params if p.requires_grad]
     if not ps:
         return
-    dev = ps[0].device
-    has = torch.tensor([0.0 if p.grad is None else 1.0 for p in ps], dtype=ps[0].dtype, device=dev)
-    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ps] + [has])
-    dist.all_reduce(flat)
-    counts = flat[-len(ps):].tolist()
-    if average:
-        flat /= dist.get_world_size()
+    dev, dt = ps[0].device, ps[0].dtype
+    has_local = [p.grad is not None for p in ps]
+    sizes = [p.numel() for p in ps]
+    total = sum(sizes)
+    flat = torch.empty((total + len(ps),), dtype=dt, device=dev)
     off = 0
-    for p, c in zip(ps, counts):
-        n = p.numel()
-        if c > 0.0:
-            g = flat[off:off + n].view_as(p)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
+    for p, h, n in zip(ps, has_local, sizes):
+        if h:
+            flat[off:off + n].copy_(p.grad.reshape(-1))
+        else:
+            flat[off:off + n].zero_()
+        off += n
+    flat[total:].copy_(torch.tensor([1.0 if h else 0.0 for h in has_local], dtype=dt), non_blocking=True)
+    dist.all_reduce(flat)
+    if average:
+        flat[:total] /= dist.get_world_size()
+    # the flags are read on the HOST only for parameters this rank has no gradient for (r03 read all of them after every all-reduce:
+    # a blocking device-to-host copy in every inner step); a rank that produced every gradient never waits here
+    missing = [i for i, h in enumerate(has_local) if not h]
+    elsewhere = set()
+    if missing:
+        got = flat[total:][torch.tensor(missing, device=dev)].tolist()
+        elsewhere = {i for i, c in zip(missing, got) if c > 0.0}
+    off = 0
+    for i, (p, h, n) in enumerate(zip(ps, has_local, sizes)):
+        if h:
+            p.grad.copy_(flat[off:off + n].view_as(p))
+        elif i in elsewhere:
+            p.grad = flat[off:off + n].view_as(p).clone()
         off += n
 
 

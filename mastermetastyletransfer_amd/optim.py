@@ -171,12 +171,20 @@ class FusedAdam(torch.optim.Optimizer):
                 if not st:
                     if capturing:
                         raise ops.MasterHipError("FusedAdam: run one eager step before capturing (the moment buffers are created there)")
+                    if self.capturable and self.__dict__.setdefault("_cap_stepped", {}).get(gi, 0) > 0:
+                        # the group's ONE device counter drives every tensor's bias correction: a tensor joining at step t > 1 would be
+                        # corrected for step t, not 1 (torch.optim.Adam keeps a step per tensor; the non-capturable mode raises below)
+                        raise ops.MasterHipError("FusedAdam(capturable=True): a parameter received its first gradient after its param group had "
+                                                 "already stepped; the tensors of a param group must share their step count (put late "
+                                                 "parameters - e.g. those enabled by set_fast_adaptation - in a param group of their own)")
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 if not self.capturable:
                     st["step"] += 1
                 recs.append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), g))
+            if self.capturable and not capturing:
+                self.__dict__.setdefault("_cap_stepped", {})[gi] = self._cap_stepped.get(gi, 0) + 1
             steps = {self.state[p]["step"] for p in ps}
             if len(steps) != 1:
                 raise ops.MasterHipError("FusedAdam: the tensors of a param group must share their step count")

@@ -148,6 +148,30 @@ def test_fused_mlp_bf16(cuda, monkeypatch, form, M, C, HID, ln, res):
     assert mx < 2e-2 and l2 < 6e-3, (mx, l2)       # hidden activations and the output are each rounded to bf16 once
 
 
+@pytest.mark.parametrize("C", [256, 128])
+def test_fused_mlp_gelu_polynomial_against_erf(cuda, C):
+    """the bf16 mode's GELU (degree-4 polynomial in x^2 for Phi(x) - 1/2, clamped; csrc/common.h) against the erf GELU on the whole range
+    pre-activations take (|x| <= 6, every bf16 value on a 1/32 grid): fc1 = identity rows and fc2 = a selection, so that the kernel's
+    output IS gelu(h) of a known h.  Bound = the polynomial's own error (|error| <= 2.3e-3, reached near |x| = 3) + the two bf16 roundings
+    the kernel applies around it (hidden tile, output)."""
+    from mastermetastyletransfer_amd import ops
+    HID = 4 * C
+    h = (torch.arange(C * 2, dtype=torch.float32) / 32.0 - 6.0)[: 2 * C]                 # -6 ... with step 1/32: exact in bf16
+    grid = torch.cat([h, -h, h * 0.5, h * 0.25]).view(-1, C)                              # rows of C pre-activations
+    M = ((grid.shape[0] + 127) // 128) * 128
+    x = torch.zeros(M, C); x[: grid.shape[0]] = grid
+    w1 = torch.zeros(HID, C); w1[torch.arange(C), torch.arange(C)] = 1.0                  # hidden unit j < C reads channel j
+    w2 = torch.zeros(C, HID); w2[torch.arange(C), torch.arange(C)] = 1.0                  # output channel c = gelu(hidden c)
+    z = torch.zeros
+    out = ops.mlp(x.to(BF).to(cuda), w1.to(BF).to(cuda), z(HID).to(cuda), w2.to(BF).to(cuda), z(C).to(cuda), res=None).float().cpu()
+    ref = F.gelu(x.double())
+    err = (out.double() - ref).abs()
+    bound = 2.3e-3 + 2.0 * 2.0 ** -8 * ref.abs() + 1e-6
+    worst = float((err - bound).max())
+    print(f"C={C}: degree-4 GELU through the fused MLP, max |error| {float(err.max()):.2e} (at x = {float(x.flatten()[err.flatten().argmax()]):.3f})")
+    assert worst <= 0.0, worst
+
+
 @pytest.mark.parametrize("B,Hs,Ws", [(1, 8, 16), (2, 16, 16), (1, 64, 48)])
 def test_decoder_tail_bf16(cuda, B, Hs, Ws):
     """Upsample + Conv(32->32, reflect) + ReLU + Conv(32->3, reflect) in one launch vs the torch chain (border tiles,
