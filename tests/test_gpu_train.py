@@ -837,3 +837,47 @@ def test_non_default_decoder_branches_backward(cuda, i):
             continue
         seen.add(id(prm))
         check(n, prm.grad, p[n].grad, floor=1e-3 * gscale)
+
+
+def test_two_forwards_before_one_backward_keep_their_shared_gradients(cuda):
+    """the use counts of shared parameters (k layers, 2k uses of the StyleEncoder block) belong to the forward that counted
+    them.  Two train-mode forwards followed by ONE backward through both graphs must give the gradients of the two losses taken one
+    after the other (before r04 the second forward reset a process-wide registry and the first graph's sums were dropped silently)."""
+    m = _model(cuda).to(cuda).train()
+    for p in m.swin_encoder.parameters():
+        p.requires_grad = False
+    c1, s1, c2, s2 = (seeded_input(f"two_{i}", (2, 3, 64, 64), 70 + i, kind="image").to(cuda) for i in range(4))
+    named = [(n, p) for n, p in m.named_parameters() if p.requires_grad]
+
+    def run(joint: bool):
+        torch.manual_seed(123); torch.cuda.manual_seed(123)                 # the same StochasticDepth masks in both runs
+        m.zero_grad(set_to_none=True)
+        o1 = m(c1, s1, 2)
+        if not joint:
+            o1.square().mean().backward()
+        o2 = m(c2, s2, 1)
+        if joint:
+            (o1.square().mean() + o2.square().mean()).backward()
+        else:
+            o2.square().mean().backward()
+        return {n: p.grad.detach().clone() for n, p in named if p.grad is not None}
+    seq, joint = run(False), run(True)
+    assert seq.keys() == joint.keys() and len(seq) > 40
+    gscale = max(float(g.abs().max()) for g in seq.values())
+    errs = sorted((float((joint[n] - seq[n]).abs().max()) / max(float(seq[n].abs().max()), 1e-6 * gscale), n) for n in seq if n not in M.ZERO_GRAD)
+    print("two forwards, one backward: worst tensors", errs[-3:])
+    assert errs[-1][0] <= 1e-4, errs[-3:]         # (the three Wk.bias gradients that are zero in exact arithmetic are rounding noise)
+
+
+def test_capturable_adam_refuses_a_parameter_that_joins_late(cuda):
+    """with capturable=True the param group has ONE device step counter; a tensor whose first gradient arrives after the group
+    has stepped would be bias-corrected for the wrong step - raise, as the non-capturable path does for mismatching step counts"""
+    from mastermetastyletransfer_amd import FusedAdam
+    from mastermetastyletransfer_amd.ops import MasterHipError
+    a, b = (torch.nn.Parameter(torch.randn(64, device=cuda)) for _ in range(2))
+    opt = FusedAdam([a, b], lr=1e-3, capturable=True)
+    a.grad = torch.randn_like(a)
+    opt.step()
+    b.grad = torch.randn_like(b)
+    with pytest.raises(MasterHipError, match="share their step count"):
+        opt.step()
