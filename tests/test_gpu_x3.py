@@ -463,3 +463,130 @@ def test_train_step_with_x3_loss_network(cuda):
     errs.sort()
     print(f"x3 loss network, B={B} {S}x{S}: worst parameter gradient {errs[-1][0]:.2e} of its tensor's max ({errs[-1][1]}), median {errs[len(errs) // 2][0]:.2e}")
     assert errs[-1][0] <= 5e-3, errs[-3:]
+
+
+# ---- the split mode against the REFERENCE's own vectors (tests/golden/*.npz) and on the non-default constructor paths ---------------------
+def _x3(mod, sd, dev):
+    """a bare module (not the whole model) in the split mode: what model.set_compute_dtype("bf16x3") does to every sub-module"""
+    mod.load_state_dict(sd)
+    mod = mod.to(dev).eval()
+    for sub in mod.modules():
+        if hasattr(sub, "compute_dtype"):
+            sub.compute_dtype = torch.float32
+            sub.split_weights = True
+    return mod
+
+
+def _close(got, ref, name, tol):
+    got = got.detach().float().cpu()
+    ref = ref if isinstance(ref, torch.Tensor) else torch.from_numpy(ref)
+    assert got.shape == ref.shape and torch.isfinite(got).all(), name
+    err, top = float((got - ref).abs().max()), float(ref.abs().max())
+    assert err <= tol * max(1.0, top), f"{name}: max|d| = {err:.3e} > {tol * max(1.0, top):.3e}"
+
+
+def test_modules_x3_against_the_reference_vectors(cuda, golden):
+    """window attention (6 geometries incl. the one-axis-shift quirk), StyleSwinTransformerBlock (norm x exclude_MLP), sigma/mu attention,
+    StyleEncoder (both orders), StyleDecoder, StyleTransformer k in {1, 3} at width 64 and at the real width, Decoder at 8^2 / 32^2 and the
+    ST -> Decoder chain: the vectors the unmodified reference produced (tests/golden/make_golden.py), at the bounds of the exact-fp32 mode's
+    own module tests (1e-4 ... 3e-4 of max|ref|; full chains 1e-3)"""
+    from torch import nn
+    from mastermetastyletransfer_amd import Decoder, ShiftedWindowAttention, StyleSwinTransformerBlock, StyleTransformer
+    from tests import golden_cases as G
+    for H, W, shift in G.SWA_CASES:
+        tag, sd, (q, k, v) = G.swa_case(H, W, shift)
+        m = _x3(ShiftedWindowAttention(G.DIM, G.NH, [7, 7], list(shift)), sd, cuda)
+        _close(m(q.to(cuda), k.to(cuda), v.to(cuda)), golden[tag], tag, 1e-4)
+    for norm, excl in G.BLOCK_CASES:
+        tag, sd, (q, k, v) = G.block_case(norm, excl)
+        m = _x3(StyleSwinTransformerBlock(G.DIM, G.NH, [7, 7], [4, 4], norm_layer=nn.LayerNorm if norm else None, exclude_MLP_after=excl), sd, cuda)
+        _close(m(q.to(cuda), k.to(cuda), v.to(cuda), calculating_Key_in_encoder=False), golden[tag], tag, 1e-4)
+    build = lambda dim, nh, sd, flag=True: _x3(StyleTransformer(dim, dim, nh, nh, [7, 7], [7, 7], [4, 4], [4, 4],
+                                                                  encoder_if_use_processed_Key_in_Scale_and_Shift_calculation=flag), sd, cuda)
+    sd, abcd, fc, fs, cfg = G.st_small()
+    a, b, c, d = (t.to(cuda) for t in abcd)
+    m = build(G.DIM, G.NH, sd)
+    s, mu = m.decoder.decoder_MHA_for_sigma_and_mu(a, b, c, d)
+    _close(s, golden["sigma_mu_sigma"], "sigma", 1e-4); _close(mu, golden["sigma_mu_mu"], "mu", 1e-4)
+    for flag in (True, False):
+        for n, o in zip(("key", "scale", "shift"), build(G.DIM, G.NH, sd, flag).encoder(a, b, c)):
+            _close(o, golden[f"style_encoder_flag{int(flag)}_{n}"], f"encoder flag{flag} {n}", 1e-4)
+    _close(m.decoder(a, b, c, d), golden["style_decoder"], "style_decoder", 2e-4)
+    for k in (1, 3):
+        _close(m(fc.to(cuda), fs.to(cuda), k), golden[f"style_transformer_small_k{k}"], f"st small k{k}", 3e-4)
+    sd, fc, fs = G.st_256()
+    m = build(256, 8, sd)
+    y1 = m(fc.to(cuda), fs.to(cuda), 1)
+    _close(y1, golden["style_transformer_256_k1"], "st256 k1", 1e-3)
+    _close(m(fc.to(cuda), fs.to(cuda), 3), golden["style_transformer_256_k3"], "st256 k3", 1e-3)
+    for hw in (8, 32):
+        dsd, x = G.decoder_case(hw)
+        dec = _x3(Decoder(256), dsd, cuda)
+        _close(dec(x.to(cuda)), golden[f"decoder_{hw}"], f"decoder {hw}", 1e-3)
+    _close(dec(y1.permute(0, 3, 1, 2)), golden["st256_k1_then_decoder"], "st256 -> decoder", 1e-3)
+
+
+@pytest.mark.parametrize("i", range(5))
+def test_non_default_decoder_branches_x3(cuda, i):
+    """affine InstanceNorm, the regular-MHA decoder end, Key InstanceNorm before the Linear, exclude_MLP: the reference's own outputs
+    (tests/golden/golden_branches.npz) in the split mode, at the exact-fp32 mode's bound"""
+    import os, sys
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden_branches as MB
+    from mastermetastyletransfer_amd import StyleTransformer
+    gold = np.load(os.path.join(here, "golden", "golden_branches.npz"))
+    tag, affine, regular, after = MB.CASES[i]
+    sd, fc, fs, cfg = MB.case(i)
+    m = _x3(StyleTransformer(MB.DIM, MB.DIM, MB.NH, MB.NH, [7, 7], [7, 7], [4, 4], [4, 4], decoder_use_instance_norm_with_affine=affine,
+                             decoder_use_regular_MHA_instead_of_Swin_at_the_end=regular,
+                             decoder_use_Key_instance_norm_after_linear_transformation=after), sd, cuda)
+    for k in (1, 2):
+        with torch.no_grad():
+            _close(m(fc.to(cuda), fs.to(cuda), k), gold[f"{tag}_k{k}"], f"{tag} k={k}", 1e-4)
+
+
+@pytest.mark.parametrize("variant,B,S,k", [("swin_T", 2, 64, 1), ("swin_S", 1, 256, 1)])
+def test_swin_t_s_full_forward_x3(cuda, variant, B, S, k):
+    """swin_T / swin_S (embed 96 -> 192-wide StyleTransformer and decoder, 6 heads; the widths the fused split kernels are not specialised
+    for: generic split GEMMs, unfused MLP) against the oracle at the literal 1e-3"""
+    from mastermetastyletransfer_amd import MasterStyleTransferModel
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = MasterStyleTransferModel(swin_variant=variant, style_encoder_dim=192, style_decoder_dim=192, style_encoder_num_heads=6,
+                                     style_decoder_num_heads=6, style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7],
+                                     allow_random_swin_encoder=True)
+    sds = (seeded_state_dict(O.swin_shapes(embed=96, heads=(3, 6)), 41), seeded_state_dict(O.style_transformer_shapes(dim=192, heads=6), 42),
+           seeded_state_dict(O.decoder_shapes(192), 43))
+    m.swin_encoder.load_state_dict(sds[0]); m.style_transformer.load_state_dict(sds[1]); m.decoder.load_state_dict(sds[2])
+    m = m.to(cuda).eval()
+    m.set_compute_dtype("bf16x3")
+    cfg = dict(O.DEFAULT_ST_CFG, encoder_num_heads=6, decoder_num_heads=6)
+    c = seeded_input(f"ct{S}", (B, 3, S, S), 8, kind="image"); s = seeded_input(f"st{S}", (B, 3, S, S), 9, kind="image")
+    with torch.no_grad():
+        got = m(c.to(cuda), s.to(cuda), k).cpu()
+        ref = O.full_forward(c, s, k, *sds, cfg=cfg, swin_heads=(3, 6))
+    err = float((got - ref).abs().max())
+    print(f"{variant} x3 B{B} S{S}: max|d| {err:.2e} on outputs of max {float(ref.abs().max()):.2f}")
+    assert torch.isfinite(got).all() and err <= (ABS_TOL if float(ref.abs().max()) <= 10 else 1e-4 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("S", [256, 200])
+def test_default_constructor_window8_x3(cuda, S):
+    """the reference's default 8x8 windows (64 tokens = the whole 64-slot tile; 200^2: a 25x25 map padded to 32) in the split mode"""
+    from mastermetastyletransfer_amd import MasterStyleTransferModel
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = MasterStyleTransferModel(allow_random_swin_encoder=True)
+    sds = (seeded_state_dict(O.swin_shapes(), 41), seeded_state_dict(O.style_transformer_shapes(ws=(8, 8)), 42, ws=(8, 8)), seeded_state_dict(O.decoder_shapes(), 43))
+    m.swin_encoder.load_state_dict(sds[0]); m.style_transformer.load_state_dict(sds[1]); m.decoder.load_state_dict(sds[2])
+    m = m.to(cuda).eval()
+    m.set_compute_dtype("bf16x3")
+    c = seeded_input(f"c8_{S}", (1, 3, S, S), 8, kind="image"); s = seeded_input(f"s8_{S}", (1, 3, S, S), 9, kind="image")
+    with torch.no_grad():
+        ref = O.full_forward(c, s, 1, *sds, cfg=dict(O.DEFAULT_ST_CFG, encoder_window_size=(8, 8), decoder_window_size=(8, 8)))
+        got = m(c.to(cuda), s.to(cuda), 1).cpu()
+    err, top = float((got - ref).abs().max()), float(ref.abs().max())
+    print(f"window 8, {S}^2, x3: max|d| {err:.2e} on outputs of max {top:.2f}")
+    assert err <= (ABS_TOL if top <= 10 else 1e-4 * top)          # the rule of tests/test_gpu_parity.py::assert_close(absolute=True)
