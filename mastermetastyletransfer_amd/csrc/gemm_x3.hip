@@ -671,6 +671,10 @@ int dispatch(const X3Args& p, hipStream_t s) {
         if (force == 3) return launch<256, 128, 64, 64, CONV>(p, s);
         if (force == 5) return launch<128, 64, 64, 32, CONV>(p, s);        // 72 KB of LDS, four waves: two workgroups per CU
         if (force == 6) return launch<128, 64, 32, 32, CONV>(p, s);        // eight waves
+        // one N tile of 128 with a short K (the stage-1 projection, 262 144 x 128 x 128 + residual): 128 x 64 tiles, eight waves, two
+        // workgroups per CU - one tile's epilogue runs under the other's loop (117.6 -> 100.3 us; with more N tiles the re-split of A
+        // per N tile costs more than the overlap gives: profiles/r04 A/B of MASTER_X3_TILE=5/6)
+        if (!CONV && force == 0 && p.N <= 128 && p.K <= 128 && p.M >= 65536) return launch<128, 64, 32, 32, CONV>(p, s);
         // fewer than two 256-row tiles per CU: 128-row tiles (eight waves: two per SIMD) fill the chip better
         const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 127) / 128);
         if (t256 < 512) return launch<128, 128, 32, 64, CONV>(p, s);
