@@ -77,8 +77,11 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
     for (int t = 0; t < 2; ++t) {
         const int slot = t * 32 + r;
         const int idx = __shfl(my_src, slot, 64);
-        const float* qp = p.q + (tok0 + (idx >= 0 ? idx : 0)) * p.ldq + coff + 16 * h;
-        const float* kp = idx >= 0 ? p.k + (tok0 + idx) * p.ldk + coff + 16 * h
+        // r04: one 64-bit base per problem (uniform: scalar registers) + a 32-bit byte offset per lane - an image's rows span < 4 GB - so that
+        // the loads take the saddr + voffset form instead of a 64-bit multiply-add per row (the kernel is VALU-issue bound: 2 210 vector
+        // instructions per problem for 48 MFMAs)
+        const float* qp = (const float*)((const char*)(p.q + tok0 * p.ldq) + (unsigned)(((idx >= 0 ? idx : 0) * p.ldq + coff + 16 * h) * 4));
+        const float* kp = idx >= 0 ? (const float*)((const char*)(p.k + tok0 * p.ldk) + (unsigned)((idx * p.ldk + coff + 16 * h) * 4))
                                    : p.k_pad + (size_t)b * p.k_pad_bs + coff + 16 * h;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -92,6 +95,8 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
     float vv0[2][16], vv1[2][16];
     auto load_v = [&](const float* v, const float* v_pad, float (&vv)[2][16]) __attribute__((always_inline)) {
         const float* vpad = v_pad + (size_t)b * p.v_pad_bs + coff + r;
+        const char* vb = (const char*)(v + tok0 * p.ldv);
+        const unsigned lane_off = (unsigned)((coff + r) * 4), row_bytes = (unsigned)(p.ldv * 4);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -99,8 +104,9 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
                 const int key0 = kt * 32 + (e & 3) + 8 * (e >> 2);                   // half 0's key; half 1 takes key0 + 4
                 const int i0 = __builtin_amdgcn_readlane(my_src, key0), i1 = __builtin_amdgcn_readlane(my_src, key0 + 4);
                 const int idx = h ? i1 : i0;
-                const float a = idx >= 0 ? v[(tok0 + idx) * p.ldv + coff + r] : *vpad;
-                vv[kt][e] = (key0 + 4 * h) < p.N ? a : 0.0f;
+                // (slots >= N carry idx = -1 like zero-padded ones: they read the finite pad row, and their probability is exactly 0 -
+                // bias -1e30 - so no separate select to zero them)
+                vv[kt][e] = idx >= 0 ? *(const float*)(vb + ((unsigned)idx * row_bytes + lane_off)) : *vpad;
             }
     };
     load_v(p.v0, p.v0_pad, vv0);
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float pe = exp2f(st[kt][qt][e] - m);
+                const float pe = __builtin_amdgcn_exp2f(st[kt][qt][e] - m);        // raw v_exp_f32: the argument is <= 0, results under 2^-126 may flush (exp2f's range fix-up was 4 more instructions per value)
                 st[kt][qt][e] = pe;
                 s += pe;
             }
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
         for (int qt = 0; qt < 2; ++qt) {
             const int idx = __shfl(my_src, qt * 32 + r, 64);
             if (idx < 0) continue;
-            float* op = out + (tok0 + idx) * p.ldo + coff + 4 * h;
+            float* op = (float*)((char*)(out + tok0 * p.ldo) + (unsigned)((idx * p.ldo + coff + 4 * h) * 4));
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 ov;
