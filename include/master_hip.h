@@ -160,15 +160,6 @@ int master_window_attn_proj_fwd(const void* q, const void* k, const void* v, int
                                 const uint8_t* region, const void* wproj, const float* bproj, const void* res, int ldr, void* out,
                                 int ldo, int B, int T, int heads, int nW, int N, float scale, int dtype, master_stream_t stream);
 
-/* LayerNorm + Linear of the split-bf16 mode with the LayerNorm FOLDED into the product (style_transformer.py:390 + :114-116; torchvision
- * Swin block norm1 + qkv): out = LN(x) W^T + b is evaluated as  rstd[m] * (x W'^T - mean[m] * colsum[n]) + bias[n]  with
- * W' = W diag(gamma) (w = master_split_weights(W')), colsum[n] = sum_k W'[n][k], bias = b + W beta - the caller prepares the three once per
- * parameter version.  mean / rstd of every row are accumulated from the x registers the GEMM splits anyway (shifted sums, pivot = the row's
- * first element), so the normalised activations are never written or re-read.  dtype = MASTER_F32X3 only; N > 64, N % 4 == 0, K % 32 == 0,
- * 16-byte aligned operands.  + r2 [M, N] (optional). */
-int master_linear_lnfold_fwd(const void* x, const void* w, const float* colsum, const float* bias, const void* r2, void* out, int M, int N, int K,
-                             int ldx, int ldo, int ldr, float eps, int dtype, master_stream_t stream);
-
 /* n (1..3) independent Linear layers of one shape class in ONE launch:  out_i[M, N_i] = LN?(x_i) . w_i^T + bias_i
  * (same M and K; N_i % 128 == 0; no residual operands; x, w, bias, out, N, ldx, ldo are HOST arrays of n entries; bias_i may be NULL).
  * Replaces the groups of projections that feed one attention call from different inputs: Wk . Key | Wv_scale . Scale | Wv_shift . Shift

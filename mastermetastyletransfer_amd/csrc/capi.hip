@@ -110,7 +110,6 @@ int gemm_x3_linear(const float*, const void*, const float*, const float*, const 
 int gemm_x3_conv3x3(const float*, const void*, const float*, float*, int, int, int, int, int, int, int, int, hipStream_t, int zero_pad, int a_split,
                     int out_split);
 int gemm_x3_conv3x3_dgrad(const float*, const void*, float*, const float*, const float*, int, int, int, int, int, hipStream_t);
-int gemm_x3_linear_ln(const float*, const void*, const float*, const float*, const float*, float*, int, int, int, int, int, int, float, hipStream_t);
 
 // ---- error string -------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -574,18 +573,6 @@ int master_linear_ln_fwd(const void* x, const float* ln_gamma, const float* ln_b
                                   (const bf16_t*)r2, (bf16_t*)out, M, N, K, ldx, ldr, ldo, eps, s);
     if (rc == MASTER_ERR_UNSUPPORTED) master_set_error("linear_ln: shape M=%d N=%d K=%d not covered by the fused kernel", M, N, K);
     return rc;
-}
-
-int master_linear_lnfold_fwd(const void* x, const void* w, const float* colsum, const float* bias, const void* r2, void* out, int M, int N, int K,
-                             int ldx, int ldo, int ldr, float eps, int dtype, master_stream_t stream) {
-    REQUIRE(x && w && colsum && bias && out, "linear_lnfold: null operand");
-    if (dtype != MASTER_F32X3) { master_set_error("linear_lnfold: the folded LayerNorm form exists in the split-bf16 mode only (MASTER_F32X3)"); return MASTER_ERR_UNSUPPORTED; }
-    REQUIRE(M > 0 && N > 64 && N % 4 == 0 && K > 0 && K % 32 == 0 && ldx >= K && ldo >= N && (r2 == nullptr || ldr >= N), "linear_lnfold: bad dims (N > 64, N %% 4 == 0, K %% 32 == 0)");
-    REQUIRE(al16(x) && al16(w) && al16(colsum) && al16(bias) && al16(out) && (r2 == nullptr || al16(r2)) && ldx % 4 == 0 && ldo % 4 == 0 && ldr % 4 == 0,
-            "linear_lnfold: 16-byte aligned operands and row strides");
-    hipStream_t s = (hipStream_t)stream;
-    ProfScope ps(MASTER_K_LINEAR, s);
-    return gemm_x3_linear_ln((const float*)x, w, colsum, bias, (const float*)r2, (float*)out, M, N, K, ldx, ldo, ldr, eps, s);
 }
 
 int master_linear_group_fwd(int n, const void* const* x, const void* const* w, const void* const* bias, void* const* out, const int* N,

@@ -15,6 +15,16 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     bf16x2_hw v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
     return __builtin_bit_cast(unsigned, v);
 }
+// two fp32 values -> packed bf16 hi pair + packed bf16 lo pair (hi = bf16(x), lo = bf16(x - hi), round to nearest even both times): the split
+// of the F32X3 mode.  The packed hi word is made opaque to the optimiser: left visible, hipcc computes float(hi0) from a SECOND
+// v_cvt_pk_bf16_f32 of x0 alone instead of shifting the packed word - 3 conversions per pair instead of 2 in kernels that are bound by
+// their vector-instruction count (r04: 240 -> 160 conversions per problem in the attention kernel).
+__device__ __forceinline__ void split_bf16x2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    unsigned a = pack_bf16x2(x0, x1);
+    asm("" : "+v"(a));
+    hi = a;
+    lo = pack_bf16x2(x0 - __uint_as_float(a << 16), x1 - __uint_as_float(a & 0xffff0000u));
+}
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.0f) & 0xffffu); }
 

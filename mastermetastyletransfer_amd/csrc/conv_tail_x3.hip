@@ -70,10 +70,10 @@ __global__ __launch_bounds__(256, 2) void conv_tail_x3_kernel(TailX3Args p) {
             u32x4 hi, lo;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const unsigned a = pack_bf16x2(v0[2 * j], v0[2 * j + 1]);
-                hi[j] = a; lo[j] = pack_bf16x2(v0[2 * j] - __uint_as_float(a << 16), v0[2 * j + 1] - __uint_as_float(a & 0xffff0000u));
-                const unsigned c2 = pack_bf16x2(v1[2 * j], v1[2 * j + 1]);
-                hi[2 + j] = c2; lo[2 + j] = pack_bf16x2(v1[2 * j] - __uint_as_float(c2 << 16), v1[2 * j + 1] - __uint_as_float(c2 & 0xffff0000u));
+                unsigned ah, al, ch, cl;
+                split_bf16x2(v0[2 * j], v0[2 * j + 1], ah, al);
+                split_bf16x2(v1[2 * j], v1[2 * j + 1], ch, cl);
+                hi[j] = ah; lo[j] = al; hi[2 + j] = ch; lo[2 + j] = cl;
             }
             *(u32x4*)(S + pix * PIX + part * 16) = hi;
             *(u32x4*)(S + pix * PIX + 64 + part * 16) = lo;
@@ -128,9 +128,9 @@ __global__ __launch_bounds__(256, 2) void conv_tail_x3_kernel(TailX3Args p) {
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[4 * g + e] + b8v[4 * g + e], 0.f);
-                    const unsigned h0 = pack_bf16x2(v[0], v[1]), h1 = pack_bf16x2(v[2], v[3]);
-                    const unsigned l0 = pack_bf16x2(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u));
-                    const unsigned l1 = pack_bf16x2(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u));
+                    unsigned h0, h1, l0, l1;
+                    split_bf16x2(v[0], v[1], h0, l0);
+                    split_bf16x2(v[2], v[3], h1, l1);
                     *(u32x2*)(Y + pr * PIX + (8 * g + 4 * h) * 2) = u32x2{h0, h1};
                     *(u32x2*)(Y + pr * PIX + 64 + (8 * g + 4 * h) * 2) = u32x2{l0, l1};
                 }

@@ -37,8 +37,6 @@ struct X3Args {
     int M, N, K, lda, ldo, ldr, act;
     int Hin, Win, Cin, Hout, Wout, up, out_nchw, zero_pad;
     int mask_relu;      // r1 is a ReLU output whose sign gates the result: out = r1 > 0 ? acc + r2 : 0 (data-gradient chain of the loss network)
-    const float* ln_s;  // LayerNorm folded into the product (LN instantiations): w = split(W diag(gamma)), ln_s[n] = sum_k w[n][k], bias = b + W beta;
-    float ln_eps;       //   out = rstd[m] * (acc - mean[m] * ln_s[n]) + bias[n], the row statistics accumulated from the A registers the kernel splits anyway
     int out_split;      // the output goes out in the split layout (per row and 32-wide chunk 32 bf16 hi | 32 bf16 lo: what the next GEMM's A operand takes by LDS-DMA); N % 32 == 0
 };
 
@@ -52,12 +50,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, u32x4& hi, u32x4& lo) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const unsigned p = pack_bf16x2(x0[2 * j], x0[2 * j + 1]);
-        hi[j] = p;
-        lo[j] = pack_bf16x2(x0[2 * j] - __uint_as_float(p << 16), x0[2 * j + 1] - __uint_as_float(p & 0xffff0000u));
-        const unsigned q = pack_bf16x2(x1[2 * j], x1[2 * j + 1]);
-        hi[2 + j] = q;
-        lo[2 + j] = pack_bf16x2(x1[2 * j] - __uint_as_float(q << 16), x1[2 * j + 1] - __uint_as_float(q & 0xffff0000u));
+        unsigned ph, pl, qh, ql;
+        split_bf16x2(x0[2 * j], x0[2 * j + 1], ph, pl);
+        split_bf16x2(x1[2 * j], x1[2 * j + 1], qh, ql);
+        hi[j] = ph; lo[j] = pl; hi[2 + j] = qh; lo[2 + j] = ql;
     }
 }
 
@@ -72,7 +68,7 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, u32x4& 
 // ---- epilogue shared by the two kernels: the row form of gemm_f32.hip (accumulators through the idle ring as the [BM][BN] fp32 tile, whole
 // 16-byte row pieces out: coalesced bias / r1 / r2 loads, float4 stores), or - out_split - the same pieces split into bf16 hi | lo and
 // stored in the split layout (8 + 8 bytes per piece); element-wise fallback for outputs the row form cannot address (NCHW, N % 4).
-template <int BM, int BN, int WM, int WN, bool CONV, int RING_BYTES, bool LN = false>
+template <int BM, int BN, int WM, int WN, bool CONV, int RING_BYTES>
 __device__ __forceinline__ void x3_epilogue(const X3Args& p, f32x16 (&acc)[WM / 32][WN / 32], unsigned char* ring, int m0, int n0, int wm, int wn) {
     constexpr int NWN = BN / WN;
     constexpr int NWAVES = (BM / WM) * NWN;
@@ -100,22 +96,19 @@ __device__ __forceinline__ void x3_epilogue(const X3Args& p, f32x16 (&acc)[WM / 
                     tile[(wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * BN + wn + jn * 32 + r] = acc[i][jn][e];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");                                    // nothing that reads the tile (or the LayerNorm statistics) moves above the barrier
         const int c4 = tid % VPR, row0 = tid / VPR;
         int n = n0 + c4 * 4;
         const bool n_ok = n < p.N;
         n = n_ok ? n : p.N - 4;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) bv = *(const f32x4*)(p.bias + n);
-        f32x4 sv = {0.f, 0.f, 0.f, 0.f};
-        if (LN) sv = *(const f32x4*)(p.ln_s + n);
-        const float* stat = (const float*)(ring + RING_BYTES);             // [BM][mean, rstd], written before the first barrier above
         constexpr int BATCH = PIECES < 4 ? PIECES : 4;
 #pragma unroll
         for (int b0 = 0; b0 < PIECES; b0 += BATCH) {
             f32x4 v[BATCH], a1[BATCH], a2[BATCH];
             size_t orow[BATCH];
             bool ok[BATCH];
-            float mean[BATCH], rstd[BATCH];
 #pragma unroll
             for (int it = 0; it < BATCH; ++it) {
                 const int row = row0 + (b0 + it) * (NT / VPR);
@@ -124,13 +117,12 @@ __device__ __forceinline__ void x3_epilogue(const X3Args& p, f32x16 (&acc)[WM / 
                 m = m < p.M ? m : p.M - 1;
                 orow[it] = (size_t)m;
                 v[it] = *(const f32x4*)(tile + row * BN + c4 * 4);
-                if (LN) { mean[it] = stat[2 * row]; rstd[it] = stat[2 * row + 1]; }
                 if (p.r1) a1[it] = *(const f32x4*)(p.r1 + (size_t)m * p.ldr + n);
                 if (p.r2) a2[it] = *(const f32x4*)(p.r2 + (size_t)m * p.ldr + n);
             }
 #pragma unroll
             for (int it = 0; it < BATCH; ++it) {
-                f32x4 x = LN ? (v[it] - mean[it] * sv) * rstd[it] + bv : v[it] + bv;
+                f32x4 x = v[it] + bv;
                 if (p.act == MASTER_ACT_GELU) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) x[c] = gelu_erf(x[c]);
@@ -148,9 +140,9 @@ __device__ __forceinline__ void x3_epilogue(const X3Args& p, f32x16 (&acc)[WM / 
                 }
                 if (p.out_split) {
                     if (ok[it]) {
-                        const unsigned h0 = pack_bf16x2(x[0], x[1]), h1 = pack_bf16x2(x[2], x[3]);
-                        const unsigned l0 = pack_bf16x2(x[0] - __uint_as_float(h0 << 16), x[1] - __uint_as_float(h0 & 0xffff0000u));
-                        const unsigned l1 = pack_bf16x2(x[2] - __uint_as_float(h1 << 16), x[3] - __uint_as_float(h1 & 0xffff0000u));
+                        unsigned h0, h1, l0, l1;
+                        split_bf16x2(x[0], x[1], h0, l0);
+                        split_bf16x2(x[2], x[3], h1, l1);
                         // row of N values = N / 32 chunks of 128 B; value n of the row: hi at (n >> 5) * 128 + (n & 31) * 2, lo 64 B further
                         unsigned char* dst = (unsigned char*)(p.out + orow[it] * p.ldo) + (n >> 5) * 128 + (n & 31) * 2;
                         typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
@@ -196,9 +188,8 @@ __device__ __forceinline__ void x3_epilogue(const X3Args& p, f32x16 (&acc)[WM / 
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV, bool LN = false>
+template <int BM, int BN, int WM, int WN, bool CONV>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3_kernel(X3Args p) {
-    static_assert(!(LN && CONV), "the folded LayerNorm is a Linear form");
     constexpr int NWN = BN / WN;
     constexpr int NWAVES = (BM / WM) * NWN;
     constexpr int NT = NWAVES * 64;
@@ -287,22 +278,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3_kernel(X3A
             if (i_c0 == p.Cin) { i_c0 = 0; ++i_tap; set_tap(i_tap); }
         }
     };
-    // LN: shifted sums of the rows this thread stages (pivot = the row's first element: keeps E[x^2] - E[x]^2 out of cancellation when
-    // |mean| >> std), over the real chunks only
-    float ln_s1[APASS], ln_s2[APASS], ln_pv[APASS];
-#pragma unroll
-    for (int i = 0; i < APASS; ++i) ln_s1[i] = ln_s2[i] = ln_pv[i] = 0.0f;
-    auto store_a = [&](int slot_i, const f32x4 (&ra)[APASS][2], bool real) __attribute__((always_inline)) {
+    auto store_a = [&](int slot_i, const f32x4 (&ra)[APASS][2]) __attribute__((always_inline)) {
         unsigned char* slot = ring + slot_i * STAGE;
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
-            if (LN && real) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float d = ra[i][e >> 2][e & 3] - ln_pv[i];
-                    ln_s1[i] += d; ln_s2[i] = fmaf(d, d, ln_s2[i]);
-                }
-            }
             u32x4 hi, lo;
             split8(ra[i][0], ra[i][1], hi, lo);
             *(u32x4*)(slot + a_dst[i]) = hi;
@@ -381,11 +360,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3_kernel(X3A
     load_a(0, ra0); issue_w(0, 0);
     load_a(1, ra1); issue_w(1, 1);
     wait_regs(ra0);                                                        // A(0): W(0) and the group of chunk 1 stay in flight
-    if (LN) {
-#pragma unroll
-        for (int i = 0; i < APASS; ++i) ln_pv[i] = __shfl(ra0[i][0][0], lane & ~3, 64);     // the row's element 0 (its k8 = 0 thread)
-    }
-    store_a(0, ra0, true);
+    store_a(0, ra0);
 
     int s_cur = 0, s_nxt = 1, s_nn = 2;                                    // ring slots of chunks kt, kt + 1, kt + 2
 #ifdef X3_CLOCK_PROBE     // diagnostic build only (profiles/probes/gemm_x3_probe.hip): s_memtime sections of every wave 0, written to a buffer of their own
@@ -405,7 +380,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3_kernel(X3A
         XPROBE_ADD(3);
         wait_regs(nxt);                                                    // A(kt + 1): W(kt + 1) and the group of chunk kt + 2 stay in flight
         XPROBE_ADD(4);
-        store_a(s_nxt, nxt, kt + 1 < nk);
+        store_a(s_nxt, nxt);
         XPROBE_ADD(5);
         asm volatile("" ::: "memory");
         const int t = s_cur; s_cur = s_nxt; s_nxt = s_nn; s_nn = t;
@@ -425,20 +400,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3_kernel(X3A
     }
 #endif
 
-    if (LN) {
-        float* stat = (float*)(ring + NSTAGE * STAGE);
-#pragma unroll
-        for (int i = 0; i < APASS; ++i) {
-            float a = ln_s1[i], b = ln_s2[i];
-            a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64);
-            b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64);
-            const float inv_k = 1.0f / (float)p.K;
-            const float dm = a * inv_k;
-            const float var = fmaxf(fmaf(-dm, dm, b * inv_k), 0.0f);
-            if (k8 == 0) { stat[2 * (arow + i * RP)] = ln_pv[i] + dm; stat[2 * (arow + i * RP) + 1] = rsqrtf(var + p.ln_eps); }
-        }
-    }
-    x3_epilogue<BM, BN, WM, WN, CONV, NSTAGE * STAGE, LN>(p, acc, ring, m0, n0, wm, wn);
+    x3_epilogue<BM, BN, WM, WN, CONV, NSTAGE * STAGE>(p, acc, ring, m0, n0, wm, wn);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -643,15 +605,15 @@ int launch_s(const X3Args& p, hipStream_t s) {
     return master_check_launch("gemm_x3s");
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV, bool LN = false>
+template <int BM, int BN, int WM, int WN, bool CONV>
 int launch(const X3Args& p, hipStream_t s) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     const int MT = (p.M + BM - 1) / BM, NTN = (p.N + BN - 1) / BN;
     const int grid = ((MT + 7) / 8) * 8 * NTN;
-    const size_t lds = (size_t)3 * (BM + BN) * 128 + (LN ? BM * 8 : 0);   // LN: [BM][mean, rstd] behind the ring
+    const size_t lds = (size_t)3 * (BM + BN) * 128;
     static LdsLimit lds_limit;
-    lds_limit.ensure((const void*)gemm_x3_kernel<BM, BN, WM, WN, CONV, LN>, (int)lds);
-    hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, WM, WN, CONV, LN>), dim3(grid), dim3(NT), lds, s, p);
+    lds_limit.ensure((const void*)gemm_x3_kernel<BM, BN, WM, WN, CONV>, (int)lds);
+    hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, WM, WN, CONV>), dim3(grid), dim3(NT), lds, s, p);
     return master_check_launch("gemm_x3");
 }
 
@@ -720,25 +682,15 @@ int gemm_x3_split_weights(const float* w, void* out, size_t rows, size_t K, int 
 
 int gemm_x3_linear(const float* a, const void* w, const float* bias, const float* r1, const float* r2, float* out,
                    int M, int N, int K, int lda, int ldo, int ldr, int act, hipStream_t s, int a_split, int out_split) {
-    X3Args p{a, (const float*)w, bias, r1, r2, out, M, N, K, lda, ldo, ldr, act, 0, 0, 0, 1, 1, 0, 0, 0, 0, nullptr, 0.f, out_split};
+    X3Args p{a, (const float*)w, bias, r1, r2, out, M, N, K, lda, ldo, ldr, act, 0, 0, 0, 1, 1, 0, 0, 0, 0, out_split};
     return a_split ? dispatch_s<false>(p, s) : dispatch<false>(p, s);
-}
-
-// LayerNorm folded into the product: out = LN(a) W^T + b computed as rstd * (a W'^T - mean * colsum) + bias' with W' = W diag(gamma) (split),
-// colsum[n] = sum_k W'[n][k], bias' = b + W beta.  N > 64, N % 4 == 0, row pieces 16-byte aligned (the row-form epilogue).
-int gemm_x3_linear_ln(const float* a, const void* w, const float* colsum, const float* bias, const float* r2, float* out, int M, int N, int K,
-                      int lda, int ldo, int ldr, float eps, hipStream_t s) {
-    X3Args p{a, (const float*)w, bias, nullptr, r2, out, M, N, K, lda, ldo, ldr, MASTER_ACT_NONE, 0, 0, 0, 1, 1, 0, 0, 0, 0, colsum, eps, 0};
-    const long long t256 = (long long)((M + 255) / 256) * ((N + 127) / 128);
-    if (t256 < 512) return launch<128, 128, 32, 64, false, true>(p, s);
-    return launch<256, 128, 64, 64, false, true>(p, s);
 }
 
 int gemm_x3_conv3x3(const float* x, const void* w, const float* bias, float* out, int B, int Hin, int Win, int Cin,
                     int Cout, int up, int relu, int out_nchw, hipStream_t s, int zero_pad, int a_split, int out_split) {
     const int Hout = Hin << up, Wout = Win << up;
     X3Args p{x, (const float*)w, bias, nullptr, nullptr, out, B * Hout * Wout, Cout, 9 * Cin, 0, Cout, 0,
-             relu ? MASTER_ACT_RELU : MASTER_ACT_NONE, Hin, Win, Cin, Hout, Wout, up, out_nchw, zero_pad, 0, nullptr, 0.f, out_split};
+             relu ? MASTER_ACT_RELU : MASTER_ACT_NONE, Hin, Win, Cin, Hout, Wout, up, out_nchw, zero_pad, 0, out_split};
     return a_split ? dispatch_s<true>(p, s) : dispatch<true>(p, s);
 }
 
@@ -747,6 +699,6 @@ int gemm_x3_conv3x3(const float* x, const void* w, const float* bias, float* out
 int gemm_x3_conv3x3_dgrad(const float* g, const void* wf, float* out, const float* relu_src, const float* add, int B, int H, int W,
                           int Cg, int Cx, hipStream_t s) {
     X3Args p{g, (const float*)wf, nullptr, relu_src, add, out, B * H * W, Cx, 9 * Cg, 0, Cx, Cx, MASTER_ACT_NONE, H, W, Cg, H, W, 0, 0, 1,
-             relu_src != nullptr, nullptr, 0.f, 0};
+             relu_src != nullptr, 0};
     return dispatch<true>(p, s);
 }

@@ -183,12 +183,10 @@ __global__ __launch_bounds__(NW * 64, WGPC) void mlp_x3_kernel(MlpX3Args p) {
         for (int s = 0; s < KS1; ++s) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const unsigned a = pack_bf16x2(xv[s][0][2 * j], xv[s][0][2 * j + 1]);
-                xh[s].u[j] = a;
-                xl[s].u[j] = pack_bf16x2(xv[s][0][2 * j] - __uint_as_float(a << 16), xv[s][0][2 * j + 1] - __uint_as_float(a & 0xffff0000u));
-                const unsigned b = pack_bf16x2(xv[s][1][2 * j], xv[s][1][2 * j + 1]);
-                xh[s].u[2 + j] = b;
-                xl[s].u[2 + j] = pack_bf16x2(xv[s][1][2 * j] - __uint_as_float(b << 16), xv[s][1][2 * j + 1] - __uint_as_float(b & 0xffff0000u));
+                unsigned ah, al, bh, bl;
+                split_bf16x2(xv[s][0][2 * j], xv[s][0][2 * j + 1], ah, al);
+                split_bf16x2(xv[s][1][2 * j], xv[s][1][2 * j + 1], bh, bl);
+                xh[s].u[j] = ah; xl[s].u[j] = al; xh[s].u[2 + j] = bh; xl[s].u[2 + j] = bl;
             }
         }
     }
@@ -238,9 +236,10 @@ __global__ __launch_bounds__(NW * 64, WGPC) void mlp_x3_kernel(MlpX3Args p) {
         const int jt = v >> 4, sg = (v >> 3) & 1, i = (v >> 1) & 3, z = v & 1;
         gfine[z] = gelu_erf(PIPE ? hprev[jt][8 * sg + 2 * i + z] : hacc[jt][8 * sg + 2 * i + z]);
         if (z == 1) {
-            const unsigned a = pack_bf16x2(gfine[0], gfine[1]);
+            unsigned a, l;
+            split_bf16x2(gfine[0], gfine[1], a, l);
             hfh[jt][sg].u[i] = a;
-            hfl[jt][sg].u[i] = pack_bf16x2(gfine[0] - __uint_as_float(a << 16), gfine[1] - __uint_as_float(a & 0xffff0000u));
+            hfl[jt][sg].u[i] = l;
             asm volatile("" :: "v"(hfl[jt][sg].u[i]));          // pin: LLVM otherwise sinks the arithmetic below the MFMAs
         } else {
             asm volatile("" :: "v"(gfine[0]));

@@ -44,9 +44,9 @@ union FragX { u32x4 u; bf16x8_t b; };
 __device__ __forceinline__ void split_frag(const float (&x)[8], FragX& hi, FragX& lo) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const unsigned a = pack_bf16x2(x[2 * j], x[2 * j + 1]);
-        hi.u[j] = a;
-        lo.u[j] = pack_bf16x2(x[2 * j] - __uint_as_float(a << 16), x[2 * j + 1] - __uint_as_float(a & 0xffff0000u));
+        unsigned a, l;
+        split_bf16x2(x[2 * j], x[2 * j + 1], a, l);
+        hi.u[j] = a; lo.u[j] = l;
     }
 }
 

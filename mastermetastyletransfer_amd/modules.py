@@ -81,15 +81,7 @@ class _HipModule(nn.Module):
         return self._derived("b:" + name, params, build)
 
     def _ln_linear(self, name: str, x: Tensor, norm: nn.LayerNorm, weights: Sequence[Tensor], biases: Sequence[Tensor]) -> Tensor:
-        """LayerNorm(x) @ cat(weights).T + cat(biases).  bf16 mode: one fused launch (ops.linear_ln); fp32 modes: LayerNorm, then Linear - or, split-bf16
-        mode with MASTER_X3_LNFOLD=1, the LayerNorm folded into the product (ops.linear_ln_folded; opt-in: ops.linear_ln_folded_enabled)."""
-        if self.split_weights and ops.linear_ln_folded_enabled() and ops.linear_ln_folded_supported(x, sum(w.shape[0] for w in weights)):
-            def build():
-                w = weights[0] if len(weights) == 1 else torch.cat(list(weights), dim=0)
-                b = biases[0] if len(biases) == 1 else torch.cat(list(biases), dim=0)
-                return ops.fold_layernorm(w, b, norm.weight, norm.bias)
-            ws, colsum, bf = self._derived("lnfold:" + name, list(weights) + list(biases) + [norm.weight, norm.bias], build)
-            return ops.linear_ln_folded(x, ws, colsum, bf, norm.eps)
+        """LayerNorm(x) @ cat(weights).T + cat(biases).  bf16 mode: one fused launch; fp32 modes: LayerNorm, then Linear (ops.linear_ln)"""
         return ops.linear_ln(x, self._b("n1w", norm.weight), self._b("n1b", norm.bias), self._w(name, *weights), self._b(name, *biases), eps=norm.eps)
 
     def _bias_of(self, lin: nn.Linear) -> Tensor:

@@ -25,7 +25,7 @@ K_FAMILIES = ("linear", "conv3x3", "window_attn", "layernorm", "instnorm", "patc
 EXPORTS = (
     "master_version", "master_last_error_string", "master_split_weights", "master_linear_fwd", "master_conv3x3_reflect_fwd",
     "master_window_attn_fwd", "master_layernorm_fwd", "master_instnorm_fwd", "master_patch_embed_fwd",
-    "master_patch_merge_ln_fwd", "master_patch_merge_linear_fwd", "master_resize_plan", "master_preprocess_fwd", "master_postprocess_fwd", "master_image_to_nhwc_fwd", "master_vgg_conv1_fwd", "master_conv3x3_zero_fwd", "master_maxpool2x2_fwd", "master_channel_stats_fwd", "master_stats_slices", "master_instnorm_distance_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_linear_ln_fwd", "master_linear_lnfold_fwd", "master_attn_block_fwd", "master_window_attn_proj_fwd", "master_linear_group_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
+    "master_patch_merge_ln_fwd", "master_patch_merge_linear_fwd", "master_resize_plan", "master_preprocess_fwd", "master_postprocess_fwd", "master_image_to_nhwc_fwd", "master_vgg_conv1_fwd", "master_conv3x3_zero_fwd", "master_maxpool2x2_fwd", "master_channel_stats_fwd", "master_stats_slices", "master_instnorm_distance_fwd", "master_convert", "master_mlp_fwd", "master_decoder_tail_fwd", "master_linear_ln_fwd", "master_attn_block_fwd", "master_window_attn_proj_fwd", "master_linear_group_fwd", "master_prof_enable", "master_prof_reset", "master_prof_read",
     # train step
     "master_linear_act_fwd", "master_linear_res_fwd", "master_linear_dgrad", "master_linear_wgrad", "master_gemm_workspace_floats", "master_colsum",
     "master_colsum_workspace_floats", "master_reduce_slabs", "master_reduce_segments", "master_layernorm_bwd", "master_layernorm_bwd_workspace_floats",
@@ -101,7 +101,6 @@ def load_library() -> ctypes.CDLL:
     lib.master_instnorm_distance_fwd.argtypes = [vp] * 4 + [ci] * 4 + [cf, ci, ci, vp]
     lib.master_mlp_fwd.argtypes = [vp] * 9 + [ci] * 6 + [cf, ci, vp]
     lib.master_linear_ln_fwd.argtypes = [vp] * 8 + [ci] * 6 + [cf, ci, vp]
-    lib.master_linear_lnfold_fwd.argtypes = [vp] * 6 + [ci] * 6 + [cf, ci, vp]
     lib.master_attn_block_fwd.argtypes = [vp] * 11 + [ci] * 6 + [cf, cf, ci, vp]
     lib.master_decoder_tail_fwd.argtypes = [vp] * 6 + [ci] * 4 + [vp]
     lib.master_linear_group_fwd.argtypes = [ci] + [vp] * 9 + [ci, ci, cf, ci, vp]
@@ -280,48 +279,6 @@ def linear_ln(x: torch.Tensor, ln_gamma: torch.Tensor, ln_beta: torch.Tensor, w:
                                                     _dt(x), _stream()), "master_linear_ln_fwd")
         return out
     return linear(layernorm(x, ln_gamma, ln_beta, eps), w, bias, r2=r2)
-
-
-def fold_layernorm(w: torch.Tensor, bias: Optional[torch.Tensor], ln_gamma: torch.Tensor, ln_beta: torch.Tensor):
-    """weight preparation of linear_ln_folded (split-bf16 mode): (split(W diag(gamma)), column sums of the SPLIT weights, b + W beta)"""
-    _dev(w)
-    w = w.detach().float()
-    ws = split_weights((w * ln_gamma.detach().float()[None, :]).contiguous())
-    colsum = ws.float().sum(dim=(1, 2, 3)).contiguous()                   # of hi + lo as the kernel multiplies them: the mean term cancels exactly
-    b = torch.mv(w, ln_beta.detach().float())
-    if bias is not None:
-        b = b + bias.detach().float()
-    return ws, colsum, b.contiguous()
-
-
-def linear_ln_folded_supported(x: torch.Tensor, n_out: int) -> bool:
-    """the folded LayerNorm + Linear form of the split-bf16 mode (master_linear_lnfold_fwd): fp32 rows, K % 32 == 0, N > 64"""
-    return (x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] % 32 == 0 and x.stride(0) % 4 == 0 and n_out > 64 and n_out % 4 == 0
-            and x.data_ptr() % 16 == 0)
-
-
-def linear_ln_folded_enabled() -> bool:
-    """OPT-IN (MASTER_X3_LNFOLD=1).  Measured r04: the three qkv launches it serves get 5 - 20 % faster standalone (248.6 -> 199.1 us at
-    262 144 x 384 x 128) but inside the step, where the LayerNorm's output is still in the Infinity Cache when the GEMM reads it, the
-    forward gains 0.5 - 0.8 % (5.145 -> 5.103 ms) - and subtracting mean * colsum amplifies the product's rounding by sqrt(1 + (mean / std)^2)
-    per row, which a parity mode should not take on for that."""
-    return os.environ.get("MASTER_X3_LNFOLD", "0") == "1"
-
-
-@_on_device
-def linear_ln_folded(x: torch.Tensor, w_split: torch.Tensor, colsum: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5,
-                     r2: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """LN(x) @ W.T + b (+ r2) with the LayerNorm folded into the split-bf16 product; (w_split, colsum, bias) = fold_layernorm(W, b, gamma, beta)"""
-    _dev(x, w_split)
-    M, K = x.shape
-    N = w_split.shape[0]
-    assert is_split(w_split) and w_split.shape[1] * 32 == K
-    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    if _COUNT_ON:
-        _count("linear", flops=2.0 * M * N * K, bytes=4.0 * (M * K + N * K + M * N * (1 + (r2 is not None))))
-    _check(load_library().master_linear_lnfold_fwd(_p(x), _p(w_split), _p(colsum), _p(bias), _p(r2), _p(out), M, N, K, x.stride(0), out.stride(0),
-                                                    r2.stride(0) if r2 is not None else 0, eps, F32X3, _stream()), "master_linear_lnfold_fwd")
-    return out
 
 
 @_on_device

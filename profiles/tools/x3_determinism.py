@@ -31,10 +31,6 @@ for M, N, K, act, res in [(262144, 384, 128, 0, 0), (262144, 128, 128, 0, 1), (6
     a = torch.randn(M, K, device=dev); w = ops.split_weights(torch.randn(N, K, device=dev) / K ** 0.5)
     b = torch.randn(N, device=dev); r = torch.randn(M, N, device=dev) if res else None
     check(f"linear {M}x{N}x{K} act{act} res{res}", lambda: ops.linear(a, w, b, r2=r, act=act))
-for M, N, K in [(262144, 384, 128), (65536, 768, 256), (32768, 768, 256)]:
-    a = torch.randn(M, K, device=dev) + 0.7
-    ws, cs, bf = ops.fold_layernorm(torch.randn(N, K, device=dev) / K ** 0.5, torch.randn(N, device=dev), torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev))
-    check(f"linear with folded LayerNorm {M}x{N}x{K}", lambda: ops.linear_ln_folded(a, ws, cs, bf, 1e-5))
 for B, H, Cin, Cout, up in [(32, 32, 256, 128, 0), (32, 32, 128, 128, 1), (32, 64, 128, 128, 0), (32, 64, 128, 64, 0), (32, 64, 64, 64, 1), (32, 128, 64, 32, 0),
                             (32, 128, 32, 32, 1)]:
     x = torch.randn(B, H, H, Cin, device=dev); w = ops.split_weights(torch.randn(Cout, 3, 3, Cin, device=dev) / (3 * Cin ** .5))

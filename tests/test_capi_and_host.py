@@ -257,7 +257,7 @@ def test_shared_gradient_registry_sums_the_uses_of_a_tensor(lib):
         assert torch.allclose(got, want, rtol=1e-5, atol=1e-6)
     # the first use computed fresh buffers, the other two accumulated into them; autograd saw ONE gradient per tensor
     assert [c[2] for c in calls] == [False, True, True]
-    assert reg.uses == {}
+    assert tok.uses == {}                                        # (the counts live on the scope object, one per forward: r04)
     # outside a scope every call returns its own gradient (no accumulation) and autograd adds them
     calls.clear(); x.grad = w.grad = b.grad = None
     h = x
@@ -278,16 +278,25 @@ def test_shared_gradient_registry_slots_and_stranded_uses(lib):
     reg.end(tok)
     made = []
     alloc = lambda: made.append(torch.zeros(3)) or made[-1]
-    reg._checked = tok                                           # (the end-of-backward check is queued on the autograd engine: not outside a backward pass)
+    tok.checked = True                                           # (the end-of-backward check is queued on the autograd engine: not outside a backward pass)
     out1, acc1, ret1 = reg.slot(tok, t, alloc)
     out2, acc2, ret2 = reg.slot(tok, t, alloc)
     assert (acc1, ret1) == (False, None) and acc2 is True and ret2 is out1 and out2 is out1 and len(made) == 1
-    # a tensor the forward did not count, or a token of another graph: a private buffer every time
-    o, a, r_ = reg.slot(object(), t, alloc)
+    # a ctx recorded outside any scope, or in a scope that did not count this tensor: a private buffer every time
+    o, a, r_ = reg.slot(None, t, alloc)
     assert a is False and r_ is o and len(made) == 2
+    other = reg.begin(); reg.end(other)
+    o, a, r_ = reg.slot(other, t, alloc)
+    assert a is False and r_ is o and len(made) == 3
+    # two scopes alive at once (two forwards before one backward; r03 kept ONE registry, so the second begin() threw the first's counts away)
+    t1 = reg.begin(); reg.note(t); reg.note(t); reg.end(t1)
+    t2 = reg.begin(); reg.note(t); reg.note(t); reg.end(t2)
+    t1.checked = t2.checked = True
+    a1 = reg.slot(t1, t, alloc); b1 = reg.slot(t2, t, alloc); a2 = reg.slot(t1, t, alloc); b2 = reg.slot(t2, t, alloc)
+    assert a1[2] is None and b1[2] is None and a2[2] is a1[0] and b2[2] is b1[0] and a1[0] is not b1[0] and a2[1] and b2[1]
     # a counted use that never runs backward leaves an accumulated sum undelivered: _verify raises instead of losing it silently
     tok = reg.begin(); reg.note(t); reg.note(t); reg.end(tok)
-    reg._checked = tok
+    tok.checked = True
     reg.slot(tok, t, alloc)
     with pytest.raises(ops.MasterHipError):
         reg._verify(tok)

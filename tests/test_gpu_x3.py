@@ -306,49 +306,6 @@ def test_x3_kernels_repeatable_at_scale(cuda):
     assert e.value.code == 0
 
 
-@pytest.mark.parametrize("M,N,K,offset", [(1000, 384, 128, 0.0), (4096, 768, 256, 1.0), (70000, 384, 128, 3.0), (300, 128, 256, 0.5), (129, 768, 256, 30.0),
-                                          (66000, 768, 256, 2.0)])
-def test_linear_with_folded_layernorm_x3(cuda, M, N, K, offset):
-    """master_linear_lnfold_fwd: LN(x) W^T + b evaluated as rstd (x W'^T - mean colsum) + b' (both tile configurations, ragged M, rows whose
-    mean is `offset` standard deviations away from zero: the subtraction of the mean term amplifies the product's rounding by
-    ~sqrt(1 + offset^2), and the shifted-sum statistics must hold when |mean| >> std)"""
-    from mastermetastyletransfer_amd import ops
-    g = torch.Generator().manual_seed(M + N + K)
-    x = torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g)) + offset * torch.randn(M, 1, generator=g)
-    w = torch.randn(N, K, generator=g) / K ** 0.5
-    b = torch.randn(N, generator=g); gamma = 0.5 + torch.rand(K, generator=g); beta = 0.3 * torch.randn(K, generator=g)
-    r2 = torch.randn(M, N, generator=g)
-    assert ops.linear_ln_folded_supported(x.to(cuda), N)
-    ws, colsum, bf = ops.fold_layernorm(w.to(cuda), b.to(cuda), gamma.to(cuda), beta.to(cuda))
-    out = ops.linear_ln_folded(x.to(cuda), ws, colsum, bf, 1e-5)
-    out_r = ops.linear_ln_folded(x.to(cuda), ws, colsum, bf, 1e-5, r2=r2.to(cuda))
-    ref = F.linear(F.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-5), w.double(), b.double())
-    tol = X3_KERNEL_TOL * (1.0 + offset * offset) ** 0.5 * 1.5
-    e = rel_err(out, ref)
-    assert e <= tol, f"folded LN linear {M}x{N}x{K} offset {offset}: {e:.3e} (bound {tol:.1e})"
-    assert rel_err(out_r, ref + r2.double()) <= tol
-    # the unfused pair of the same mode agrees to the same bound
-    two = ops.linear(ops.layernorm(x.to(cuda), gamma.to(cuda), beta.to(cuda)), ops.split_weights(w.to(cuda)), b.to(cuda))
-    assert rel_err(out, two.double().cpu()) <= tol + X3_KERNEL_TOL
-
-
-def test_full_forward_with_folded_layernorm_x3(cuda, monkeypatch):
-    """MASTER_X3_LNFOLD=1 (opt-in): the whole forward with the folded form in the Swin blocks' and the StyleTransformer's LN + qkv launches,
-    against the oracle at the literal 1e-3 and against the default path of the same mode"""
-    import bench
-    monkeypatch.setenv("MASTER_X3_LNFOLD", "0")
-    model = bench.build_model(cuda, "x3", 7)
-    c, s_ = bench.synthetic_batch(2, 256, cuda, seed=3)
-    with torch.no_grad():
-        base = model(c, s_, 1).clone()
-        monkeypatch.setenv("MASTER_X3_LNFOLD", "1")
-        got = model(c, s_, 1)
-    assert not torch.equal(base, got), "the folded form did not run"
-    d = float((got - base).abs().max())
-    print(f"folded LayerNorm against the default x3 path: max |d| {d:.2e} on outputs of max {float(base.abs().max()):.2f}")
-    assert d <= 2e-4
-
-
 # ---- the frozen loss network of the train step in split-bf16 (custom_loss.set_compute_dtype("bf16x3")) -------------------------------
 @pytest.mark.parametrize("B,H,W,Cg,Cx,mask,add", [(2, 16, 16, 64, 64, True, True), (1, 9, 13, 128, 64, True, False), (2, 8, 8, 512, 256, False, False),
                                                   (1, 32, 32, 64, 32, False, False), (3, 7, 5, 256, 256, True, True)])
