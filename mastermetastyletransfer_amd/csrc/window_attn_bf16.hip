@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void window_attn_bf16_kernel(AttnArgsB p) {
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    const unsigned pk = pack_bf16x2(exp2f(st[kt][qt][8 * s + 2 * jj] - m), exp2f(st[kt][qt][8 * s + 2 * jj + 1] - m));
+                    const unsigned pk = pack_bf16x2(__builtin_amdgcn_exp2f(st[kt][qt][8 * s + 2 * jj] - m), __builtin_amdgcn_exp2f(st[kt][qt][8 * s + 2 * jj + 1] - m));
                     pf[qt][kt][s].u[jj] = pk;
                     sum += __uint_as_float(pk << 16) + __uint_as_float(pk & 0xffff0000u);
                 }

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_f32_kernel(AttnBwdArgs p)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { const float pe = exp2f(st[kt][qt][e] - m); st[kt][qt][e] = pe; s += pe; }
+            for (int e = 0; e < 16; ++e) { const float pe = __builtin_amdgcn_exp2f(st[kt][qt][e] - m); st[kt][qt][e] = pe; s += pe; }
         s += __shfl_xor(s, 32, 64);
         const float inv = 1.0f / s;
 #pragma unroll
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_f32_kernel(AttnBwdArgs p)
         for (int e = 0; e < 16; ++e) {
             const float L = lrow[wave][qt * 32 + rowof(e, h)];
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) pq[qt][kt][e] = exp2f(pq[qt][kt][e] - L);
+            for (int kt = 0; kt < 2; ++kt) pq[qt][kt][e] = __builtin_amdgcn_exp2f(pq[qt][kt][e] - L);      // raw v_exp_f32: the argument is <= 0 (exp2f adds a 4-instruction range fix-up per value)
         }
 
     // rows of one key slot: the token row for a real token, the pad-slot buffer for a zero-padded slot
