@@ -52,7 +52,8 @@ __device__ __forceinline__ void split_frag(const float (&x)[8], FragX& hi, FragX
 
 template <bool DUAL, bool X3>
 __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // uniform: the problem's bases and table pointers become scalar arithmetic
     const int r = lane & 31, h = lane >> 5;
     // problem id: heads of one window are adjacent waves (same gather table, same rows of K/V in L2)
     const int pid = blockIdx.x * 4 + wave;
@@ -93,20 +94,31 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
     // ---- V^T rows (A operand of O^T = V^T P^T: channel on the lane, one key per k-step = accumulator register (kt, e)): requested
     //      now, consumed after the softmax
     float vv0[2][16], vv1[2][16];
+    // r04: the row of key (kt, e) is the same for all 32 lanes of a half-wave, so its byte offset comes from the lane that holds the slot
+    // (ONE ds_bpermute; the LDS pipe is otherwise idle here) instead of two readlanes + a per-half select + a multiply, and whether the slot
+    // is a real token is a SCALAR bit test on a ballot of the table (the padded slots take the pad row through one v_cndmask on a scalar
+    // lane mask): 2 vector instructions per V element instead of 8 in a kernel that is bound by their count.
+    const int my_voff = my_src >= 0 ? my_src * (p.ldv * 4) : 0;              // padded slots read row 0 (any valid address), then take the pad value
+    const unsigned long long real_slots = __ballot(my_src >= 0);
+    const int bp_sel = 16 * h;                                               // ds_bpermute address of lane 4 h
     auto load_v = [&](const float* v, const float* v_pad, float (&vv)[2][16]) __attribute__((always_inline)) {
-        const float* vpad = v_pad + (size_t)b * p.v_pad_bs + coff + r;
+        const float padv = v_pad[(size_t)b * p.v_pad_bs + coff + r];
         const char* vb = (const char*)(v + tok0 * p.ldv);
-        const unsigned lane_off = (unsigned)((coff + r) * 4), row_bytes = (unsigned)(p.ldv * 4);
+        const int lane_off = (coff + r) * 4;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int key0 = kt * 32 + (e & 3) + 8 * (e >> 2);                   // half 0's key; half 1 takes key0 + 4
-                const int i0 = __builtin_amdgcn_readlane(my_src, key0), i1 = __builtin_amdgcn_readlane(my_src, key0 + 4);
-                const int idx = h ? i1 : i0;
-                // (slots >= N carry idx = -1 like zero-padded ones: they read the finite pad row, and their probability is exactly 0 -
-                // bias -1e30 - so no separate select to zero them)
-                vv[kt][e] = idx >= 0 ? *(const float*)(vb + ((unsigned)idx * row_bytes + lane_off)) : *vpad;
+                const int off = __builtin_amdgcn_ds_bpermute(bp_sel + 4 * key0, my_voff);
+                const float a = *(const float*)(vb + (unsigned)(off + lane_off));
+                // lanes 0-31: is slot key0 real, lanes 32-63: is slot key0 + 4 real (slots >= N count as padded: they read the finite pad
+                // row and their probability is exactly 0 - bias -1e30)
+                const unsigned long long m = (((real_slots >> key0) & 1ull) ? 0x00000000ffffffffull : 0ull) |
+                                             (((real_slots >> (key0 + 4)) & 1ull) ? 0xffffffff00000000ull : 0ull);
+                float sel;
+                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sel) : "v"(padv), "v"(a), "s"(m));
+                vv[kt][e] = sel;
             }
     };
     load_v(p.v0, p.v0_pad, vv0);
