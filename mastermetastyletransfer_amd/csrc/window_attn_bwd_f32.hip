@@ -37,7 +37,8 @@ __device__ __forceinline__ int rowof(int e, int h) { return (e & 3) + 8 * (e >> 
 template <bool DUAL>
 __global__ __launch_bounds__(256) void window_attn_bwd_f32_kernel(AttnBwdArgs p) {
     __shared__ float lrow[4][64], drow[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // uniform: the problem's bases become scalar arithmetic (r04)
     const int r = lane & 31, h = lane >> 5;
     const int pid = blockIdx.x * 4 + wave;
     const int total = p.B * p.nW * p.heads;
