@@ -119,7 +119,9 @@ class custom_loss(nn.Module):
             if not os.path.exists(path):
                 raise ValueError(f"VGG-19 weights not found at {path}: the reference downloads them from torchvision (utils.py:10-57), "
                                  "which needs a network; save vgg19().features[:30].state_dict() there or pass vgg_state_dict=")
-            loaded = torch.load(path, map_location="cpu")
+            # the reference's file is a pickled MODULE (utils.py:10-57 torch.save(<cut nn.Sequential>), read by loss.py:163-168 with a plain
+            # torch.load): it needs weights_only=False on a current torch (as model.py does for the cut Swin encoder file)
+            loaded = torch.load(path, map_location="cpu", weights_only=False)
             vgg_state_dict = loaded.state_dict() if isinstance(loaded, nn.Module) else loaded
         self.feature_extractor_model.features.load_state_dict(vgg_state_dict)
         for param in self.feature_extractor_model.parameters():               # loss.py:173-175

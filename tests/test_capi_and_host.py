@@ -443,3 +443,29 @@ def test_trace_by_shape_prints_the_whole_grid(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "profiles", "trace_by_shape.py"), str(p), "1"], capture_output=True, text=True, check=True).stdout
     assert "wgs=    16x32" in out and "wgs=       16 " in out
+
+
+def test_custom_loss_reads_the_cut_vgg_file_both_ways(tmp_path, lib):
+    """loss.py:163-175: the reference torch.load()s `weights/vgg_19_last_layer_is_relu_5_1_output.pt`, which utils.py:10-57 wrote with
+    torch.save(<the cut nn.Sequential>) - a pickled MODULE; a state-dict file with torchvision's `features` keys is accepted too.  Both
+    forms, the default relative path and an explicit one; a missing file names the reason (no network to download ImageNet weights)."""
+    from mastermetastyletransfer_amd import VGG19_custom, custom_loss
+    torch.manual_seed(3)
+    cut = VGG19_custom().features                                     # torchvision vgg19().features[:30]: same child indices / keys
+    for m_ in cut.modules():
+        if isinstance(m_, torch.nn.Conv2d):
+            torch.nn.init.normal_(m_.weight, std=0.02); torch.nn.init.normal_(m_.bias, std=0.02)
+    (tmp_path / "weights").mkdir()
+    torch.save(cut, tmp_path / "weights" / "vgg_19_last_layer_is_relu_5_1_output.pt")              # the module itself (the reference's format)
+    torch.save(cut.state_dict(), tmp_path / "weights" / "vgg_sd.pt")
+    a = custom_loss(project_absolute_path=str(tmp_path))                                              # default relative path
+    b = custom_loss(project_absolute_path=str(tmp_path), feature_extractor_model_relative_path="weights/vgg_sd.pt", default_lambda_value=3)
+    for lf in (a, b):
+        got = lf.feature_extractor_model.features.state_dict()
+        assert set(got) == set(cut.state_dict()) and all(torch.equal(got[k], v) for k, v in cut.state_dict().items())
+        assert not any(p.requires_grad for p in lf.feature_extractor_model.parameters())              # loss.py:173-175
+    assert a.lambda_value == 10 and b.lambda_value == 3
+    with pytest.raises(ValueError, match="VGG-19 weights not found"):
+        custom_loss(project_absolute_path=str(tmp_path / "nowhere"))
+    with pytest.raises(NotImplementedError):
+        custom_loss(project_absolute_path=str(tmp_path), use_vgg19_with_batchnorm=True)
