@@ -240,7 +240,7 @@ def latest_profile(suffix):
 
 
 _PROFILES_READ = set()
-PROFILE_DERIVED_KEYS = ["roofline.traffic", "attn_core.cross_attn_kernel_mfma_busy_pct_pmc", "attn_core.qk_phase_from_committed_probe",
+PROFILE_DERIVED_KEYS = ["roofline.traffic", "x3_mode.roofline.traffic", "attn_core.cross_attn_kernel_mfma_busy_pct_pmc", "attn_core.qk_phase_from_committed_probe",
                         "train_step.roofline.traffic", "train_step.launches_k2_step.torch_from_committed_trace_avg_over_traced_k"]
 
 
@@ -415,13 +415,26 @@ def extras(model, content, style, k, args, ops):
         c5, s5 = synthetic_batch(16, 512, content.device, seed=5)
         t53 = timed(c5, s5, 4, warm=1)
         del c5, s5
+        # HBM bytes per launch of the dominant family from the committed PMC passes of `bench.py --dtype x3` (profiles/collect.sh x3)
+        X3_PMC = {"mlp": ("mlp_x3_kernel",), "linear": ("gemm_x3_kernel<256, 128, 64, 64, false", "gemm_x3_kernel<128, 128, 32, 64, false", "gemm_x3_kernel<128, 64, 32, 32, false"),
+                  "conv3x3": ("gemm_x3s_kernel", "gemm_x3_kernel<128, 128, 32, 64, true"), "window_attn": ("window_attn_f32_kernel",)}
+        tr3 = tr3_src = None
+        p3 = latest_profile("x3_bs32_pmc_traffic.json")
+        if p3 is not None and B == 32 and S == 256 and k == 1:
+            pj = json.load(open(p3)); tb = tn = 0.0
+            for name, v in pj.items():
+                if any(name.startswith(pfx) for pfx in X3_PMC.get(dom3, ())):
+                    tb += v["hbm_bytes_per_launch"] * v["launches"]; tn += v["launches"]
+            if tn:
+                tr3, tr3_src = round(tb / tn), os.path.relpath(p3, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         out["x3_mode"] = {"note": "fast parity mode: fp32 storage, every Linear / convolution as three bf16 MFMAs per product on operands split "
                                   "into bf16 hi + lo (csrc/gemm_x3.hip, mlp_x3.hip); meets the 1e-3 max-abs bar (parity_x3_mode)",
                           "config1_bs%d_%d" % (B, S): {"images_per_s": round(B / t3, 1), "ms_per_step": round(t3 * 1e3, 3), "steps": 20, "launch": "hipGraph replay"},
                           "config5_bs16_512": {"images_per_s": round(16 / t53, 1), "ms_per_step": round(t53 * 1e3, 3), "steps": 4, "launch": "eager"},
                           "kernels": fam3,
                           "roofline": {"family": dom3, "bound": "mfma", "achieved": round(ach3, 2), "peak": round(PEAK_TFLOPS["x3"], 1), "unit": "TFLOP/s",
-                                       "frac": round(ach3 / PEAK_TFLOPS["x3"], 4), "traffic": None,
+                                       "frac": round(ach3 / PEAK_TFLOPS["x3"], 4), "traffic": tr3, "traffic_source": tr3_src,
+                                       "alg_bytes_per_launch": (counts3[dom3].get("bytes", 0.0) / prof3[dom3][0]) if prof3[dom3][0] else None,
                                        "note": "algorithmic flops over the eager event-timed launches of the family; peak = 2.5 PF / 3 (three bf16 MFMAs per product)",
                                        "avg_launch_us": round(prof3[dom3][1] / prof3[dom3][0] * 1e3, 2)}}
         model.set_compute_dtype(torch.bfloat16)
