@@ -547,3 +547,96 @@ def test_default_constructor_window8_x3(cuda, S):
     err, top = float((got - ref).abs().max()), float(ref.abs().max())
     print(f"window 8, {S}^2, x3: max|d| {err:.2e} on outputs of max {top:.2f}")
     assert err <= (ABS_TOL if top <= 10 else 1e-4 * top)          # the rule of tests/test_gpu_parity.py::assert_close(absolute=True)
+
+
+def test_x3_gemm_random_shapes(cuda):
+    """40 random Linear shapes (ragged M, N from 1 to 1100 incl. N % 4 != 0, K = 32 ... 1024, every epilogue form) and 16 random convolution
+    shapes (odd maps, 1 - 3 images, upsample on / off, reflect and zero padding) through the split-bf16 GEMM against float64: the tile
+    dispatch, the clamped dummy look-ahead chunks and the row / element epilogues on sizes nobody picked by hand"""
+    from mastermetastyletransfer_amd import ops
+    g = torch.Generator().manual_seed(20261004)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    for case in range(40):
+        M, N, K = ri(1, 3000), ri(1, 1100), 32 * ri(1, 32)
+        if case % 5 == 0:
+            M = ri(60000, 70000)                                                   # the 256-row tiles
+            N, K = min(N, 400), min(K, 256)
+        a = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g) if case % 3 else None
+        r1 = torch.randn(M, N, generator=g) if case % 4 == 1 else None
+        r2 = torch.randn(M, N, generator=g) if case % 2 else None
+        act = (ops.ACT_NONE, ops.ACT_GELU, ops.ACT_RELU)[case % 3]
+        out = ops.linear(a.to(cuda), ops.split_weights(w.to(cuda)), None if b is None else b.to(cuda), r1=None if r1 is None else r1.to(cuda),
+                         r2=None if r2 is None else r2.to(cuda), act=act)
+        ref = a.double() @ w.double().t() + (0 if b is None else b.double())
+        ref = F.gelu(ref) if act == ops.ACT_GELU else (F.relu(ref) if act == ops.ACT_RELU else ref)
+        if r1 is not None:
+            ref = ref * r1.double()
+        if r2 is not None:
+            ref = ref + r2.double()
+        e = rel_err(out, ref)
+        assert e <= 2 * X3_KERNEL_TOL, f"linear {M}x{N}x{K} act{act} r1{r1 is not None} r2{r2 is not None}: {e:.2e}"
+    for case in range(16):
+        B, H, W = ri(1, 3), ri(3, 40), ri(3, 40)
+        Cin, Cout = 32 * ri(1, 8), (ri(1, 8) * 32 if case % 3 else ri(5, 200))
+        up, zero = bool(case % 2), case % 4 == 3
+        x = torch.randn(B, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5; b = torch.randn(Cout, generator=g)
+        xd = x.permute(0, 2, 3, 1).contiguous().to(cuda); wd = ops.split_weights(w.permute(0, 2, 3, 1).contiguous().to(cuda))
+        if zero:
+            out = ops.conv3x3_zero(xd, wd, b.to(cuda), relu=True)
+            ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+        else:
+            out = ops.conv3x3_reflect(xd, wd, b.to(cuda), up, True)
+            xs = F.interpolate(x.double(), scale_factor=2, mode="nearest") if up else x.double()
+            ref = F.relu(F.conv2d(F.pad(xs, (1, 1, 1, 1), mode="reflect"), w.double(), b.double()))
+        e = rel_err(out.permute(0, 3, 1, 2), ref)
+        assert e <= 2 * X3_KERNEL_TOL, f"conv {B}x{H}x{W} {Cin}->{Cout} up{up} zero{zero}: {e:.2e}"
+
+
+def test_x3_fused_kernels_random_shapes(cuda):
+    """random token counts / hidden widths for the fused split MLP, random map sizes, shifts, head counts and batch sizes for the split window
+    attention (against the exact-fp32 kernel), random source sizes for the fused decoder tail (against the two-launch path): the ragged
+    edges of every fused split kernel on sizes nobody picked by hand"""
+    from mastermetastyletransfer_amd import ops
+    from mastermetastyletransfer_amd.window_plan import window_plan
+    g = torch.Generator().manual_seed(4102026)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    for case in range(14):
+        C = (128, 256)[case % 2]; M = ri(1, 3000); HID = 64 * ri(1, 4 * C // 64)
+        ln, res = bool(case & 2), bool(case & 4)
+        x = torch.randn(M, C, generator=g) + 0.2
+        w1, b1 = torch.randn(HID, C, generator=g) / C ** 0.5, torch.randn(HID, generator=g) * 0.1
+        w2, b2 = torch.randn(C, HID, generator=g) / HID ** 0.5, torch.randn(C, generator=g) * 0.1
+        lg, lb = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+        xd = x.to(cuda)
+        assert ops.mlp_fused_supported(xd, HID, True)
+        out = ops.mlp(xd, ops.split_weights(w1.to(cuda)), b1.to(cuda), ops.split_weights(w2.to(cuda), layout=1), b2.to(cuda), res=xd if res else None,
+                      ln_gamma=lg.to(cuda) if ln else None, ln_beta=lb.to(cuda) if ln else None)
+        xin = F.layer_norm(x.double(), (C,), lg.double(), lb.double(), 1e-5) if ln else x.double()
+        ref = F.linear(F.gelu(F.linear(xin, w1.double(), b1.double())), w2.double(), b2.double()) + (x.double() if res else 0)
+        e = rel_err(out, ref)
+        assert e <= 2 * X3_KERNEL_TOL, f"mlp M={M} C={C} HID={HID} ln{ln} res{res}: {e:.2e}"
+    for case in range(10):
+        heads, B, H, W = (4, 8, 2, 6)[case % 4], ri(1, 3), ri(5, 40), ri(5, 40)
+        shift = (0, 0) if case % 3 == 0 else ((3, 3) if case % 3 == 1 else (4, 4))
+        dual = bool(case & 1)
+        C, T = heads * 32, H * W
+        qkv = (torch.randn(B * T, 4 * C, generator=g) * 1.5).to(cuda)
+        pads = torch.randn(3, C, generator=g).to(cuda)
+        bias64 = torch.zeros(heads, 64, 64); bias64[:, :, 49:] = -1e30; bias64[:, :49, :49] = torch.randn(heads, 49, 49, generator=g) * 0.5
+        plan = window_plan(H, W, [7, 7], list(shift), cuda)
+        args = (qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:3 * C], qkv[:, 3 * C:] if dual else None, pads[0], pads[1], pads[2] if dual else None,
+                bias64.to(cuda), plan.src, plan.region, B, T, heads, plan.nW, plan.N, 32 ** -0.5)
+        for a, b in zip(ops.window_attn(*args, x3=True), ops.window_attn(*args)):
+            if b is not None:
+                assert rel_err(a, b.double().cpu()) < 5e-5, f"attention heads{heads} B{B} {H}x{W} shift{shift} dual{dual}"
+    for case in range(6):
+        B, Hs, Ws = ri(1, 3), 4 * ri(1, 12), 16 * ri(1, 5)
+        x = torch.randn(B, Hs, Ws, 32, generator=g).to(cuda)
+        w8 = (torch.randn(32, 3, 3, 32, generator=g) / 17).to(cuda); w9 = (torch.randn(3, 3, 3, 32, generator=g) / 17).to(cuda)
+        b8, b9 = (torch.randn(32, generator=g) * 0.1).to(cuda), (torch.randn(3, generator=g) * 0.1).to(cuda)
+        assert ops.decoder_tail_supported(x, 32, True)
+        got = ops.decoder_tail(x, ops.split_weights(w8), b8, ops.split_weights(w9), b9)
+        ref = F.conv2d(F.pad(F.relu(F.conv2d(F.pad(F.interpolate(x.permute(0, 3, 1, 2).double(), scale_factor=2, mode="nearest"), (1, 1, 1, 1), mode="reflect"),
+                                              w8.permute(0, 3, 1, 2).double(), b8.double())), (1, 1, 1, 1), mode="reflect"), w9.permute(0, 3, 1, 2).double(), b9.double())
+        assert rel_err(got, ref.cpu()) <= 3 * X3_KERNEL_TOL, f"tail {B}x{Hs}x{Ws}"
