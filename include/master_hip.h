@@ -48,7 +48,14 @@ enum master_dtype {
      * master_mlp_fwd (activations, bias, residuals and outputs fp32 exactly as with MASTER_F32, the WEIGHT operand must have gone through
      * master_split_weights) and by master_window_attn_fwd (all operands fp32: Q, K, V and the probabilities are split in registers).
      * Every other kernel of this mode runs with MASTER_F32. */
-    MASTER_F32X3 = 2
+    MASTER_F32X3 = 2,
+    /* The same three-product form with IEEE-HALF halves (hi = half(x), lo = half(x - hi); v_mfma_f32_32x32x16_f16): 11 significant bits per
+     * half instead of 8, so hi + lo carries x to 2^-22 instead of 2^-17 and the stylized image sits at the exact-fp32 mode's distance from
+     * the CPU path (r05: 7e-5 max-abs where the bf16 halves give 7e-4 ... 1e-3 on the same pairs), at the same matrix-core rate.  What it
+     * gives up is fp32's exponent range: an operand beyond +-65 504 becomes inf (as under fp16 autocast), values below 2^-14 lose their
+     * low half gradually (the matrix core takes subnormal halves).  Accepted wherever MASTER_F32X3 is, except master_conv3x3_dgrad (gradients
+     * need fp32's range); weights = master_split_weights(..., layout | MASTER_SPLIT_F16). */
+    MASTER_F16X3 = 3
 };
 /* OR-ed into the `dtype` argument of master_linear_wgrad / master_colsum / master_layernorm_bwd: the parameter gradient is ADDED to
  * the output buffer (dw and dbias / out / dgb) instead of overwriting it - the gradient of a tensor used several times in one graph (the k
@@ -61,7 +68,9 @@ enum master_flags {
      * same bytes and row stride as the fp32 matrix - and / or the OUTPUT is written in it (N, ldo % 32 == 0; NHWC).  A chain of
      * convolutions (decoder.py:24-54) then hands its maps on in the form the next layer's LDS-DMA pieces copy: no split arithmetic and
      * no LDS stores in the consumer's loop.  hi + lo reproduces the fp32 value to 2^-17 relative. */
-    MASTER_A_SPLIT = 0x200, MASTER_OUT_SPLIT = 0x400
+    MASTER_A_SPLIT = 0x200, MASTER_OUT_SPLIT = 0x400,
+    /* OR-ed into the `layout` argument of master_split_weights: IEEE-half halves (for MASTER_F16X3) instead of bf16 halves */
+    MASTER_SPLIT_F16 = 0x10
 };
 enum master_act { MASTER_ACT_NONE = 0, MASTER_ACT_GELU = 1 /* exact erf */, MASTER_ACT_RELU = 2 };
 
@@ -85,7 +94,8 @@ int master_linear_fwd(const void* a, const void* w, const void* bias, const void
  * 128-byte row segments the GEMM's LDS-DMA pieces copy.  Done once per weight (the host mirror caches it per parameter version).
  * layout 0: k in natural order (master_linear_fwd, master_conv3x3_reflect_fwd, w1 of master_mlp_fwd).  layout 1: inside every group of
  * 16 k the order 0-3, 8-11, 4-7, 12-15 - the order in which a packed 32x32 MFMA accumulator tile presents its rows as an operand; w2 of
- * master_mlp_fwd (MASTER_F32X3) must be in this layout, so that the GELU'd hidden tile feeds the second product without a lane exchange. */
+ * master_mlp_fwd (MASTER_F32X3) must be in this layout, so that the GELU'd hidden tile feeds the second product without a lane exchange.
+ * layout | MASTER_SPLIT_F16: the halves are IEEE half instead of bf16 (the weight operand of MASTER_F16X3). */
 int master_split_weights(const float* w, void* out, size_t rows, size_t K, int layout, master_stream_t stream);
 
 /* master_linear_fwd with the block's LayerNorm folded in:  out = r1 (.) (LayerNorm(x) . w^T + bias) + r2, one launch

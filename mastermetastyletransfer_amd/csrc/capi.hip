@@ -101,15 +101,19 @@ int postprocess_launch(const float*, uint8_t*, int, int, int, hipStream_t);
 int mlp_c128_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const float*,
                   const bf16_t*, bf16_t*, int, int, int, int, int, int, float, hipStream_t);
 
-int gemm_x3_split_weights(const float*, void*, size_t, size_t, int, hipStream_t);
-int conv_tail_x3(const void*, int, const void*, const float*, const void*, const float*, float*, int, int, int, hipStream_t);
+int gemm_x3_split_weights(const float*, void*, size_t, size_t, int, hipStream_t, int fmt);
+int conv_tail_x3(const void*, int, const void*, const float*, const void*, const float*, float*, int, int, int, hipStream_t, int fmt);
 int mlp_x3(const float*, const float*, const float*, const void*, const float*, const void*, const float*, const float*, float*, int, int, int, int, int, int,
-           float, hipStream_t);
+           float, hipStream_t, int fmt);
 int gemm_x3_linear(const float*, const void*, const float*, const float*, const float*, float*, int, int, int, int, int, int, int, hipStream_t,
-                   int a_split, int out_split);
+                   int a_split, int out_split, int fmt);
 int gemm_x3_conv3x3(const float*, const void*, const float*, float*, int, int, int, int, int, int, int, int, hipStream_t, int zero_pad, int a_split,
-                    int out_split);
+                    int out_split, int fmt);
 int gemm_x3_conv3x3_dgrad(const float*, const void*, float*, const float*, const float*, int, int, int, int, int, hipStream_t);
+
+// the two split-operand parity modes: bf16 halves (MASTER_F32X3) and IEEE-half halves (MASTER_F16X3); the kernels' format code (common.h)
+static inline bool is_x3(int dtype) { return dtype == MASTER_F32X3 || dtype == MASTER_F16X3; }
+static inline int x3_fmt(int dtype) { return dtype == MASTER_F16X3 ? X3_F16 : X3_BF16; }
 
 // ---- error string -------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -339,7 +343,8 @@ int master_conv3x3_dgrad(const void* g, const void* wf, void* out, const void* r
         return gemm_bf16_conv3x3_dgrad((const bf16_t*)g, (const bf16_t*)wf, (bf16_t*)out, (const bf16_t*)relu_src, (const bf16_t*)add, B, H, W, Cg, Cx, sb);
     }
     if (dtype == MASTER_F32X3) {         // the frozen loss network in split-bf16: fp32 gradients, wf = master_split_weights of the flipped weights
-        REQUIRE(full == 0 && B > 0 && H > 0 && W > 0 && Cg % 32 == 0 && Cx > 0 && al16(g) && al16(wf), "conv3x3_dgrad(x3): zero-padded form, Cg %% 32 == 0");
+        REQUIRE(full == 0 && B > 0 && H > 0 && W > 0 && Cg > 0 && Cg % 32 == 0 && Cg <= 512 && Cx > 0 && al16(g) && al16(wf) && al16(out),
+                "conv3x3_dgrad(x3): zero-padded form, 0 < Cg <= 512, Cg %% 32 == 0, 16-byte aligned g / wf / out");
         hipStream_t sx = (hipStream_t)stream;
         ProfScope psx(MASTER_K_CONV_DGRAD, sx);
         return gemm_x3_conv3x3_dgrad((const float*)g, wf, (float*)out, (const float*)relu_src, (const float*)add, B, H, W, Cg, Cx, sx);
@@ -347,6 +352,7 @@ int master_conv3x3_dgrad(const void* g, const void* wf, void* out, const void* r
     F32_ONLY("conv3x3_dgrad");
     REQUIRE(B > 0 && H > 0 && W > 0 && Cg > 0 && Cg % 32 == 0 && Cx > 0 && (full == 0 || full == 1), "conv3x3_dgrad: bad dims (Cg=%d)", Cg);
     REQUIRE(al16(g) && al16(wf), "conv3x3_dgrad: g/wf must be 16-byte aligned");
+    REQUIRE(Cg <= 512, "conv3x3_dgrad: Cg <= 512 (taps outside the image read a 512-float zero row; got %d)", Cg);
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_CONV_DGRAD, s);
     return gemm_f32_conv3x3_dgrad((const float*)g, (const float*)wf, (float*)out, (const float*)relu_src, (const float*)add, B, H, W, Cg, Cx,
@@ -526,16 +532,19 @@ int master_linear_fwd(const void* a, const void* w, const void* bias, const void
     REQUIRE(act >= MASTER_ACT_NONE && act <= MASTER_ACT_RELU, "linear: bad act %d", act);
     const int io = dtype & (MASTER_A_SPLIT | MASTER_OUT_SPLIT);
     dtype &= ~(MASTER_A_SPLIT | MASTER_OUT_SPLIT);
-    REQUIRE(io == 0 || dtype == MASTER_F32X3, "linear: MASTER_A_SPLIT / MASTER_OUT_SPLIT go with MASTER_F32X3");
+    REQUIRE(io == 0 || is_x3(dtype), "linear: MASTER_A_SPLIT / MASTER_OUT_SPLIT go with MASTER_F32X3 / MASTER_F16X3");
     REQUIRE(!(io & MASTER_A_SPLIT) || lda % 32 == 0, "linear: a split A operand has whole 32-wide chunks per row (lda %% 32 == 0)");
     REQUIRE(!(io & MASTER_OUT_SPLIT) || (N % 32 == 0 && ldo % 32 == 0 && al16(out)), "linear: a split output needs N, ldo %% 32 == 0");
+    // the split epilogue exists in the whole-row form only: everything it loads must be addressable in 16-byte pieces
+    REQUIRE(!(io & MASTER_OUT_SPLIT) || ((!bias || al16(bias)) && ((!r1 && !r2) || (ldr % 4 == 0 && (!r1 || al16(r1)) && (!r2 || al16(r2))))),
+            "linear: a split output needs 16-byte aligned bias / r1 / r2 and ldr %% 4 == 0");
     const int ea = dtype == MASTER_BF16 ? 8 : 4;   // elements per 16 B
     REQUIRE(al16(a) && al16(w) && lda % ea == 0, "linear: a/w must be 16-byte aligned, lda%%%d==0", ea);
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_LINEAR, s);
-    if (dtype == MASTER_F32X3)
+    if (is_x3(dtype))
         return gemm_x3_linear((const float*)a, w, (const float*)bias, (const float*)r1, (const float*)r2, (float*)out, M, N, K, lda, ldo,
-                              ldr, act, s, (io & MASTER_A_SPLIT) != 0, (io & MASTER_OUT_SPLIT) != 0);
+                              ldr, act, s, (io & MASTER_A_SPLIT) != 0, (io & MASTER_OUT_SPLIT) != 0, x3_fmt(dtype));
     if (dtype == MASTER_F32)
         return gemm_f32_linear((const float*)a, (const float*)w, (const float*)bias, (const float*)r1,
                                (const float*)r2, (float*)out, M, N, K, lda, ldo, ldr, act, s);
@@ -555,9 +564,11 @@ int master_linear_fwd(const void* a, const void* w, const void* bias, const void
 
 int master_split_weights(const float* w, void* out, size_t rows, size_t K, int layout, master_stream_t stream) {
     REQUIRE(w && out && rows > 0 && K > 0 && K % 32 == 0, "split_weights: need K%%32==0 (rows=%zu K=%zu)", rows, K);
-    REQUIRE(layout == 0 || layout == 1, "split_weights: layout 0 (plain) or 1 (accumulator k order)");
+    const int fmt = (layout & MASTER_SPLIT_F16) ? X3_F16 : X3_BF16;
+    layout &= ~MASTER_SPLIT_F16;
+    REQUIRE(layout == 0 || layout == 1, "split_weights: layout 0 (plain) or 1 (accumulator k order), optionally | MASTER_SPLIT_F16");
     REQUIRE(al16(w) && al16(out), "split_weights: 16-byte alignment");
-    return gemm_x3_split_weights(w, out, rows, K, layout, (hipStream_t)stream);
+    return gemm_x3_split_weights(w, out, rows, K, layout, (hipStream_t)stream, fmt);
 }
 
 int master_linear_ln_fwd(const void* x, const float* ln_gamma, const float* ln_beta, const void* w, const void* bias,
@@ -636,12 +647,12 @@ int master_mlp_fwd(const void* x, const float* ln_gamma, const float* ln_beta, c
     REQUIRE(x && w1 && b1 && w2 && b2 && out, "mlp: null operand");
     REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), "mlp: ln_gamma and ln_beta come together");
     REQUIRE(M > 0 && C > 0 && HID > 0 && ldx >= C && ldo >= C && (res == nullptr || ldr >= C), "mlp: bad dims");
-    if (dtype == MASTER_F32X3) {
+    if (is_x3(dtype)) {
         REQUIRE(al16(x) && al16(w1) && al16(w2) && al16(out) && (!res || al16(res)) && ldx % 4 == 0 && ldo % 4 == 0 && ldr % 4 == 0,
                 "mlp(x3): alignment (x/w/res/out 16 B, ldx, ldo, ldr %% 4)");
         hipStream_t s3 = (hipStream_t)stream;
         ProfScope ps3(MASTER_K_MLP, s3);
-        return mlp_x3((const float*)x, ln_gamma, ln_beta, w1, b1, w2, b2, (const float*)res, (float*)out, M, C, HID, ldx, ldr, ldo, eps, s3);
+        return mlp_x3((const float*)x, ln_gamma, ln_beta, w1, b1, w2, b2, (const float*)res, (float*)out, M, C, HID, ldx, ldr, ldo, eps, s3, x3_fmt(dtype));
     }
     if (dtype != MASTER_BF16) { master_set_error("mlp: fused kernel is bf16 / f32x3 only; use two master_linear_fwd calls in fp32 mode"); return MASTER_ERR_UNSUPPORTED; }
     REQUIRE(al16(x) && al16(w1) && al16(w2) && ldx % 8 == 0 && ldo % 4 == 0 && ldr % 4 == 0, "mlp: alignment (x/w 16 B, ldx%%8, ldo%%4, ldr%%4)");
@@ -669,13 +680,14 @@ int master_conv3x3_reflect_fwd(const void* x, const void* w, const void* bias, v
     REQUIRE(al16(x) && al16(w), "conv3x3: x/w must be 16-byte aligned");
     const int io = dtype & (MASTER_A_SPLIT | MASTER_OUT_SPLIT);
     dtype &= ~(MASTER_A_SPLIT | MASTER_OUT_SPLIT);
-    REQUIRE(io == 0 || dtype == MASTER_F32X3, "conv3x3: MASTER_A_SPLIT / MASTER_OUT_SPLIT go with MASTER_F32X3");
-    REQUIRE(!(io & MASTER_OUT_SPLIT) || (Cout % 32 == 0 && !out_nchw && al16(out)), "conv3x3: a split output is NHWC with Cout %% 32 == 0");
+    REQUIRE(io == 0 || is_x3(dtype), "conv3x3: MASTER_A_SPLIT / MASTER_OUT_SPLIT go with MASTER_F32X3 / MASTER_F16X3");
+    REQUIRE(!(io & MASTER_OUT_SPLIT) || (Cout % 32 == 0 && !out_nchw && al16(out) && (!bias || al16(bias))),
+            "conv3x3: a split output is NHWC with Cout %% 32 == 0 and a 16-byte aligned bias");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_CONV, s);
-    if (dtype == MASTER_F32X3)
+    if (is_x3(dtype))
         return gemm_x3_conv3x3((const float*)x, w, (const float*)bias, (float*)out, B, Hin, Win, Cin, Cout, upsample, relu, out_nchw, s, 0,
-                               (io & MASTER_A_SPLIT) != 0, (io & MASTER_OUT_SPLIT) != 0);
+                               (io & MASTER_A_SPLIT) != 0, (io & MASTER_OUT_SPLIT) != 0, x3_fmt(dtype));
     if (dtype == MASTER_F32)
         return gemm_f32_conv3x3((const float*)x, (const float*)w, (const float*)bias, (float*)out, B, Hin, Win, Cin,
                                 Cout, upsample, relu, out_nchw, s);
@@ -700,12 +712,17 @@ int master_conv3x3_zero_fwd(const void* x, const void* w, const void* bias, void
     REQUIRE(al16(x) && al16(w), "conv3x3_zero: x/w must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_CONV, s);
-    if (dtype == MASTER_F32)
+    if (dtype == MASTER_F32) {
+        REQUIRE(Cin <= 512, "conv3x3_zero: Cin <= 512 (taps outside the image read a 512-float zero row; got %d)", Cin);
         return gemm_f32_conv3x3((const float*)x, (const float*)w, (const float*)bias, (float*)out, B, H, W, Cin, Cout, 0, relu, 0, s, 1);
+    }
     if (dtype == MASTER_BF16)
         return gemm_bf16_conv3x3((const bf16_t*)x, (const bf16_t*)w, (const float*)bias, out, B, H, W, Cin, Cout, 0, relu, 0, s, 1);
-    if (dtype == MASTER_F32X3)           // fp32 maps, w = master_split_weights of the packed weights
-        return gemm_x3_conv3x3((const float*)x, w, (const float*)bias, (float*)out, B, H, W, Cin, Cout, 0, relu, 0, s, 1, 0, 0);
+    if (is_x3(dtype)) {                  // fp32 maps, w = master_split_weights of the packed weights
+        // taps outside the image read a 512-float zero row at channel offsets up to Cin - 32 (gemm_x3.hip: g_zero_row_x3)
+        REQUIRE(Cin <= 512, "conv3x3_zero(x3): Cin <= 512 (got %d)", Cin);
+        return gemm_x3_conv3x3((const float*)x, w, (const float*)bias, (float*)out, B, H, W, Cin, Cout, 0, relu, 0, s, 1, 0, 0, x3_fmt(dtype));
+    }
     master_set_error("conv3x3_zero: bad dtype %d", dtype);
     return MASTER_ERR_INVALID;
 }
@@ -758,10 +775,10 @@ int master_decoder_tail_fwd(const void* x, const void* w8, const float* b8, cons
                             int B, int Hs, int Ws, int dtype, master_stream_t stream) {
     REQUIRE(x && w8 && b8 && w9 && b9 && out, "decoder_tail: null operand");
     REQUIRE(B > 0 && Hs > 0 && Ws > 0 && al16(x) && al16(w8) && al16(w9), "decoder_tail: bad dims/alignment");
-    if ((dtype & ~MASTER_A_SPLIT) == MASTER_F32X3) {           // split-bf16 fast parity mode: x fp32 NHWC, or (MASTER_A_SPLIT) in the split layout
+    if (is_x3(dtype & ~MASTER_A_SPLIT)) {           // split-bf16 fast parity mode: x fp32 NHWC, or (MASTER_A_SPLIT) in the split layout
         hipStream_t s3 = (hipStream_t)stream;
         ProfScope ps3(MASTER_K_DECODER_TAIL, s3);
-        return conv_tail_x3(x, (dtype & MASTER_A_SPLIT) != 0, w8, b8, w9, b9, out, B, Hs, Ws, s3);
+        return conv_tail_x3(x, (dtype & MASTER_A_SPLIT) != 0, w8, b8, w9, b9, out, B, Hs, Ws, s3, x3_fmt(dtype & ~MASTER_A_SPLIT));
     }
     if (dtype != MASTER_BF16) { master_set_error("decoder_tail: fused kernel is bf16-only; use master_conv3x3_reflect_fwd in fp32 mode"); return MASTER_ERR_UNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
@@ -783,11 +800,11 @@ int master_window_attn_fwd(const void* q, const void* k, const void* v0, const v
     REQUIRE(al16(q) && al16(k) && al16(v0) && al16(out0) && al16(k_pad) && al16(bias), "window_attn: operands must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_ATTN, s);
-    if (dtype == MASTER_F32 || dtype == MASTER_F32X3)       // F32X3: fp32 tensors, both products as three bf16 MFMAs on split operands
+    if (dtype == MASTER_F32 || is_x3(dtype))                // F32X3 / F16X3: fp32 tensors, both products as three 16-bit MFMAs on split operands
         return window_attn_f32((const float*)q, (const float*)k, (const float*)v0, (const float*)v1, ldq, ldk, ldv,
                                (const float*)k_pad, (const float*)v0_pad, (const float*)v1_pad, k_pad_bstride,
                                v_pad_bstride, bias, src, region, (float*)out0, (float*)out1, ldo, B, T, heads, nW, N,
-                               scale, s, dtype == MASTER_F32X3);
+                               scale, s, dtype == MASTER_F16X3 ? 2 : dtype == MASTER_F32X3);
     if (dtype == MASTER_BF16) {
         // persistent window-per-workgroup kernel for 8-head maps (StyleTransformer, Swin stage 2); one-problem-per-wave otherwise
         const int rc = window_attn_pw_bf16((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v0, (const bf16_t*)v1, ldq, ldk, ldv,

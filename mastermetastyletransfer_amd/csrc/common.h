@@ -25,6 +25,40 @@ __device__ __forceinline__ void split_bf16x2(float x0, float x1, unsigned& hi, u
     hi = a;
     lo = pack_bf16x2(x0 - __uint_as_float(a << 16), x1 - __uint_as_float(a & 0xffff0000u));
 }
+// The same split with IEEE-half halves (MASTER_F16X3, r05): hi = half(x), lo = half(x - hi), round to nearest even (v_cvt_pk_f16_f32).  11
+// significant bits per half instead of 8: hi + lo reproduces x to 2^-22 |x| (bf16 halves: 2^-17) down to the subnormal floor 2^-25 - the
+// matrix core takes subnormal half operands at full precision (profiles/r05_f16_split_probe_mi355x.txt).  What it gives up is bf16's
+// exponent range: |x| > 65 504 becomes inf (as under fp16 autocast), so the frozen loss network and its gradients stay on bf16 halves.
+typedef _Float16 f16x2_hw __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
+    f16x2_hw v; v[0] = (_Float16)lo; v[1] = (_Float16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void split_f16x2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    unsigned a = pack_f16x2(x0, x1);
+    asm("" : "+v"(a));
+    hi = a;
+    const f16x2_hw v = __builtin_bit_cast(f16x2_hw, a);
+    lo = pack_f16x2(x0 - (float)v[0], x1 - (float)v[1]);
+}
+// operand format of the split kernels: X3_BF16 (MASTER_F32X3) or X3_F16 (MASTER_F16X3); fragments travel as four 32-bit words either way
+constexpr int X3_BF16 = 0, X3_F16 = 1;
+typedef unsigned int x3_frag __attribute__((ext_vector_type(4)));
+template <int FMT> __device__ __forceinline__ void split_x2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    if constexpr (FMT == X3_F16) split_f16x2(x0, x1, hi, lo); else split_bf16x2(x0, x1, hi, lo);
+}
+template <int FMT> __device__ __forceinline__ f32x16 mfma_x3_32(const x3_frag& a, const x3_frag& b, const f32x16& c) {
+    typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    if constexpr (FMT == X3_F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
+}
+template <int FMT> __device__ __forceinline__ f32x4 mfma_x3_16(const x3_frag& a, const x3_frag& b, const f32x4& c) {
+    typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    if constexpr (FMT == X3_F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
+}
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.0f) & 0xffffu); }
 

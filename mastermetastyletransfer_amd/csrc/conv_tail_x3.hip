@@ -19,7 +19,6 @@
 
 namespace {
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -35,11 +34,12 @@ constexpr int RP = RH * RW;
 constexpr int PIX = 144;                        // bytes per pixel record in LDS: 64 B hi | 64 B lo | 16 B pad
 constexpr int S_BYTES = SH * SW * PIX, Y_BYTES = RP * PIX;
 
-union Frag { u32x4 u; bf16x8_t b; };
+struct Frag { u32x4 u; };        // 8 sixteen-bit halves: bf16 or IEEE half, by FMT
 
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 __device__ __forceinline__ int clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }
 
+template <int FMT>
 __global__ __launch_bounds__(256, 2) void conv_tail_x3_kernel(TailX3Args p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[S_BYTES + Y_BYTES];
     unsigned char* S = smem;
@@ -71,8 +71,8 @@ __global__ __launch_bounds__(256, 2) void conv_tail_x3_kernel(TailX3Args p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 unsigned ah, al, ch, cl;
-                split_bf16x2(v0[2 * j], v0[2 * j + 1], ah, al);
-                split_bf16x2(v1[2 * j], v1[2 * j + 1], ch, cl);
+                split_x2<FMT>(v0[2 * j], v0[2 * j + 1], ah, al);
+                split_x2<FMT>(v1[2 * j], v1[2 * j + 1], ch, cl);
                 hi[j] = ah; lo[j] = al; hi[2 + j] = ch; lo[2 + j] = cl;
             }
             *(u32x4*)(S + pix * PIX + part * 16) = hi;
@@ -116,9 +116,9 @@ __global__ __launch_bounds__(256, 2) void conv_tail_x3_kernel(TailX3Args p) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     Frag xh, xl; xh.u = *(const u32x4*)(px + 32 * s2); xl.u = *(const u32x4*)(px + 64 + 32 * s2);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w8h[2 * t + s2].b, xl.b, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w8l[2 * t + s2].b, xh.b, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w8h[2 * t + s2].b, xh.b, acc, 0, 0, 0);
+                    acc = mfma_x3_32<FMT>(w8h[2 * t + s2].u, xl.u, acc);
+                    acc = mfma_x3_32<FMT>(w8l[2 * t + s2].u, xh.u, acc);
+                    acc = mfma_x3_32<FMT>(w8h[2 * t + s2].u, xh.u, acc);
                 }
             }
             if (pr < RP) {
@@ -129,8 +129,8 @@ __global__ __launch_bounds__(256, 2) void conv_tail_x3_kernel(TailX3Args p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[4 * g + e] + b8v[4 * g + e], 0.f);
                     unsigned h0, h1, l0, l1;
-                    split_bf16x2(v[0], v[1], h0, l0);
-                    split_bf16x2(v[2], v[3], h1, l1);
+                    split_x2<FMT>(v[0], v[1], h0, l0);
+                    split_x2<FMT>(v[2], v[3], h1, l1);
                     *(u32x2*)(Y + pr * PIX + (8 * g + 4 * h) * 2) = u32x2{h0, h1};
                     *(u32x2*)(Y + pr * PIX + 64 + (8 * g + 4 * h) * 2) = u32x2{l0, l1};
                 }
@@ -161,9 +161,9 @@ __global__ __launch_bounds__(256, 2) void conv_tail_x3_kernel(TailX3Args p) {
             for (int t = 0; t < 9; ++t) {
                 const unsigned char* pt = py + ((t / 3) * RW + (t % 3)) * PIX;
                 Frag yh, yl; yh.u = *(const u32x4*)pt; yl.u = *(const u32x4*)(pt + 64);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w9h[t].b, yl.b, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w9l[t].b, yh.b, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w9h[t].b, yh.b, acc, 0, 0, 0);
+                acc = mfma_x3_16<FMT>(w9h[t].u, yl.u, acc);
+                acc = mfma_x3_16<FMT>(w9l[t].u, yh.u, acc);
+                acc = mfma_x3_16<FMT>(w9h[t].u, yh.u, acc);
             }
             if (kg == 0) {                                   // rows 0..3 of the 16x16 result live in lanes 0..15
                 float* op = p.out + (size_t)b * 3 * plane + (size_t)(y0 + oy) * W + x0 + ox;
@@ -176,13 +176,14 @@ __global__ __launch_bounds__(256, 2) void conv_tail_x3_kernel(TailX3Args p) {
 }  // namespace
 
 int conv_tail_x3(const void* x, int x_split, const void* w8, const float* b8, const void* w9, const float* b9, float* out, int B, int Hs, int Ws,
-                 hipStream_t s) {
+                 hipStream_t s, int fmt) {
     if ((2 * Hs) % TH != 0 || (2 * Ws) % TW != 0) {
         master_set_error("decoder_tail(x3): output %dx%d is not a multiple of the %dx%d tile", 2 * Hs, 2 * Ws, TH, TW);
         return MASTER_ERR_UNSUPPORTED;
     }
     TailX3Args p{(const unsigned char*)x, (const unsigned char*)w8, b8, (const unsigned char*)w9, b9, out, B, Hs, Ws, x_split};
     const int grid = B * (2 * Hs / TH) * (2 * Ws / TW);
-    hipLaunchKernelGGL(conv_tail_x3_kernel, dim3(grid), dim3(256), 0, s, p);
+    if (fmt == X3_F16) hipLaunchKernelGGL(conv_tail_x3_kernel<X3_F16>, dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(conv_tail_x3_kernel<X3_BF16>, dim3(grid), dim3(256), 0, s, p);
     return master_check_launch("conv_tail_x3");
 }

@@ -29,7 +29,6 @@ namespace {
 
 constexpr int BK = 32;
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct X3Args {
@@ -47,12 +46,13 @@ template <int V> struct template_int { static constexpr int value = V; };
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 // 8 fp32 -> 8 bf16 hi + 8 bf16 lo (round-to-nearest-even both times; x - hi is exact in fp32)
+template <int FMT>
 __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, u32x4& hi, u32x4& lo) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         unsigned ph, pl, qh, ql;
-        split_bf16x2(x0[2 * j], x0[2 * j + 1], ph, pl);
-        split_bf16x2(x1[2 * j], x1[2 * j + 1], qh, ql);
+        split_x2<FMT>(x0[2 * j], x0[2 * j + 1], ph, pl);
+        split_x2<FMT>(x1[2 * j], x1[2 * j + 1], qh, ql);
         hi[j] = ph; lo[j] = pl; hi[2 + j] = qh; lo[2 + j] = ql;
     }
 }
@@ -68,7 +68,7 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, u32x4& 
 // ---- epilogue shared by the two kernels: the row form of gemm_f32.hip (accumulators through the idle ring as the [BM][BN] fp32 tile, whole
 // 16-byte row pieces out: coalesced bias / r1 / r2 loads, float4 stores), or - out_split - the same pieces split into bf16 hi | lo and
 // stored in the split layout (8 + 8 bytes per piece); element-wise fallback for outputs the row form cannot address (NCHW, N % 4).
-template <int BM, int BN, int WM, int WN, bool CONV, int RING_BYTES>
+template <int BM, int BN, int WM, int WN, bool CONV, int RING_BYTES, int FMT>
 __device__ __forceinline__ void x3_epilogue(const X3Args& p, f32x16 (&acc)[WM / 32][WN / 32], unsigned char* ring, int m0, int n0, int wm, int wn) {
     constexpr int NWN = BN / WN;
     constexpr int NWAVES = (BM / WM) * NWN;
@@ -141,8 +141,8 @@ __device__ __forceinline__ void x3_epilogue(const X3Args& p, f32x16 (&acc)[WM / 
                 if (p.out_split) {
                     if (ok[it]) {
                         unsigned h0, h1, l0, l1;
-                        split_bf16x2(x[0], x[1], h0, l0);
-                        split_bf16x2(x[2], x[3], h1, l1);
+                        split_x2<FMT>(x[0], x[1], h0, l0);
+                        split_x2<FMT>(x[2], x[3], h1, l1);
                         // row of N values = N / 32 chunks of 128 B; value n of the row: hi at (n >> 5) * 128 + (n & 31) * 2, lo 64 B further
                         unsigned char* dst = (unsigned char*)(p.out + orow[it] * p.ldo) + (n >> 5) * 128 + (n & 31) * 2;
                         typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
@@ -188,7 +188,7 @@ __device__ __forceinline__ void x3_epilogue(const X3Args& p, f32x16 (&acc)[WM / 
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV>
+template <int BM, int BN, int WM, int WN, bool CONV, int FMT>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3_kernel(X3Args p) {
     constexpr int NWN = BN / WN;
     constexpr int NWAVES = (BM / WM) * NWN;
@@ -283,7 +283,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3_kernel(X3A
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
             u32x4 hi, lo;
-            split8(ra[i][0], ra[i][1], hi, lo);
+            split8<FMT>(ra[i][0], ra[i][1], hi, lo);
             *(u32x4*)(slot + a_dst[i]) = hi;
             *(u32x4*)(slot + (a_dst[i] ^ 64)) = lo;
         }
@@ -323,24 +323,24 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3_kernel(X3A
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int ohi = ((2 * s + h) ^ fsw) << 4, olo = ohi ^ 64;
-            bf16x8_t ah[TM], al[TM], wh[TN], wl[TN];
+            x3_frag ah[TM], al[TM], wh[TN], wl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                ah[i] = *(const bf16x8_t*)(ab + i * 32 * 128 + ohi);
-                al[i] = *(const bf16x8_t*)(ab + i * 32 * 128 + olo);
+                ah[i] = *(const x3_frag*)(ab + i * 32 * 128 + ohi);
+                al[i] = *(const x3_frag*)(ab + i * 32 * 128 + olo);
             }
 #pragma unroll
             for (int jn = 0; jn < TN; ++jn) {
-                wh[jn] = *(const bf16x8_t*)(wb + jn * 32 * 128 + ohi);
-                wl[jn] = *(const bf16x8_t*)(wb + jn * 32 * 128 + olo);
+                wh[jn] = *(const x3_frag*)(wb + jn * 32 * 128 + ohi);
+                wl[jn] = *(const x3_frag*)(wb + jn * 32 * 128 + olo);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn) {
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], wh[jn], acc[i][jn], 0, 0, 0);
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wl[jn], acc[i][jn], 0, 0, 0);
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wh[jn], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = mfma_x3_32<FMT>(al[i], wh[jn], acc[i][jn]);
+                    acc[i][jn] = mfma_x3_32<FMT>(ah[i], wl[jn], acc[i][jn]);
+                    acc[i][jn] = mfma_x3_32<FMT>(ah[i], wh[jn], acc[i][jn]);
                 }
         }
     };
@@ -350,8 +350,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3_kernel(X3A
     // hipcc copy the still-loading registers in front of the wait)
     auto wait_regs = [&](f32x4 (&ra)[APASS][2]) __attribute__((always_inline)) {
         constexpr int WCNT = PER + WPW;
-        if constexpr (APASS == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ra[0][0]), "+v"(ra[0][1]) : "n"(WCNT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]) : "n"(WCNT) : "memory");
+        // the registers are printed behind the instruction ("; landed v[..] .."): profiles/tools/isa_audit.py reads them from the generated
+        // code and checks that no compiler copy / spill touches a register between the asm load that targets it and this wait
+        if constexpr (APASS == 1) asm volatile("s_waitcnt vmcnt(%2) ; landed %0 %1" : "+v"(ra[0][0]), "+v"(ra[0][1]) : "n"(WCNT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%4) ; landed %0 %1 %2 %3" : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]) : "n"(WCNT) : "memory");
     };
     static_assert(APASS == 1 || APASS == 2, "wait_regs covers one or two A passes");
 
@@ -387,7 +389,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3_kernel(X3A
     };
     for (int kt = 0; kt < nk; kt += 2) {
         body(kt, ra1, ra0);
-        if (kt + 1 < nk) body(kt + 1, ra0, ra1);
+        if (kt + 1 >= nk) break;          // (a break, not a guarded second half: the flow graph then has no path from a skipped half back to the loop head, which the ISA audit would have to assume)
+        body(kt + 1, ra0, ra1);
     }
     // the two look-ahead groups past the end and this wave's last (look-ahead) A stores must have landed before the barrier below lets
     // other waves write the output tile over the ring (a store still in flight would land on top of it)
@@ -400,7 +403,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3_kernel(X3A
     }
 #endif
 
-    x3_epilogue<BM, BN, WM, WN, CONV, NSTAGE * STAGE>(p, acc, ring, m0, n0, wm, wn);
+    x3_epilogue<BM, BN, WM, WN, CONV, NSTAGE * STAGE, FMT>(p, acc, ring, m0, n0, wm, wn);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -412,7 +415,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3_kernel(X3A
 // Ring, k order, waits and epilogue as above; per chunk a wave issues BM / 8 / NWAVES pieces of A (8 rows x 128 B, per-lane row
 // pointers: the convolution gather moves them when the tap changes) and BN / 8 / NWAVES of W.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool CONV>
+template <int BM, int BN, int WM, int WN, bool CONV, int FMT>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3s_kernel(X3Args p) {
     constexpr int NWN = BN / WN;
     constexpr int NWAVES = (BM / WM) * NWN;
@@ -552,24 +555,24 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3s_kernel(X3
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int ohi = ((2 * s + h) ^ fsw) << 4, olo = ohi ^ 64;
-            bf16x8_t ah[TM], al[TM], wh[TN], wl[TN];
+            x3_frag ah[TM], al[TM], wh[TN], wl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                ah[i] = *(const bf16x8_t*)(ab + i * 32 * 128 + ohi);
-                al[i] = *(const bf16x8_t*)(ab + i * 32 * 128 + olo);
+                ah[i] = *(const x3_frag*)(ab + i * 32 * 128 + ohi);
+                al[i] = *(const x3_frag*)(ab + i * 32 * 128 + olo);
             }
 #pragma unroll
             for (int jn = 0; jn < TN; ++jn) {
-                wh[jn] = *(const bf16x8_t*)(wb + jn * 32 * 128 + ohi);
-                wl[jn] = *(const bf16x8_t*)(wb + jn * 32 * 128 + olo);
+                wh[jn] = *(const x3_frag*)(wb + jn * 32 * 128 + ohi);
+                wl[jn] = *(const x3_frag*)(wb + jn * 32 * 128 + olo);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn) {
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], wh[jn], acc[i][jn], 0, 0, 0);
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wl[jn], acc[i][jn], 0, 0, 0);
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wh[jn], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = mfma_x3_32<FMT>(al[i], wh[jn], acc[i][jn]);
+                    acc[i][jn] = mfma_x3_32<FMT>(ah[i], wl[jn], acc[i][jn]);
+                    acc[i][jn] = mfma_x3_32<FMT>(ah[i], wh[jn], acc[i][jn]);
                     // pieces due after this group: piece q goes behind group floor(q * NG / PER)
                     ++g;
 #pragma unroll
@@ -590,30 +593,30 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3s_kernel(X3
         dst[6] = __builtin_amdgcn_s_memtime() - probe_t0;
     }
 #endif
-    x3_epilogue<BM, BN, WM, WN, CONV, NSTAGE * STAGE>(p, acc, ring, m0, n0, wm, wn);
+    x3_epilogue<BM, BN, WM, WN, CONV, NSTAGE * STAGE, FMT>(p, acc, ring, m0, n0, wm, wn);
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV>
+template <int BM, int BN, int WM, int WN, bool CONV, int FMT>
 int launch_s(const X3Args& p, hipStream_t s) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     const int MT = (p.M + BM - 1) / BM, NTN = (p.N + BN - 1) / BN;
     const int grid = ((MT + 7) / 8) * 8 * NTN;
     const size_t lds = (size_t)3 * (BM + BN) * 128;
     static LdsLimit lds_limit;
-    lds_limit.ensure((const void*)gemm_x3s_kernel<BM, BN, WM, WN, CONV>, (int)lds);
-    hipLaunchKernelGGL((gemm_x3s_kernel<BM, BN, WM, WN, CONV>), dim3(grid), dim3(NT), lds, s, p);
+    lds_limit.ensure((const void*)gemm_x3s_kernel<BM, BN, WM, WN, CONV, FMT>, (int)lds);
+    hipLaunchKernelGGL((gemm_x3s_kernel<BM, BN, WM, WN, CONV, FMT>), dim3(grid), dim3(NT), lds, s, p);
     return master_check_launch("gemm_x3s");
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV>
+template <int BM, int BN, int WM, int WN, bool CONV, int FMT>
 int launch(const X3Args& p, hipStream_t s) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     const int MT = (p.M + BM - 1) / BM, NTN = (p.N + BN - 1) / BN;
     const int grid = ((MT + 7) / 8) * 8 * NTN;
     const size_t lds = (size_t)3 * (BM + BN) * 128;
     static LdsLimit lds_limit;
-    lds_limit.ensure((const void*)gemm_x3_kernel<BM, BN, WM, WN, CONV>, (int)lds);
-    hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, WM, WN, CONV>), dim3(grid), dim3(NT), lds, s, p);
+    lds_limit.ensure((const void*)gemm_x3_kernel<BM, BN, WM, WN, CONV, FMT>, (int)lds);
+    hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, WM, WN, CONV, FMT>), dim3(grid), dim3(NT), lds, s, p);
     return master_check_launch("gemm_x3");
 }
 
@@ -624,42 +627,43 @@ static int x3_tile() {
     return v;
 }
 
-template <bool CONV>
+template <bool CONV, int FMT>
 int dispatch(const X3Args& p, hipStream_t s) {
     const int force = x3_tile();
     if (p.N > 64) {
-        if (force == 1) return launch<128, 128, 64, 64, CONV>(p, s);
-        if (force == 2) return launch<128, 128, 32, 64, CONV>(p, s);
-        if (force == 3) return launch<256, 128, 64, 64, CONV>(p, s);
-        if (force == 5) return launch<128, 64, 64, 32, CONV>(p, s);        // 72 KB of LDS, four waves: two workgroups per CU
-        if (force == 6) return launch<128, 64, 32, 32, CONV>(p, s);        // eight waves
+        if (force == 1) return launch<128, 128, 64, 64, CONV, FMT>(p, s);
+        if (force == 2) return launch<128, 128, 32, 64, CONV, FMT>(p, s);
+        if (force == 3) return launch<256, 128, 64, 64, CONV, FMT>(p, s);
+        if (force == 5) return launch<128, 64, 64, 32, CONV, FMT>(p, s);        // 72 KB of LDS, four waves: two workgroups per CU
+        if (force == 6) return launch<128, 64, 32, 32, CONV, FMT>(p, s);        // eight waves
         // one N tile of 128 with a short K (the stage-1 projection, 262 144 x 128 x 128 + residual): 128 x 64 tiles, eight waves, two
         // workgroups per CU - one tile's epilogue runs under the other's loop (117.6 -> 100.3 us; with more N tiles the re-split of A
         // per N tile costs more than the overlap gives: profiles/r04 A/B of MASTER_X3_TILE=5/6)
-        if (!CONV && force == 0 && p.N <= 128 && p.K <= 128 && p.M >= 65536) return launch<128, 64, 32, 32, CONV>(p, s);
+        if (!CONV && force == 0 && p.N <= 128 && p.K <= 128 && p.M >= 65536) return launch<128, 64, 32, 32, CONV, FMT>(p, s);
         // fewer than two 256-row tiles per CU: 128-row tiles (eight waves: two per SIMD) fill the chip better
         const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 127) / 128);
-        if (t256 < 512) return launch<128, 128, 32, 64, CONV>(p, s);
-        return launch<256, 128, 64, 64, CONV>(p, s);
+        if (t256 < 512) return launch<128, 128, 32, 64, CONV, FMT>(p, s);
+        return launch<256, 128, 64, 64, CONV, FMT>(p, s);
     }
-    if (p.N > 32 || force == 4) return launch<256, 64, 64, 32, CONV>(p, s);
-    return launch<128, 32, 32, 32, CONV>(p, s);
+    if (p.N > 32 || force == 4) return launch<256, 64, 64, 32, CONV, FMT>(p, s);
+    return launch<128, 32, 32, 32, CONV, FMT>(p, s);
 }
 
-template <bool CONV>
+template <bool CONV, int FMT>
 int dispatch_s(const X3Args& p, hipStream_t s) {
     if (p.N > 64) {
         const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 127) / 128);
-        if (t256 < 512) return launch_s<128, 128, 32, 64, CONV>(p, s);
-        return launch_s<256, 128, 64, 64, CONV>(p, s);
+        if (t256 < 512) return launch_s<128, 128, 32, 64, CONV, FMT>(p, s);
+        return launch_s<256, 128, 64, 64, CONV, FMT>(p, s);
     }
-    if (p.N > 32) return launch_s<256, 64, 64, 32, CONV>(p, s);
-    return launch_s<128, 32, 32, 32, CONV>(p, s);
+    if (p.N > 32) return launch_s<256, 64, 64, 32, CONV, FMT>(p, s);
+    return launch_s<128, 32, 32, 32, CONV, FMT>(p, s);
 }
 
 // ---- weight split: fp32 [rows, K] -> per row and 32-wide chunk: 32 bf16 hi, 32 bf16 lo (same byte size and row stride as the fp32 matrix) ----
 // layout 1 (the second Linear of the fused MLP, mlp_x3.hip): inside every group of 16 k the order is 0-3, 8-11, 4-7, 12-15 - the k order
 // of a packed 32x32 accumulator tile used as an MFMA operand (lane half h holds rows 4h + 0..3 and 8 + 4h + 0..3 of each group).
+template <int FMT>
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, unsigned* __restrict__ out, size_t n8, int layout) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;            // one 8-element unit of the OUTPUT per thread
     if (i >= n8) return;
@@ -667,38 +671,43 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
     const float* src = layout == 1 ? w + chunk * 32 + (u >> 1) * 16 + (u & 1) * 4 : w + i * 8;
     const f32x4 x0 = *(const f32x4*)src, x1 = *(const f32x4*)(src + (layout == 1 ? 8 : 4));
     u32x4 hi, lo;
-    split8(x0, x1, hi, lo);
+    split8<FMT>(x0, x1, hi, lo);
     *(u32x4*)(out + chunk * 32 + u * 4) = hi;
     *(u32x4*)(out + chunk * 32 + 16 + u * 4) = lo;
 }
 
 }  // namespace
 
-int gemm_x3_split_weights(const float* w, void* out, size_t rows, size_t K, int layout, hipStream_t s) {
+// fmt: X3_BF16 (MASTER_F32X3) or X3_F16 (MASTER_F16X3) halves, for the weights, the A split in registers and the out_split epilogue alike
+int gemm_x3_split_weights(const float* w, void* out, size_t rows, size_t K, int layout, hipStream_t s, int fmt) {
     const size_t n8 = rows * K / 8;
-    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, w, (unsigned*)out, n8, layout);
+    if (fmt == X3_F16) hipLaunchKernelGGL(split_weights_kernel<X3_F16>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, w, (unsigned*)out, n8, layout);
+    else hipLaunchKernelGGL(split_weights_kernel<X3_BF16>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, w, (unsigned*)out, n8, layout);
     return master_check_launch("split_weights");
 }
 
 int gemm_x3_linear(const float* a, const void* w, const float* bias, const float* r1, const float* r2, float* out,
-                   int M, int N, int K, int lda, int ldo, int ldr, int act, hipStream_t s, int a_split, int out_split) {
+                   int M, int N, int K, int lda, int ldo, int ldr, int act, hipStream_t s, int a_split, int out_split, int fmt) {
     X3Args p{a, (const float*)w, bias, r1, r2, out, M, N, K, lda, ldo, ldr, act, 0, 0, 0, 1, 1, 0, 0, 0, 0, out_split};
-    return a_split ? dispatch_s<false>(p, s) : dispatch<false>(p, s);
+    if (fmt == X3_F16) return a_split ? dispatch_s<false, X3_F16>(p, s) : dispatch<false, X3_F16>(p, s);
+    return a_split ? dispatch_s<false, X3_BF16>(p, s) : dispatch<false, X3_BF16>(p, s);
 }
 
 int gemm_x3_conv3x3(const float* x, const void* w, const float* bias, float* out, int B, int Hin, int Win, int Cin,
-                    int Cout, int up, int relu, int out_nchw, hipStream_t s, int zero_pad, int a_split, int out_split) {
+                    int Cout, int up, int relu, int out_nchw, hipStream_t s, int zero_pad, int a_split, int out_split, int fmt) {
     const int Hout = Hin << up, Wout = Win << up;
     X3Args p{x, (const float*)w, bias, nullptr, nullptr, out, B * Hout * Wout, Cout, 9 * Cin, 0, Cout, 0,
              relu ? MASTER_ACT_RELU : MASTER_ACT_NONE, Hin, Win, Cin, Hout, Wout, up, out_nchw, zero_pad, 0, out_split};
-    return a_split ? dispatch_s<true>(p, s) : dispatch<true>(p, s);
+    if (fmt == X3_F16) return a_split ? dispatch_s<true, X3_F16>(p, s) : dispatch<true, X3_F16>(p, s);
+    return a_split ? dispatch_s<true, X3_BF16>(p, s) : dispatch<true, X3_BF16>(p, s);
 }
 
 // data gradient of a zero-padded 3x3 convolution (the frozen loss network's chain, gemm_f32.hip's gemm_f32_conv3x3_dgrad in split-bf16):
-// g [B,H,W,Cg] fp32, wf = split [Cx][3][3][Cg] flipped weights; out = relu_src > 0 ? conv(g, wf) + add : 0  (relu_src / add optional)
+// g [B,H,W,Cg] fp32, wf = split [Cx][3][3][Cg] flipped weights; out = relu_src > 0 ? conv(g, wf) + add : 0  (relu_src / add optional).
+// bf16 halves only: gradients span fp32's exponent range (1e-9 ... 1), which half halves cannot represent.
 int gemm_x3_conv3x3_dgrad(const float* g, const void* wf, float* out, const float* relu_src, const float* add, int B, int H, int W,
                           int Cg, int Cx, hipStream_t s) {
     X3Args p{g, (const float*)wf, nullptr, relu_src, add, out, B * H * W, Cx, 9 * Cg, 0, Cx, Cx, MASTER_ACT_NONE, H, W, Cg, H, W, 0, 0, 1,
              relu_src != nullptr, 0};
-    return dispatch<true>(p, s);
+    return dispatch<true, X3_BF16>(p, s);
 }

@@ -22,9 +22,8 @@
 
 namespace {
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-union Frag { u32x4 u; bf16x8_t b; };
+struct Frag { u32x4 u; };        // one MFMA operand fragment: 8 sixteen-bit halves (bf16 or IEEE half, by FMT)
 
 struct MlpX3Args {
     const float* x; const float* ln_g; const float* ln_b;
@@ -46,7 +45,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // one's GELU burst, prologue (row loads, LayerNorm, split) and epilogue (transpose, residual, stores) run under the other's MFMAs,
 // which eight waves of ONE workgroup in lockstep at every step barrier could not do (probe: 28.7 k of 126 k clocks in the GELU with the
 // matrix cores idle, 27 k in prologue + epilogue).
-template <int C, int NW, bool PIPE, int RING, int WGPC>
+template <int C, int NW, bool PIPE, int RING, int WGPC, int FMT>
 __global__ __launch_bounds__(NW * 64, WGPC) void mlp_x3_kernel(MlpX3Args p) {
     constexpr int AHEAD = RING - 1;             // steps of DMA in flight ahead of the one being consumed
     constexpr int KS1 = C / 16;                 // k-steps of phase 1
@@ -184,8 +183,8 @@ __global__ __launch_bounds__(NW * 64, WGPC) void mlp_x3_kernel(MlpX3Args p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 unsigned ah, al, bh, bl;
-                split_bf16x2(xv[s][0][2 * j], xv[s][0][2 * j + 1], ah, al);
-                split_bf16x2(xv[s][1][2 * j], xv[s][1][2 * j + 1], bh, bl);
+                split_x2<FMT>(xv[s][0][2 * j], xv[s][0][2 * j + 1], ah, al);
+                split_x2<FMT>(xv[s][1][2 * j], xv[s][1][2 * j + 1], bh, bl);
                 xh[s].u[j] = ah; xl[s].u[j] = al; xh[s].u[2 + j] = bh; xl[s].u[2 + j] = bl;
             }
         }
@@ -225,7 +224,11 @@ __global__ __launch_bounds__(NW * 64, WGPC) void mlp_x3_kernel(MlpX3Args p) {
     // are inline asm (the compiler neither waits for nor moves them): the 4 fragments of group g + 1 are requested, a counted lgkmcnt
     // retires exactly the 4 of group g (LDS returns in order), a sched_barrier keeps the 6 MFMAs of the group below it.
 #define LDS_READ128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
-#define LGKM_WAIT(n) do { asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(n) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+// the wait names the four fragment registers it retires as in/out operands: nothing that reads them can be placed above it, and the
+// operand list is printed behind the instruction so that the build-time ISA audit (profiles/tools/isa_audit.py) can check that no compiler
+// copy / spill touches a register between the asm read that targets it and this wait
+#define LGKM_LANDED(n, B) do { asm volatile("s_waitcnt lgkmcnt(%4) ; landed %0 %1 %2 %3" : "+v"((B)[0]), "+v"((B)[1]), "+v"((B)[2]), "+v"((B)[3]) : "n"(n) : "memory"); \
+                               __builtin_amdgcn_sched_barrier(0); } while (0)
 #define SB() __builtin_amdgcn_sched_barrier(0)
 
     // GELU (exact erf) + split of the previous block, one hidden value at a time between the MFMA groups of the next block's phase 1:
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(NW * 64, WGPC) void mlp_x3_kernel(MlpX3Args p) {
         gfine[z] = gelu_erf(PIPE ? hprev[jt][8 * sg + 2 * i + z] : hacc[jt][8 * sg + 2 * i + z]);
         if (z == 1) {
             unsigned a, l;
-            split_bf16x2(gfine[0], gfine[1], a, l);
+            split_x2<FMT>(gfine[0], gfine[1], a, l);
             hfh[jt][sg].u[i] = a;
             hfl[jt][sg].u[i] = l;
             asm volatile("" :: "v"(hfl[jt][sg].u[i]));          // pin: LLVM otherwise sinks the arithmetic below the MFMAs
@@ -268,9 +271,9 @@ __global__ __launch_bounds__(NW * 64, WGPC) void mlp_x3_kernel(MlpX3Args p) {
                 }
 #pragma unroll
                 for (int jt = 0; jt < 2; ++jt) {
-                    hacc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[jt].b, xl[s].b, hacc[jt], 0, 0, 0);
-                    hacc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[jt].b, xh[s].b, hacc[jt], 0, 0, 0);
-                    hacc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[jt].b, xh[s].b, hacc[jt], 0, 0, 0);
+                    hacc[jt] = mfma_x3_32<FMT>(wh[jt].u, xl[s].u, hacc[jt]);
+                    hacc[jt] = mfma_x3_32<FMT>(wl[jt].u, xh[s].u, hacc[jt]);
+                    hacc[jt] = mfma_x3_32<FMT>(wh[jt].u, xh[s].u, hacc[jt]);
                     if (jt == 0) early_pieces(it);
                 }
             }
@@ -289,14 +292,14 @@ __global__ __launch_bounds__(NW * 64, WGPC) void mlp_x3_kernel(MlpX3Args p) {
         rd(0, 0);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            if (it + 1 < 8) { rd((it + 1) & 1, it + 1); LGKM_WAIT(4); } else { LGKM_WAIT(0); }
+            if (it + 1 < 8) { rd((it + 1) & 1, it + 1); LGKM_LANDED(4, a[it & 1]); } else { LGKM_LANDED(0, a[it & 1]); }
             const int s = (i1 * 4 + (it >> 1)) * 2 + (it & 1);             // k-step of x
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
                 Frag wh, wl; wh.u = a[it & 1][2 * jt]; wl.u = a[it & 1][2 * jt + 1];
-                hacc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh.b, xl[s].b, hacc[jt], 0, 0, 0);
-                hacc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl.b, xh[s].b, hacc[jt], 0, 0, 0);
-                hacc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh.b, xh[s].b, hacc[jt], 0, 0, 0);
+                hacc[jt] = mfma_x3_32<FMT>(wh.u, xl[s].u, hacc[jt]);
+                hacc[jt] = mfma_x3_32<FMT>(wl.u, xh[s].u, hacc[jt]);
+                hacc[jt] = mfma_x3_32<FMT>(wh.u, xh[s].u, hacc[jt]);
                 if (jt == 0) { SB(); if (PPW == 8) dma_piece(it); else if ((it & 1) == 0) dma_piece(it >> 1); SB(); }
                 if (pipe) {
                     constexpr int VPG = 32 / (P1 * 16);                    // hidden values per MFMA group: 1 (C = 256) or 2 (C = 128)
@@ -321,9 +324,9 @@ __global__ __launch_bounds__(NW * 64, WGPC) void mlp_x3_kernel(MlpX3Args p) {
                     Frag wh, wl;
                     wh.u = *(const u32x4*)lds_ptr(ad + q * 4096);
                     wl.u = *(const u32x4*)lds_ptr((ad ^ 64u) + q * 4096);
-                    oacc[nt0 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh.b, hfl[jt][sg].b, oacc[nt0 + q], 0, 0, 0);
-                    oacc[nt0 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl.b, hfh[jt][sg].b, oacc[nt0 + q], 0, 0, 0);
-                    oacc[nt0 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh.b, hfh[jt][sg].b, oacc[nt0 + q], 0, 0, 0);
+                    oacc[nt0 + q] = mfma_x3_32<FMT>(wh.u, hfl[jt][sg].u, oacc[nt0 + q]);
+                    oacc[nt0 + q] = mfma_x3_32<FMT>(wl.u, hfh[jt][sg].u, oacc[nt0 + q]);
+                    oacc[nt0 + q] = mfma_x3_32<FMT>(wh.u, hfh[jt][sg].u, oacc[nt0 + q]);
                     if (q == 0) early_pieces(it);
                 }
             }
@@ -347,16 +350,16 @@ __global__ __launch_bounds__(NW * 64, WGPC) void mlp_x3_kernel(MlpX3Args p) {
         rd(0, 0);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            if (it + 1 < 8) { rd((it + 1) & 1, it + 1); LGKM_WAIT(4); } else { LGKM_WAIT(0); }
+            if (it + 1 < 8) { rd((it + 1) & 1, it + 1); LGKM_LANDED(4, a[it & 1]); } else { LGKM_LANDED(0, a[it & 1]); }
             const int sg = C == 256 ? it >> 2 : (it >> 1) & 1;
             const int nt0 = C == 256 ? 2 * (it & 3) : 2 * (it & 1);
             const int jt = C == 256 ? i2 : (it >> 2);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 Frag wh, wl; wh.u = a[it & 1][2 * q]; wl.u = a[it & 1][2 * q + 1];
-                oacc[nt0 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh.b, hfl[jt][sg].b, oacc[nt0 + q], 0, 0, 0);
-                oacc[nt0 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl.b, hfh[jt][sg].b, oacc[nt0 + q], 0, 0, 0);
-                oacc[nt0 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh.b, hfh[jt][sg].b, oacc[nt0 + q], 0, 0, 0);
+                oacc[nt0 + q] = mfma_x3_32<FMT>(wh.u, hfl[jt][sg].u, oacc[nt0 + q]);
+                oacc[nt0 + q] = mfma_x3_32<FMT>(wl.u, hfh[jt][sg].u, oacc[nt0 + q]);
+                oacc[nt0 + q] = mfma_x3_32<FMT>(wh.u, hfh[jt][sg].u, oacc[nt0 + q]);
                 if (q == 0) { SB(); if (PPW == 8) dma_piece(it); else if ((it & 1) == 0) dma_piece(it >> 1); SB(); }
             }
         }
@@ -465,28 +468,29 @@ __global__ __launch_bounds__(NW * 64, WGPC) void mlp_x3_kernel(MlpX3Args p) {
 #endif
 }
 
-template <int C, int NW, bool PIPE, int RING, int WGPC>
+template <int C, int NW, bool PIPE, int RING, int WGPC, int FMT>
 int launch(const MlpX3Args& p, hipStream_t s) {
     static_assert(NW * 32 * C * 4 <= RING * SLOT, "the epilogue's per-wave [32][C] fp32 tiles must fit in the ring");
     const size_t lds = (size_t)RING * SLOT + (size_t)(p.HID + 3 * C) * sizeof(float) + NW * 1024;
     if (lds > 160 * 1024) { master_set_error("mlp(x3): hidden width %d needs %zu B of LDS", p.HID, lds); return MASTER_ERR_UNSUPPORTED; }
     static LdsLimit lds_limit;
-    lds_limit.ensure((const void*)mlp_x3_kernel<C, NW, PIPE, RING, WGPC>, (int)lds);
-    hipLaunchKernelGGL((mlp_x3_kernel<C, NW, PIPE, RING, WGPC>), dim3((p.M + NW * 32 - 1) / (NW * 32)), dim3(NW * 64), lds, s, p);
+    lds_limit.ensure((const void*)mlp_x3_kernel<C, NW, PIPE, RING, WGPC, FMT>, (int)lds);
+    hipLaunchKernelGGL((mlp_x3_kernel<C, NW, PIPE, RING, WGPC, FMT>), dim3((p.M + NW * 32 - 1) / (NW * 32)), dim3(NW * 64), lds, s, p);
     return master_check_launch("mlp_x3");
 }
 
 }  // namespace
 
 int mlp_x3(const float* x, const float* ln_g, const float* ln_b, const void* w1, const float* b1, const void* w2, const float* b2,
-           const float* res, float* out, int M, int C, int HID, int ldx, int ldr, int ldo, float eps, hipStream_t s) {
+           const float* res, float* out, int M, int C, int HID, int ldx, int ldr, int ldo, float eps, hipStream_t s, int fmt) {
     MlpX3Args p{x, ln_g, ln_b, (const unsigned char*)w1, b1, (const unsigned char*)w2, b2, res, out, M, HID, ldx, ldr, ldo, eps};
     if (HID % HB != 0) { master_set_error("mlp(x3): hidden width must be a multiple of 64 (got %d)", HID); return MASTER_ERR_UNSUPPORTED; }
-    if (C == 256) return launch<256, 4, true, 4, 1>(p, s);
+    if (C == 256) return fmt == X3_F16 ? launch<256, 4, true, 4, 1, X3_F16>(p, s) : launch<256, 4, true, 4, 1, X3_BF16>(p, s);
     if (C == 128) {
         static int form = -1;                     // MASTER_MLP_X3_C128 = 8w: the first form (eight waves, 256 tokens, one workgroup per CU) for A/B runs
         if (form < 0) { const char* e = getenv("MASTER_MLP_X3_C128"); form = (e && e[0] == '8') ? 1 : 0; }
-        return form ? launch<128, 8, false, 4, 1>(p, s) : launch<128, 4, false, 2, 2>(p, s);
+        if (fmt == X3_F16) return form ? launch<128, 8, false, 4, 1, X3_F16>(p, s) : launch<128, 4, false, 2, 2, X3_F16>(p, s);
+        return form ? launch<128, 8, false, 4, 1, X3_BF16>(p, s) : launch<128, 4, false, 2, 2, X3_BF16>(p, s);
     }
     master_set_error("mlp(x3): channel width %d not built (128, 256)", C);
     return MASTER_ERR_UNSUPPORTED;

@@ -36,21 +36,21 @@ struct AttnArgs {
 
 constexpr float LOG2E = 1.4426950408889634f;
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-union FragX { u32x4 u; bf16x8_t b; };
+struct FragX { u32x4 u; };       // 8 sixteen-bit halves: bf16 or IEEE half, by FMT
 
 // 8 fp32 -> the bf16 hi and lo fragments (round to nearest even both times)
+template <int FMT>
 __device__ __forceinline__ void split_frag(const float (&x)[8], FragX& hi, FragX& lo) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         unsigned a, l;
-        split_bf16x2(x[2 * j], x[2 * j + 1], a, l);
+        split_x2<FMT>(x[2 * j], x[2 * j + 1], a, l);
         hi.u[j] = a; lo.u[j] = l;
     }
 }
 
-template <bool DUAL, bool X3>
+template <bool DUAL, bool X3, int FMT = X3_BF16>
 __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // uniform: the problem's bases and table pointers become scalar arithmetic
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
                     kx[j] = kv[t][2 * sp + (j >> 2)][j & 3];
                     qx[j] = qv[t][2 * sp + (j >> 2)][j & 3] * p.scale_log2e;
                 }
-                split_frag(kx, kh[t][sp], kl[t][sp]);
-                split_frag(qx, qh[t][sp], ql[t][sp]);
+                split_frag<FMT>(kx, kh[t][sp], kl[t][sp]);
+                split_frag<FMT>(qx, qh[t][sp], ql[t][sp]);
             }
 #pragma unroll
         for (int sp = 0; sp < 2; ++sp)
@@ -176,9 +176,9 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) {
-                    st[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[kt][sp].b, qh[qt][sp].b, st[kt][qt], 0, 0, 0);
-                    st[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[kt][sp].b, ql[qt][sp].b, st[kt][qt], 0, 0, 0);
-                    st[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[kt][sp].b, qh[qt][sp].b, st[kt][qt], 0, 0, 0);
+                    st[kt][qt] = mfma_x3_32<FMT>(kl[kt][sp].u, qh[qt][sp].u, st[kt][qt]);
+                    st[kt][qt] = mfma_x3_32<FMT>(kh[kt][sp].u, ql[qt][sp].u, st[kt][qt]);
+                    st[kt][qt] = mfma_x3_32<FMT>(kh[kt][sp].u, qh[qt][sp].u, st[kt][qt]);
                 }
     } else {
 #pragma unroll
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
                     float px[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) px[j] = st[kt][qt][8 * sp + j];
-                    split_frag(px, ph[kt][qt][sp], pl[kt][qt][sp]);
+                    split_frag<FMT>(px, ph[kt][qt][sp], pl[kt][qt][sp]);
                 }
     }
     auto pv = [&](const float (&vv)[2][16], float* out) {
@@ -251,12 +251,12 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) vx[j] = vv[kt][8 * sp + j];
                     FragX vh, vl;
-                    split_frag(vx, vh, vl);
+                    split_frag<FMT>(vx, vh, vl);
 #pragma unroll
                     for (int qt = 0; qt < 2; ++qt) {
-                        o[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl.b, ph[kt][qt][sp].b, o[qt], 0, 0, 0);
-                        o[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh.b, pl[kt][qt][sp].b, o[qt], 0, 0, 0);
-                        o[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh.b, ph[kt][qt][sp].b, o[qt], 0, 0, 0);
+                        o[qt] = mfma_x3_32<FMT>(vl.u, ph[kt][qt][sp].u, o[qt]);
+                        o[qt] = mfma_x3_32<FMT>(vh.u, pl[kt][qt][sp].u, o[qt]);
+                        o[qt] = mfma_x3_32<FMT>(vh.u, ph[kt][qt][sp].u, o[qt]);
                     }
                 }
         } else {
@@ -297,9 +297,12 @@ int window_attn_f32(const float* q, const float* k, const float* v0, const float
                out0, out1, ldo, B, T, heads, nW, N, scale * LOG2E};
     const int total = B * nW * heads;
     const int grid = (total + 3) / 4;
-    if (x3) {
-        if (v1) hipLaunchKernelGGL((window_attn_f32_kernel<true, true>), dim3(grid), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((window_attn_f32_kernel<false, true>), dim3(grid), dim3(256), 0, s, p);
+    if (x3 == 2) {                       // IEEE-half halves (MASTER_F16X3)
+        if (v1) hipLaunchKernelGGL((window_attn_f32_kernel<true, true, X3_F16>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((window_attn_f32_kernel<false, true, X3_F16>), dim3(grid), dim3(256), 0, s, p);
+    } else if (x3) {                     // bf16 halves (MASTER_F32X3)
+        if (v1) hipLaunchKernelGGL((window_attn_f32_kernel<true, true, X3_BF16>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((window_attn_f32_kernel<false, true, X3_BF16>), dim3(grid), dim3(256), 0, s, p);
     } else {
         if (v1) hipLaunchKernelGGL((window_attn_f32_kernel<true, false>), dim3(grid), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((window_attn_f32_kernel<false, false>), dim3(grid), dim3(256), 0, s, p);

@@ -136,8 +136,8 @@ class custom_loss(nn.Module):
         gradient, which this loss makes ill-conditioned, is 0.7-1.7e-2 in relative L2 from float64 where fp32 is 0.5-3.5e-3
         (tests/test_gpu_x3.py).  conv1_1 keeps its exact fp32 kernel."""
         if isinstance(dtype, str):
-            if dtype != "bf16x3":
-                raise ValueError('compute_dtype must be torch.float32, torch.bfloat16 or "bf16x3"')
+            if dtype != "bf16x3":     # "f16x3" (IEEE-half halves, the model's parity mode) is refused here: gradients of the chain span fp32's exponent range
+                raise ValueError('compute_dtype must be torch.float32, torch.bfloat16 or "bf16x3" (the loss network keeps bf16 halves: its gradients need fp32\'s range)')
             dtype, split_bf16 = torch.float32, True
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError('compute_dtype must be torch.float32, torch.bfloat16 or "bf16x3"')

@@ -150,24 +150,31 @@ class MasterStyleTransferModel(nn.Module):
             decoder_exclude_MLP_after_Fcs_self_MHA=self.style_decoder_exclude_MLP_after_Fcs_self_MHA)
         self.style_transformer.load_state_dict(sd)
 
-    def set_compute_dtype(self, dtype, split_bf16: bool = False) -> "MasterStyleTransferModel":
+    def set_compute_dtype(self, dtype, split_bf16: bool = False, split: Optional[str] = None) -> "MasterStyleTransferModel":
         """torch.float32: exact-fp32 matrix cores, parity mode.  torch.bfloat16: bf16 MFMA, throughput mode.
-        torch.float32 with split_bf16=True (or the string "bf16x3"): the FAST parity mode - fp32 storage, norms, softmax and epilogues
-        as in the fp32 mode, every Linear / convolution as three bf16 MFMAs per product on operands split into bf16 hi + lo
-        (csrc/gemm_x3.hip); meets the 1e-3 max-abs bar of the fp32 mode (measured 1.2e-4) at several times its throughput.
-        Inference only."""
-        if dtype == "bf16x3":
-            dtype, split_bf16 = torch.float32, True
+        "f16x3" / "bf16x3" (= torch.float32 with split="f16" / "bf16"; split_bf16=True is "bf16"): the FAST parity modes - fp32 storage,
+        norms, softmax and epilogues as in the fp32 mode, every Linear / convolution / attention product as three 16-bit MFMAs on operands
+        split into hi + lo halves (csrc/gemm_x3.hip).  "f16x3" (r05) uses IEEE-half halves: hi + lo carries 22 significant bits, the stylized
+        image sits at the exact mode's distance from the CPU path (~1e-4 max-abs on outputs of max-abs 4 - 17; bar 1e-3) as long as every
+        activation stays inside half's range (|x| <= 65 504, as under fp16 autocast; beyond it the output is inf / NaN, never silently
+        wrong).  "bf16x3" (r04) uses bf16 halves: fp32's exponent range, 17 significant bits, 5e-4 ... 1e-3 on the same pairs - inside the
+        bar on the benchmark pair (1.1e-4) but without margin on others (profiles/r05_x3_split_sim.txt).  Same throughput.  Inference only."""
+        if dtype in ("bf16x3", "f16x3"):
+            dtype, split = torch.float32, dtype[:-2]
+        if split is None and split_bf16:
+            split = "bf16"
         if dtype not in (torch.float32, torch.bfloat16):
-            raise ValueError("compute_dtype must be torch.float32, torch.bfloat16 or \"bf16x3\"")
-        if split_bf16 and dtype != torch.float32:
-            raise ValueError("split_bf16 is a form of the fp32 mode: set_compute_dtype(torch.float32, split_bf16=True)")
+            raise ValueError("compute_dtype must be torch.float32, torch.bfloat16, \"f16x3\" or \"bf16x3\"")
+        if split not in (None, "bf16", "f16"):
+            raise ValueError("split must be None, \"bf16\" or \"f16\"")
+        if split and dtype != torch.float32:
+            raise ValueError("the split modes are forms of the fp32 mode: set_compute_dtype(torch.float32, split=\"f16\")")
         self.compute_dtype = dtype
-        self.split_weights = bool(split_bf16)
+        self.split_weights = split or False
         for m in self.modules():
             if isinstance(m, (_HipModule, SwinEncoder)):
                 m.compute_dtype = dtype
-                m.split_weights = bool(split_bf16)
+                m.split_weights = split or False
         # swin_T / swin_S: stage 1 is 96 channels wide and the bf16 GEMMs step K in 64s, so the patch embedding, the two stage-1 blocks
         # and the patch merging stay in fp32 (SwinEncoder.run converts once, after the merge); stage 2, the StyleTransformer and the
         # decoder (192 / 768 / 384 wide) run on the generic bf16 kernels - the fused ones are specialised for swin_B's 128 / 256.

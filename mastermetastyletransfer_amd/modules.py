@@ -52,7 +52,7 @@ def _train_mode(m: nn.Module) -> bool:
 class _HipModule(nn.Module):
     """nn.Module with a cache of tensors derived from parameters (fused / repacked / bf16 copies)."""
     compute_dtype = torch.float32
-    split_weights = False          # True: the split-bf16 fast parity mode (ops.F32X3) - fp32 activations, GEMM / conv weights as bf16 hi + lo
+    split_weights = False          # "bf16" / "f16" (or True = "bf16"): the split fast parity modes (ops.F32X3 / ops.F16X3) - fp32 activations, GEMM / conv weights as 16-bit hi + lo
 
     def _derived(self, name: str, srcs: Sequence[Tensor], build: Callable[[], Tensor]) -> Tensor:
         cache = self.__dict__.setdefault("_derived_cache", {})
@@ -69,7 +69,7 @@ class _HipModule(nn.Module):
         def build():
             w = params[0] if len(params) == 1 else torch.cat(list(params), dim=0)
             if self.split_weights:
-                return ops.split_weights(w)
+                return ops.split_weights(w, fmt=self.split_weights)
             return ops.convert(w.detach().contiguous(), self.compute_dtype)
         return self._derived("w:" + name, params, build)
 
@@ -136,7 +136,7 @@ def _mlp_fwd(owner: _HipModule, name: str, mlp: nn.Sequential, x: Tensor, residu
     relu = isinstance(mlp[1], nn.ReLU)          # MLP_activation_layer = nn.ReLU (full_model.py:47-50): the fused kernels are GELU-only
     if not relu and ops.mlp_fused_supported(x, w1.shape[0], owner.split_weights):
         # split mode: the fused kernel reads W2 in the k order of a packed accumulator tile (ops.split_weights layout 1)
-        w2f = owner._derived("w:" + name + ".3:acc_k", [mlp[3].weight], lambda: ops.split_weights(mlp[3].weight, layout=1)) \
+        w2f = owner._derived("w:" + name + ".3:acc_k", [mlp[3].weight], lambda: ops.split_weights(mlp[3].weight, layout=1, fmt=owner.split_weights)) \
             if owner.split_weights else owner._w(name + ".3", mlp[3].weight)
         try:
             return ops.mlp(x, w1, b1, w2f, b2, res=residual, ln_gamma=g, ln_beta=b, eps=norm.eps if norm is not None else EPS)
@@ -722,7 +722,7 @@ class Decoder(_HipModule):
                 if (co, ci) != tuple(w.shape[:2]):
                     w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, ci - w.shape[1], 0, co - w.shape[0]))
                 if self.split_weights and co > 4:          # the 3-channel last layer runs on the direct fp32 kernel in both fp32 modes
-                    return ops.split_weights(w.permute(0, 2, 3, 1).contiguous())
+                    return ops.split_weights(w.permute(0, 2, 3, 1).contiguous(), fmt=self.split_weights)
                 return ops.convert(w.permute(0, 2, 3, 1).contiguous(), self.compute_dtype)
             return self._derived(f"conv{i}", [conv.weight], build)
 
@@ -739,7 +739,7 @@ class Decoder(_HipModule):
                 # bf16 and split modes: Upsample + Conv(32->32) + ReLU + Conv(32->3) in one launch, intermediate kept in LDS
                 w_last = packed(last) if not self.split_weights else self._derived(
                     f"conv{last}:split", [self.decoder[last].weight],
-                    lambda: ops.split_weights(self.decoder[last].weight.detach().permute(0, 2, 3, 1).contiguous()))
+                    lambda: ops.split_weights(self.decoder[last].weight.detach().permute(0, 2, 3, 1).contiguous(), fmt=self.split_weights))
                 return ops.decoder_tail(x, packed(prev), self._b(f"conv{prev}", conv.bias), w_last,
                                         self._b(f"conv{last}", self.decoder[last].bias))
             # split mode: the maps between two x3 convolutions travel in the split layout (the consumer's LDS-DMA pieces copy them as they

@@ -15,7 +15,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MASTER_HIP_LIB") or os.path.join(_HERE, "csrc", "libmaster_hip.so")   # override: A/B runs of two builds
 
-F32, BF16, F32X3 = 0, 1, 2
+F32, BF16, F32X3, F16X3 = 0, 1, 2, 3   # F32X3 / F16X3: fp32 storage, three 16-bit MFMAs per product on bf16 / IEEE-half operand halves
+SPLIT_F16 = 0x10                        # OR-ed into the layout argument of master_split_weights: IEEE-half halves
 A_SPLIT, OUT_SPLIT = 0x200, 0x400        # OR-ed into F32X3: activation operand / output in the split layout (include/master_hip.h)
 
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
@@ -208,20 +209,38 @@ def _dev(*ts):
             raise MasterHipError("the stylization path runs on the GPU only (got a CPU tensor); there is no CPU fallback")
 
 
+_SPLIT_DTYPES = (torch.bfloat16, torch.float16)
+
+
 def is_split(w: torch.Tensor) -> bool:
-    """True for a weight in the split-bf16 layout of the F32X3 mode: [rows, K/32, 2, 32] bf16 (split_weights)"""
-    return w.dtype == torch.bfloat16 and w.dim() == 4 and w.shape[2] == 2 and w.shape[3] == 32
+    """True for a weight in the split layout of the F32X3 / F16X3 modes: [rows, K/32, 2, 32] bf16 or half (split_weights)"""
+    return w.dtype in _SPLIT_DTYPES and w.dim() == 4 and w.shape[2] == 2 and w.shape[3] == 32
 
 
 def is_split_act(x: torch.Tensor) -> bool:
-    """True for an NHWC activation map in the split layout [B, H, W, C/32, 2, 32] bf16 (written by a convolution with out_split=True)"""
-    return x.dtype == torch.bfloat16 and x.dim() == 6 and x.shape[4] == 2 and x.shape[5] == 32
+    """True for an NHWC activation map in the split layout [B, H, W, C/32, 2, 32] bf16 or half (written by a convolution with out_split=True)"""
+    return x.dtype in _SPLIT_DTYPES and x.dim() == 6 and x.shape[4] == 2 and x.shape[5] == 32
+
+
+def x3_code(w: torch.Tensor) -> int:
+    """the C ABI's dtype code of a split operand: bf16 halves -> MASTER_F32X3, IEEE-half halves -> MASTER_F16X3"""
+    return F16X3 if w.dtype == torch.float16 else F32X3
+
+
+def split_torch_dtype(fmt) -> torch.dtype:
+    """"bf16" (or True) / "f16" -> the torch dtype that tags a split tensor of that format"""
+    if fmt in (True, "bf16"):
+        return torch.bfloat16
+    if fmt == "f16":
+        return torch.float16
+    raise ValueError(f"split format must be 'bf16' or 'f16' (got {fmt!r})")
 
 
 @_on_device
-def split_weights(w: torch.Tensor, layout: int = 0) -> torch.Tensor:
+def split_weights(w: torch.Tensor, layout: int = 0, fmt="bf16") -> torch.Tensor:
     """fp32 [rows, K] (or a packed conv weight [Cout,3,3,Cin], flattened) -> bf16 [rows, K/32, 2, 32]: per 32-wide k chunk the 32 bf16
     hi = bf16(w) then the 32 bf16 lo = bf16(w - hi) - what master_linear_fwd / master_conv3x3_reflect_fwd take as `w` with MASTER_F32X3.
+    fmt="f16": IEEE-half halves (torch.float16 tensor of the same shape), the weight operand of MASTER_F16X3.
     layout=1: k order 0-3, 8-11, 4-7, 12-15 inside every group of 16 (the second Linear of the fused MLP, master_mlp_fwd)"""
     _dev(w)
     w = w.detach().float().contiguous()
@@ -229,8 +248,10 @@ def split_weights(w: torch.Tensor, layout: int = 0) -> torch.Tensor:
     K = w.numel() // rows
     if K % 32:
         raise MasterHipError(f"split_weights: K = {K} is not a multiple of 32")
-    out = torch.empty((rows, K // 32, 2, 32), dtype=torch.bfloat16, device=w.device)
-    _check(load_library().master_split_weights(_p(w), _p(out), rows, K, layout, _stream()), "master_split_weights")
+    dt = split_torch_dtype(fmt)
+    out = torch.empty((rows, K // 32, 2, 32), dtype=dt, device=w.device)
+    _check(load_library().master_split_weights(_p(w), _p(out), rows, K, layout | (SPLIT_F16 if dt == torch.float16 else 0), _stream()),
+           "master_split_weights")
     return out
 
 
@@ -259,7 +280,7 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         _count("linear", flops=2.0 * M * N * K,
                bytes=es * (M * K + N * K + M * N * (1 + (r1 is not None) + (r2 is not None))))
     _check(load_library().master_linear_fwd(_p(a), _p(w), _p(bias), _p(r1), _p(r2), _p(out), M, N, K, a.stride(0),
-                                             out.stride(0), ldr, act, F32X3 if x3 else _dt(a), _stream()), "master_linear_fwd")
+                                             out.stride(0), ldr, act, x3_code(w) if x3 else _dt(a), _stream()), "master_linear_fwd")
     return out
 
 
@@ -330,7 +351,7 @@ def mlp(x: torch.Tensor, w1, b1, w2, b2, res: Optional[torch.Tensor] = None, ln_
         _count("mlp", flops=4.0 * M * C * HID, bytes=x.element_size() * (M * C * (2 + extra_res) + 2 * C * HID))
     _check(load_library().master_mlp_fwd(_p(x), _p(ln_gamma), _p(ln_beta), _p(w1), _p(b1), _p(w2), _p(b2), _p(res), _p(out),
                                           M, C, HID, x.stride(0), res.stride(0) if res is not None else 0, out.stride(0),
-                                          eps, F32X3 if x3 else _dt(x), _stream()), "master_mlp_fwd")
+                                          eps, x3_code(w1) if x3 else _dt(x), _stream()), "master_mlp_fwd")
     return out
 
 
@@ -347,20 +368,20 @@ def conv3x3_reflect(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor,
     Cout = w_packed.shape[0]
     x3 = is_split(w_packed)
     assert x.is_contiguous() and w_packed.is_contiguous() and bias.dtype == torch.float32
-    assert not x3 or ((a_split or x.dtype == torch.float32) and w_packed.shape[1] * 32 == 9 * Cin)
+    assert not x3 or ((x.dtype == w_packed.dtype if a_split else x.dtype == torch.float32) and w_packed.shape[1] * 32 == 9 * Cin)
     assert x3 or not (a_split or out_split), "split activations belong to the F32X3 mode"
     Ho, Wo = (H * 2, W * 2) if upsample else (H, W)
     if out_nchw:
         out = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
     elif out_split:
         assert Cout % 32 == 0
-        out = torch.empty((B, Ho, Wo, Cout // 32, 2, 32), dtype=torch.bfloat16, device=x.device)
+        out = torch.empty((B, Ho, Wo, Cout // 32, 2, 32), dtype=w_packed.dtype, device=x.device)      # halves in the weights' format
     else:
         out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32 if a_split else x.dtype, device=x.device)
     if _COUNT_ON:
         _count("conv3x3", flops=2.0 * B * Ho * Wo * Cout * 9 * Cin,
                bytes=x.element_size() * (x.numel() + w_packed.numel()) + out.element_size() * out.numel())
-    dt = (F32X3 | (A_SPLIT if a_split else 0) | (OUT_SPLIT if out_split else 0)) if x3 else _dt(x)
+    dt = (x3_code(w_packed) | (A_SPLIT if a_split else 0) | (OUT_SPLIT if out_split else 0)) if x3 else _dt(x)
     _check(load_library().master_conv3x3_reflect_fwd(_p(x), _p(w_packed), _p(bias), _p(out), B, H, W, Cin, Cout,
                                                       int(upsample), int(relu), int(out_nchw), dt, _stream()),
            "master_conv3x3_reflect_fwd")
@@ -409,7 +430,7 @@ def decoder_tail(x: torch.Tensor, w8, b8, w9, b9) -> torch.Tensor:
     assert x.is_contiguous() and w8.is_contiguous() and w9.is_contiguous()
     if x3:
         assert is_split(w9) and w8.shape[:2] == (32, 9) and w9.shape[:2] == (3, 9)
-        dt = F32X3 | (A_SPLIT if is_split_act(x) else 0)
+        dt = x3_code(w8) | (A_SPLIT if is_split_act(x) else 0)
     else:
         assert w8.shape == (32, 3, 3, 32) and w9.shape == (3, 3, 3, 32)
         dt = _dt(x)
@@ -423,9 +444,10 @@ def decoder_tail(x: torch.Tensor, w8, b8, w9, b9) -> torch.Tensor:
 
 @_on_device
 def window_attn(q, k, v0, v1, k_pad, v0_pad, v1_pad, bias64, src, region, B: int, T: int, heads: int, nW: int, N: int,
-                scale: float, x3: bool = False):
+                scale: float, x3=False):
     """q/k/v*: [B*T, heads*32] views (row stride free).  Returns out0 (and out1 when v1 is given), [B*T, heads*32].
-    x3 (fp32 tensors): both products as three bf16 MFMAs on operands split in registers (the F32X3 fast parity mode)."""
+    x3 (fp32 tensors; True / "bf16" / "f16"): both products as three 16-bit MFMAs on operands split in registers into bf16 or IEEE-half
+    halves (the F32X3 / F16X3 fast parity modes)."""
     _dev(q, k, v0)
     C = heads * 32
     out0 = torch.empty((B * T, C), dtype=q.dtype, device=q.device)
@@ -440,7 +462,7 @@ def window_attn(q, k, v0, v1, k_pad, v0_pad, v1_pad, bias64, src, region, B: int
     _check(load_library().master_window_attn_fwd(
         _p(q), _p(k), _p(v0), _p(v1), q.stride(0), k.stride(0), v0.stride(0), _p(k_pad), _p(v0_pad), _p(v1_pad),
         kbs, vbs, _p(bias64), _p(src), _p(region), _p(out0), _p(out1), C, B, T, heads, nW, N, float(scale),
-        F32X3 if (x3 and q.dtype == torch.float32 and os.environ.get("MASTER_ATTN_X3", "1") != "0") else _dt(q),
+        (F16X3 if x3 == "f16" else F32X3) if (x3 and q.dtype == torch.float32 and os.environ.get("MASTER_ATTN_X3", "1") != "0") else _dt(q),
         _stream()), "master_window_attn_fwd")
     return out0, out1
 
@@ -605,7 +627,7 @@ def conv3x3_zero(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, re
         lc = Cin if logical_cin is None else logical_cin
         _count("conv3x3", flops=2.0 * B * H * W * Cout * 9 * lc,
                bytes=x.element_size() * (B * H * W * lc + Cout * 9 * lc + out.numel()))
-    dt = F32X3 if is_split(w_packed) else _dt(x)
+    dt = x3_code(w_packed) if is_split(w_packed) else _dt(x)
     _check(load_library().master_conv3x3_zero_fwd(_p(x), _p(w_packed), _p(bias), _p(out), B, H, W, Cin, Cout, int(relu), dt, _stream()),
            "master_conv3x3_zero_fwd")
     return out

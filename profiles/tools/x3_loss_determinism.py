@@ -9,7 +9,7 @@ from oracle import loss_oracle as L
 from oracle.seeded import seeded_input, seeded_state_dict
 
 dev = torch.device("cuda:0")
-REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 6
 bad = 0
 
 

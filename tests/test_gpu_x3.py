@@ -306,6 +306,33 @@ def test_x3_kernels_repeatable_at_scale(cuda):
     assert e.value.code == 0
 
 
+def test_x3_loss_network_repeatable_at_scale(cuda):
+    """the zero-padded convolutions and the data-gradient chain (mask_relu epilogue) of the split-bf16 loss network, small and full map
+    sizes, several launches on the same inputs with recycled allocations holding garbage in between: bitwise identical"""
+    import runpy, os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    argv = sys.argv
+    sys.argv = ["x3_loss_determinism.py", "4"]
+    try:
+        with pytest.raises(SystemExit) as e:
+            runpy.run_path(os.path.join(root, "profiles", "tools", "x3_loss_determinism.py"), run_name="__main__")
+    finally:
+        sys.argv = argv
+    assert e.value.code == 0
+
+
+def test_x3_tile_variants_repeatable(cuda):
+    """the A/B tile forms behind MASTER_X3_TILE = 1..6 and the eight-wave C = 128 MLP (MASTER_MLP_X3_C128=8w) are read once per process,
+    so each runs the determinism tool in a child process of its own (one at a time; ADVICE r04: the default tiles alone were covered)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "profiles", "tools", "x3_determinism.py")
+    runs = [({"MASTER_X3_TILE": str(t)}, "linear,conv") for t in range(1, 7)] + [({"MASTER_MLP_X3_C128": "8w"}, "mlp")]
+    for env, only in runs:
+        r = subprocess.run([sys.executable, tool, "4", "--only", only], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, f"{env}: rc {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}"
+
+
 # ---- the frozen loss network of the train step in split-bf16 (custom_loss.set_compute_dtype("bf16x3")) -------------------------------
 @pytest.mark.parametrize("B,H,W,Cg,Cx,mask,add", [(2, 16, 16, 64, 64, True, True), (1, 9, 13, 128, 64, True, False), (2, 8, 8, 512, 256, False, False),
                                                   (1, 32, 32, 64, 32, False, False), (3, 7, 5, 256, 256, True, True)])
