@@ -25,7 +25,8 @@ import torch  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "x3": 2500.0 / 3}     # dense MFMA peaks, MI355X_MICROARCH.md; x3: three bf16 MFMAs per product
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "x3": 2500.0 / 3, "x3b": 2500.0 / 3}     # dense MFMA peaks, MI355X_MICROARCH.md; x3: three 16-bit MFMAs per product
+MODE_OF = {"fp32": torch.float32, "bf16": torch.bfloat16, "x3": "f16x3", "x3b": "bf16x3"}     # --dtype -> model.set_compute_dtype
 BF16_REL_L2_BOUND = 2.5e-2                          # bf16 mode vs the fp32 CPU oracle (measured 1.7e-2); the run fails above it
 HBM_PEAK_GBS = 8000.0
 
@@ -56,7 +57,7 @@ def build_model(device, dtype, window=7):
         if n.startswith("swin_encoder") and n.endswith("bias"):
             torch.nn.init.trunc_normal_(p, std=0.02)
     m = m.to(device).eval()
-    m.set_compute_dtype({"fp32": torch.float32, "bf16": torch.bfloat16, "x3": "bf16x3"}[dtype])
+    m.set_compute_dtype(MODE_OF[dtype])
     return m
 
 
@@ -78,9 +79,10 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--layers", type=int, default=1, help="transformer_layer_count k")
     ap.add_argument("--window", type=int, default=7, help="StyleTransformer window (7 = BASELINE.json; 8 = the reference constructor's default)")
-    ap.add_argument("--dtype", choices=["fp32", "bf16", "x3"], default=os.environ.get("MASTER_BENCH_DTYPE", "bf16"),
+    ap.add_argument("--dtype", choices=["fp32", "bf16", "x3", "x3b"], default=os.environ.get("MASTER_BENCH_DTYPE", "bf16"),
                     help="bf16 = BASELINE.json's configuration (bf16 MFMA, fp32 accumulate); fp32 = exact-fp32 parity mode; "
-                         "x3 = fast parity mode (fp32 storage, three bf16 MFMAs per product on split operands)")
+                         "x3 = fast parity mode (fp32 storage, three 16-bit MFMAs per product on operands split into IEEE-half hi + lo: 'f16x3'); "
+                         "x3b = the same with bf16 halves ('bf16x3': fp32's exponent range, ~10x the error)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / parity / cpu_baseline legs")
     ap.add_argument("--no-repeats", action="store_true", help="skip the ten repeat blocks behind the timed one")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
@@ -215,7 +217,7 @@ def main():
         dist.destroy_process_group()
     # a headline number whose parity leg failed is not a result: fail the run
     par, par32, par3 = result.get("parity"), result.get("parity_fp32_mode"), result.get("parity_x3_mode")
-    bad = (par32 is not None and not par32["pass"]) or (par3 is not None and not par3["pass"]) or (par is not None and par["dtype"] in ("fp32", "x3") and par["max_abs_vs_cpu_oracle"] > 1e-3) or \
+    bad = (par32 is not None and not par32["pass"]) or (par3 is not None and not par3["pass"]) or (par is not None and par["dtype"] in ("fp32", "x3") and par["max_abs_vs_cpu_oracle"] > 1e-3) or (par3 is not None and par3["worst_of_pairs"]["max_abs_vs_cpu_oracle"] > 1e-3) or \
           (par is not None and par["dtype"] == "bf16" and par["rel_l2"] > BF16_REL_L2_BOUND)
     if bad:
         print("bench.py: PARITY FAILED - the images/s above must not be used", file=sys.stderr)
@@ -351,7 +353,7 @@ def extras(model, content, style, k, args, ops):
         ref = O.full_forward(c1.cpu(), s1.cpu(), k, *sds)
     out["parity"] = {"dtype": args.dtype, "max_abs_vs_cpu_oracle": float((got - ref).abs().max()), "ref_max_abs": float(ref.abs().max()),
                      "rel_l2": float((got - ref).norm() / ref.norm()),
-                     "tolerance": "max-abs <= 1e-3" if args.dtype in ("fp32", "x3") else f"rel-L2 <= {BF16_REL_L2_BOUND} (bf16 cannot meet 1e-3 max-abs; see parity_fp32_mode / parity_x3_mode)"}
+                     "tolerance": "max-abs <= 1e-3" if args.dtype in ("fp32", "x3", "x3b") else f"rel-L2 <= {BF16_REL_L2_BOUND} (bf16 cannot meet 1e-3 max-abs; see parity_fp32_mode / parity_x3_mode)"}
     # what the bf16 error means for an image: 8-bit grey levels after the harness's clip(x*255) (test_model.py:207)
     q = lambda t: (t * 255.0).clamp(0, 255).to(torch.uint8).float()
     dq = (q(got) - q(ref)).abs()
@@ -380,13 +382,32 @@ def extras(model, content, style, k, args, ops):
         c5, s5 = synthetic_batch(16, 512, content.device, seed=5)
         t5 = timed(c5, s5, 4, warm=1)
         del c5, s5
-        # ---- the FAST parity mode (split-bf16, "bf16x3"): fp32 storage, three bf16 MFMAs per product; same 1e-3 bar, asserted here ----
-        model.set_compute_dtype("bf16x3")
+        # ---- the FAST parity mode ("f16x3": fp32 storage, three 16-bit MFMAs per product on IEEE-half operand halves); same 1e-3 bar, asserted
+        #      here - on the benchmark pair and on three more content / style pairs of other sizes and statistics (the worst is reported:
+        #      ADVICE r04), next to the bf16 halves of r04 ("bf16x3") and the exact-fp32 kernels on the same pairs
+        from oracle.seeded import seeded_input
+        pairs = [(c1, s1, ref)]
+        for size, seed in ((64, 14), (128, 4), (128, 34)):
+            cp = seeded_input("smoke_c" if seed == 4 else f"sim_c{seed}", (1, 3, size, size), seed, kind="image")
+            sp = seeded_input("smoke_s" if seed == 4 else f"sim_s{seed}", (1, 3, size, size), seed + 1, kind="image")
+            with torch.no_grad():
+                pairs.append((cp.to(content.device), sp.to(content.device), O.full_forward(cp, sp, k, *sds)))
+        worst = {}
+        for mode in ("f16x3", "bf16x3", torch.float32):
+            model.set_compute_dtype(mode)
+            with torch.no_grad():
+                errs = [(float((model(cp, sp, k).float().cpu() - rp).abs().max()), float(rp.abs().max())) for cp, sp, rp in pairs]
+            worst[str(mode).replace("torch.", "")] = {"max_abs_vs_cpu_oracle": max(e for e, _ in errs), "ref_max_abs_of_that_pair": max(errs)[1],
+                                                       "benchmark_pair": errs[0][0]}
+        model.set_compute_dtype("f16x3")
         with torch.no_grad():
             got3 = model(c1, s1, k).float().cpu()
         e3 = float((got3 - ref).abs().max())
-        out["parity_x3_mode"] = {"max_abs_vs_cpu_oracle": e3, "ref_max_abs": float(ref.abs().max()), "rel_l2": float((got3 - ref).norm() / ref.norm()),
-                                 "tolerance": 1e-3, "pass": bool(e3 <= 1e-3)}
+        out["parity_x3_mode"] = {"mode": "f16x3", "max_abs_vs_cpu_oracle": e3, "ref_max_abs": float(ref.abs().max()), "rel_l2": float((got3 - ref).norm() / ref.norm()),
+                                 "tolerance": 1e-3, "worst_of_pairs": dict(worst["f16x3"], pairs="the benchmark pair + 64^2 seed 14, 128^2 seeds 4 (the smoke() pair) and 34 "
+                                                                                                    "(oracle.seeded images, outputs of max-abs 12 - 17)"),
+                                 "bf16_halves_same_pairs": worst["bf16x3"], "exact_fp32_kernels_same_pairs": worst["float32"],
+                                 "pass": bool(e3 <= 1e-3 and worst["f16x3"]["max_abs_vs_cpu_oracle"] <= 1e-3)}
         from mastermetastyletransfer_amd import GraphedStylizer
         g3 = GraphedStylizer(model, B, S, S, k)
         g3.content.copy_(content); g3.style.copy_(style)
@@ -427,8 +448,9 @@ def extras(model, content, style, k, args, ops):
                     tb += v["hbm_bytes_per_launch"] * v["launches"]; tn += v["launches"]
             if tn:
                 tr3, tr3_src = round(tb / tn), os.path.relpath(p3, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-        out["x3_mode"] = {"note": "fast parity mode: fp32 storage, every Linear / convolution as three bf16 MFMAs per product on operands split "
-                                  "into bf16 hi + lo (csrc/gemm_x3.hip, mlp_x3.hip); meets the 1e-3 max-abs bar (parity_x3_mode)",
+        out["x3_mode"] = {"note": "fast parity mode 'f16x3': fp32 storage, every Linear / convolution / attention product as three 16-bit MFMAs on operands split "
+                                  "into IEEE-half hi + lo (csrc/gemm_x3.hip, mlp_x3.hip); sits at the exact-fp32 kernels' distance from the CPU path (parity_x3_mode); "
+                                  "'bf16x3' (bf16 halves, r04) runs the same kernels at the same rate with ~10x the error and fp32's exponent range",
                           "config1_bs%d_%d" % (B, S): {"images_per_s": round(B / t3, 1), "ms_per_step": round(t3 * 1e3, 3), "steps": 20, "launch": "hipGraph replay"},
                           "config5_bs16_512": {"images_per_s": round(16 / t53, 1), "ms_per_step": round(t53 * 1e3, 3), "steps": 4, "launch": "eager"},
                           "kernels": fam3,

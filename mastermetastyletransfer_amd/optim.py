@@ -142,6 +142,9 @@ class FusedAdam(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             d = self._dev.get(gi)
             steps = {int(self.state[p]["step"]) for p in group["params"] if self.state.get(p)}
+            if self.capturable and steps:
+                # a resumed group HAS stepped: the late-joiner guard of step() must see that (its counter lives outside the state dict)
+                self.__dict__.setdefault("_cap_stepped", {})[gi] = max(self.__dict__.get("_cap_stepped", {}).get(gi, 0), max(steps))
             if d is not None and steps:
                 d["step"].fill_(steps.pop())
 

@@ -881,3 +881,24 @@ def test_capturable_adam_refuses_a_parameter_that_joins_late(cuda):
     b.grad = torch.randn_like(b)
     with pytest.raises(MasterHipError, match="share their step count"):
         opt.step()
+
+
+def test_capturable_adam_keeps_the_late_joiner_guard_across_a_resume(cuda):
+    """the guard's counter is not part of the state dict; load_state_dict rebuilds it from the loaded step counts, so a
+    parameter without saved state still cannot join a resumed group at device step t > 1"""
+    from mastermetastyletransfer_amd import FusedAdam
+    from mastermetastyletransfer_amd.ops import MasterHipError
+    a, b = (torch.nn.Parameter(torch.randn(64, device=cuda)) for _ in range(2))
+    opt = FusedAdam([a, b], lr=1e-3, capturable=True)
+    a.grad = torch.randn_like(a)
+    opt.step(); opt.step()
+    sd = opt.state_dict()
+    a2, b2 = (torch.nn.Parameter(t.detach().clone()) for t in (a, b))
+    fresh = FusedAdam([a2, b2], lr=1e-3, capturable=True)
+    fresh.load_state_dict(sd)
+    a2.grad = a.grad.clone()
+    fresh.step()                                                   # the resumed tensor steps on
+    assert int(fresh.state_dict()["state"][0]["step"]) == 3
+    b2.grad = torch.randn_like(b2)
+    with pytest.raises(MasterHipError, match="share their step count"):
+        fresh.step()
