@@ -100,6 +100,8 @@ int preprocess_launch(const uint8_t*, int, int, int, float*, int, int, const int
 int postprocess_launch(const float*, uint8_t*, int, int, int, hipStream_t);
 int mlp_c128_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const float*,
                   const bf16_t*, bf16_t*, int, int, int, int, int, int, float, hipStream_t);
+int mlp_2w_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const float*,
+                const bf16_t*, bf16_t*, int, int, int, int, int, int, float, hipStream_t);
 
 int gemm_x3_split_weights(const float*, void*, size_t, size_t, int, hipStream_t, int fmt);
 int conv_tail_x3(const void*, int, const void*, const float*, const void*, const float*, float*, int, int, int, hipStream_t, int fmt);
@@ -661,6 +663,11 @@ int master_mlp_fwd(const void* x, const float* ln_gamma, const float* ln_beta, c
     // forms of the same kernel.  Default: the 256-token specialisation for C = 128 (mlp_c128_bf16.hip), else the one-wave-per-SIMD
     // form (mlp_bf16.hip).  MASTER_MLP_FORM=mono forces the generic form.
     const char* form = getenv("MASTER_MLP_FORM");              // read per call: tests cover every form in one process
+    if (form && !strcmp(form, "2w")) {                        // C = 128: two workgroups per CU, GELU dealt out behind the phase-1 MFMAs (mlp_2w_bf16.hip)
+        const int rc = mlp_2w_bf16((const bf16_t*)x, ln_gamma, ln_beta, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, (const bf16_t*)res,
+                                   (bf16_t*)out, M, C, HID, ldx, ldr, ldo, eps, s);
+        if (rc != MASTER_ERR_UNSUPPORTED) return rc;
+    }
     if (!form || strcmp(form, "mono")) {
         const int rc = mlp_c128_bf16((const bf16_t*)x, ln_gamma, ln_beta, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, (const bf16_t*)res,
                                      (bf16_t*)out, M, C, HID, ldx, ldr, ldo, eps, s);

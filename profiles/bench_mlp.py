@@ -2,7 +2,9 @@ import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mastermetastyletransfer_amd import ops
 dev = torch.device("cuda:0")
-for M, C, HID in [(32768,256,1024),(65536,256,1024),(262144,128,512)]:
+shapes = [(262144,128,512)] if "c128" in sys.argv else [(32768,256,1024),(65536,256,1024),(262144,128,512)]
+print("MASTER_MLP_FORM =", os.environ.get("MASTER_MLP_FORM"))
+for M, C, HID in shapes:
     x = torch.randn(M, C, device=dev).bfloat16(); w1 = (torch.randn(HID, C, device=dev)/16).bfloat16(); w2 = (torch.randn(C, HID, device=dev)/32).bfloat16()
     b1 = torch.randn(HID, device=dev); b2 = torch.randn(C, device=dev); g = torch.ones(C, device=dev)
     for ln in (False, True):
