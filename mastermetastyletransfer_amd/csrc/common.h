@@ -38,8 +38,24 @@ __device__ __forceinline__ void split_f16x2(float x0, float x1, unsigned& hi, un
     unsigned a = pack_f16x2(x0, x1);
     asm("" : "+v"(a));
     hi = a;
+#if defined(MASTER_SPLIT_NO_FMA_MIX)   // A/B builds: the remainder through v_cvt_f32_f16 + v_sub_f32 + v_cvt_pk (6 vector instructions per pair)
     const f16x2_hw v = __builtin_bit_cast(f16x2_hw, a);
     lo = pack_f16x2(x0 - (float)v[0], x1 - (float)v[1]);
+#elif defined(MASTER_SPLIT_FMA_MIX_F32)  // A/B builds: x - float(hi) by v_fma_mix_f32, then v_cvt_pk (4 per pair; r05 first form: the x3 step 5.05 -> 4.81 ms)
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(a), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(a), "v"(x1));
+    lo = pack_f16x2(l0, l1);
+#else
+    // lo = half(x - float(hi)) in ONE instruction per value, THREE per pair: v_fma_mixlo_f16 / v_fma_mixhi_f16 read the half straight out of
+    // the packed word (op_sel picks the half, op_sel_hi marks source 0 as f16), compute hi * -1.0 + x in fp32 (exact: x - hi is representable)
+    // and round the result to half (nearest even) into the low / high half of the destination - bit-identical to the long form
+    // (tests/test_gpu_f16x3.py::test_split_weights_half_layout_bit_exact, subnormal remainders included)
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(a), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(a), "v"(x1));
+    lo = l;
+#endif
 }
 // operand format of the split kernels: X3_BF16 (MASTER_F32X3) or X3_F16 (MASTER_F16X3); fragments travel as four 32-bit words either way
 constexpr int X3_BF16 = 0, X3_F16 = 1;
