@@ -41,7 +41,7 @@ __device__ __forceinline__ void split_f16x2(float x0, float x1, unsigned& hi, un
 #if defined(MASTER_SPLIT_NO_FMA_MIX)   // A/B builds: the remainder through v_cvt_f32_f16 + v_sub_f32 + v_cvt_pk (6 vector instructions per pair)
     const f16x2_hw v = __builtin_bit_cast(f16x2_hw, a);
     lo = pack_f16x2(x0 - (float)v[0], x1 - (float)v[1]);
-#elif defined(MASTER_SPLIT_FMA_MIX_F32)  // A/B builds: x - float(hi) by v_fma_mix_f32, then v_cvt_pk (4 per pair; r05 first form: the x3 step 5.05 -> 4.81 ms)
+#elif defined(MASTER_SPLIT_FMA_MIX_F32)  // A/B builds: x - float(hi) by v_fma_mix_f32, then v_cvt_pk (4 per pair; measured equal to the shipped form)
     float l0, l1;
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(a), "v"(x0));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(a), "v"(x1));
