@@ -88,7 +88,9 @@ def main():
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = the headline metric; train = BASELINE config 4: inner-loop train step bs=8 256x256 (fp32 mode), steps/s")
     ap.add_argument("--eager", action="store_true", help="enqueue kernel by kernel instead of replaying a HIP graph of the forward")
-    ap.add_argument("--loss-dtype", choices=["fp32", "bf16", "x3"], default="fp32", help="--mode train: compute dtype of the frozen VGG-19 loss network")
+    ap.add_argument("--loss-dtype", choices=["fp32", "bf16", "x3", "x3b"], default="fp32",
+                    help="--mode train: compute dtype of the frozen VGG-19 loss network (x3 = 'f16x3': half halves forward, bf16 halves in the data gradients; x3b = 'bf16x3')")
+    ap.add_argument("--encoder-dtype", choices=["fp32", "x3"], default="fp32", help="--mode train: the frozen Swin encoder in exact fp32 or in f16x3")
     ap.add_argument("--train-graph", type=int, default=int(os.environ.get("MASTER_TRAIN_GRAPH", "0")),
                     help="--mode train: 1 = replay one hipGraph per layer count k (graph.GraphedTrainStep), 0 = enqueue launch by launch")
     args = ap.parse_args()
@@ -468,8 +470,13 @@ def extras(model, content, style, k, args, ops):
             out["train_step"]["gradients_vs_float64_oracle"] = train_grad_check(content.device)
             alt3 = train_bench(content.device, steps=5, warmup=2, roofline=False, loss_dtype="x3")
             out["train_step"]["with_x3_loss_network"] = {"value": alt3["value"], "unit": "steps/s", "ms_per_step": alt3["ms_per_step"],
-                                                         "note": "frozen VGG-19 convolutions and data gradients as split-bf16 products on fp32 maps (custom_loss.set_compute_dtype('bf16x3')); "
-                                                                 "model, weight gradients and Adam fp32; its gradients against float64: gradients_vs_float64_oracle.with_x3_loss_network"}
+                                                         "note": "frozen VGG-19 of the loss in the split mode (custom_loss.set_compute_dtype('f16x3'): IEEE-half halves in the forward convolutions, bf16 halves in the "
+                                                                 "data gradients; fp32 maps); model, weight gradients and Adam exact fp32; its gradients against float64: "
+                                                                 "gradients_vs_float64_oracle.with_x3_loss_network"}
+            alt4 = train_bench(content.device, steps=5, warmup=2, roofline=False, loss_dtype="x3", encoder_dtype="x3")
+            out["train_step"]["with_x3_frozen_networks"] = {"value": alt4["value"], "unit": "steps/s", "ms_per_step": alt4["ms_per_step"],
+                                                            "note": "as with_x3_loss_network, and the frozen Swin encoder (no graph) in f16x3 as well (model.set_encoder_compute_dtype('f16x3')); "
+                                                                    "gradients_vs_float64_oracle.with_x3_frozen_networks"}
             alt = train_bench(content.device, steps=5, warmup=2, roofline=False, loss_dtype="bf16")
             out["train_step"]["with_bf16_loss_network"] = {"value": alt["value"], "unit": "steps/s", "ms_per_step": alt["ms_per_step"],
                                                            "note": "frozen VGG-19 in bf16 (activations and data gradients); model, weight gradients and Adam fp32"}
@@ -504,7 +511,7 @@ def extras(model, content, style, k, args, ops):
 FWD_GFLOP = {"swin_per_image": 7.552, "st_layer": 9.079, "decoder": 7.965, "vgg": 47.34}      # per image @256^2, BASELINE.md section 3
 
 
-def train_bench(device, steps=10, warmup=3, B=8, S=256, max_layers=4, roofline=True, loss_dtype="fp32", graph=False):
+def train_bench(device, steps=10, warmup=3, B=8, S=256, max_layers=4, roofline=True, loss_dtype="fp32", graph=False, encoder_dtype="fp32"):
     """K train steps: random k, train-mode forward (StochasticDepth masks drawn on the device), custom_loss, backward, FusedAdam.
     Returns the result dict (steps/s, algorithmic TFLOP/s, per-family kernel times of one step, roofline of the dominant family)."""
     import random
@@ -518,7 +525,9 @@ def train_bench(device, steps=10, warmup=3, B=8, S=256, max_layers=4, roofline=T
         if isinstance(m_, torch.nn.Conv2d):
             torch.nn.init.kaiming_normal_(m_.weight, nonlinearity="relu"); torch.nn.init.normal_(m_.bias, std=0.05)
     loss_fn = custom_loss(default_lambda_value=10.0, vgg_state_dict=vgg.state_dict()).to(device)
-    loss_fn.set_compute_dtype({"fp32": torch.float32, "bf16": torch.bfloat16, "x3": "bf16x3"}[loss_dtype])     # the frozen loss network only; the model stays fp32
+    loss_fn.set_compute_dtype({"fp32": torch.float32, "bf16": torch.bfloat16, "x3": "f16x3", "x3b": "bf16x3"}[loss_dtype])     # the frozen loss network; the trainable model stays fp32
+    if encoder_dtype == "x3":                          # the other frozen network, the Swin encoder (no graph): IEEE-half halves
+        model.set_encoder_compute_dtype("f16x3")
     opt = FusedAdam([{"params": model.style_transformer.parameters()}, {"params": model.decoder.parameters()}], lr=1e-4, capturable=graph)
     content, style = synthetic_batch(B, S, device, seed=11)
     random.seed(0)
@@ -554,7 +563,8 @@ def train_bench(device, steps=10, warmup=3, B=8, S=256, max_layers=4, roofline=T
     res = {"metric": "train steps/sec, inner-loop step (train-mode forward + VGG-19 perceptual loss + backward + Adam), bs=8 256x256",
            "value": round(steps / dt, 3), "unit": "steps/s", "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps, "warmup": warmup,
            "dtype": {"fp32": "fp32", "bf16": "fp32 model + bf16 frozen VGG-19 loss network",
-                     "x3": "fp32 model + split-bf16 (bf16x3, fp32 maps) frozen VGG-19 loss network"}[loss_dtype], "images_per_s": round(B * steps / dt, 1),
+                     "x3": "fp32 model + split (f16x3: half halves forward, bf16 halves in the data gradients; fp32 maps) frozen VGG-19 loss network",
+                     "x3b": "fp32 model + split-bf16 (bf16x3, fp32 maps) frozen VGG-19 loss network"}[loss_dtype] + (", frozen Swin encoder in f16x3" if encoder_dtype == "x3" else ""), "images_per_s": round(B * steps / dt, 1),
            "transformer_layer_counts": kt,
            "alg_tflop_per_step": round(gf / steps / 1e3, 3), "alg_tflops": round(gf / dt / 1e3, 2),
            "frac_of_fp32_mfma_peak": round(gf / dt / 1e3 / PEAK_TFLOPS["fp32"], 4), "final_loss": float(last.detach())}
@@ -618,8 +628,9 @@ def train_grad_check(device, B=8, S=256, k=2):
     named = [("style_transformer." + n, p) for n, p in m.style_transformer.named_parameters()] + [("decoder." + n, p) for n, p in m.decoder.named_parameters()]
     gscale = max(float(v.abs().max()) for v in ref64.values())
 
-    def run(loss_mode):
+    def run(loss_mode, encoder_mode=torch.float32):
         loss_fn.set_compute_dtype(loss_mode)
+        m.set_encoder_compute_dtype(encoder_mode)
         for _, p in named:
             p.grad = None
         TF.sd_masks.set_masks(swin_masks + masks)
@@ -639,7 +650,9 @@ def train_grad_check(device, B=8, S=256, k=2):
                 "median": round(errs[len(errs) // 2][0], 6), "bound": 5e-3, "pass": bool(errs[-1][0] <= 5e-3), "loss_hip": float(total.detach())}
     res = {"config": f"B={B} {S}x{S} k={k}, explicit StochasticDepth masks, lambda 10", **run(torch.float32),
            "loss_float64_oracle": float(losses64["total"])}
-    res["with_x3_loss_network"] = run("bf16x3")
+    res["with_x3_loss_network"] = run("f16x3")
+    res["with_x3_frozen_networks"] = run("f16x3", "f16x3")
+    res["with_bf16x3_loss_network"] = run("bf16x3")
     res["seconds"] = round(time.perf_counter() - t0, 1)
     return res
 
@@ -689,7 +702,7 @@ def train_main(args):
         raise SystemExit("--mode train is BASELINE config 4: one GPU")
     device = torch.device("cuda:0")
     torch.cuda.set_device(device)
-    res = train_bench(device, steps=args.steps, warmup=args.warmup, roofline=not args.no_extras, loss_dtype=args.loss_dtype, graph=bool(args.train_graph))
+    res = train_bench(device, steps=args.steps, warmup=args.warmup, roofline=not args.no_extras, loss_dtype=args.loss_dtype, graph=bool(args.train_graph), encoder_dtype=args.encoder_dtype)
     res["hip_graphs"] = bool(args.train_graph)
     res.update({"n_gpus": 1, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
                 "config": {"workload": "train_only_inner_loop.py:519-575 step on synthetic 256x256 batches of 8 content + 8 style images: "

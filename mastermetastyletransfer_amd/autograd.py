@@ -892,7 +892,7 @@ class PerceptualLossFn(torch.autograd.Function):
                     ops._count("conv_dgrad", flops=2.0 * Bn * H * W * Cg * 9 * cx_real,
                                bytes=g.element_size() * (Bn * H * W * (Cg + cx_real * (1 + (relu_src is not None) + (add is not None))) + Cg * 9 * cx_real))
                 _check(lib.master_conv3x3_dgrad(_p(g), _p(wf), _p(dx), _p(relu_src), _p(add), Bn, H, W, Cg, Cx, 0,
-                                                ops.F32X3 if ops.is_split(wf) else DT, _stream()), "master_conv3x3_dgrad")
+                                                ops.x3_code(wf) if ops.is_split(wf) else DT, _stream()), "master_conv3x3_dgrad")
                 g = dx
                 if pooled:
                     y = out_of(below)                     # the pool's input = ReLU output of the conv below

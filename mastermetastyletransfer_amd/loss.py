@@ -43,11 +43,15 @@ class VGG19_custom(nn.Module):
             features = nn.Sequential(*layers)
         self.features = features
         self.compute_dtype = torch.float32
-        self.split_weights = False          # fp32 maps, split-bf16 contractions (custom_loss.set_compute_dtype("bf16x3"))
+        self.split_weights = False          # "bf16" / "f16": fp32 maps, split contractions (custom_loss.set_compute_dtype("bf16x3" / "f16x3")); "f16": half halves in the FORWARD convolutions only
         self._packed: Dict[int, tuple] = {}
 
-    def _convert(self, w: Tensor) -> Tensor:
-        return ops.split_weights(w) if self.split_weights else ops.convert(w, self.compute_dtype)
+    def _convert(self, w: Tensor, backward: bool = False) -> Tensor:
+        """weights of a forward convolution / of its data gradient in the mode's form.  The data gradient always takes bf16 halves in the
+        split modes: gradients span fp32's exponent range (1e-9 ... 1), which IEEE-half halves cannot carry"""
+        if self.split_weights:
+            return ops.split_weights(w, fmt="bf16" if backward else self.split_weights)
+        return ops.convert(w, self.compute_dtype)
 
     def _weights(self, i: int):
         conv = self.features[i]
@@ -75,7 +79,7 @@ class VGG19_custom(nn.Module):
                 if w.shape[1] % 32:
                     w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, _CPAD - w.shape[1]))
                 wf = w.flip(2, 3).permute(1, 2, 3, 0).contiguous()
-                hit = (key, self._convert(wf))
+                hit = (key, self._convert(wf, backward=True))
             cache[i] = hit
         return hit[1]
 
@@ -128,23 +132,31 @@ class custom_loss(nn.Module):
             param.requires_grad = False
         self.set_compute_dtype(compute_dtype)
 
-    def set_compute_dtype(self, dtype, split_bf16: bool = False) -> "custom_loss":
-        """torch.float32 (parity mode), torch.bfloat16, or "bf16x3" (= torch.float32 with split_bf16=True): fp32 feature maps, statistics and
-        gradients, the 3x3 convolutions of the frozen network (forward and data gradient) as three bf16 MFMA products of hi/lo operand
-        halves with fp32 accumulation (products good to ~2^-17).  Loss values agree with fp32 to 2e-4 and the PARAMETER gradients of a train
-        step are as close to float64 as the all-fp32 step's (worst tensor 2.1e-3 against 1.9e-3 on BASELINE config 4); the per-pixel image
-        gradient, which this loss makes ill-conditioned, is 0.7-1.7e-2 in relative L2 from float64 where fp32 is 0.5-3.5e-3
-        (tests/test_gpu_x3.py).  conv1_1 keeps its exact fp32 kernel."""
+    def set_compute_dtype(self, dtype, split_bf16: bool = False, split: Optional[str] = None) -> "custom_loss":
+        """torch.float32 (parity mode), torch.bfloat16, or a split mode: fp32 feature maps, statistics and gradients, the 3x3 convolutions of
+        the frozen network (forward and data gradient) as three 16-bit MFMA products of hi/lo operand halves with fp32 accumulation.
+        "bf16x3" (= torch.float32 with split_bf16=True / split="bf16"; r04): bf16 halves everywhere (products good to ~2^-17).  Loss values
+        agree with fp32 to 2e-4 and the PARAMETER gradients of a train step are as close to float64 as the all-fp32 step's (worst tensor
+        2.1e-3 against 1.9e-3 on BASELINE config 4); the per-pixel image gradient, which this loss makes ill-conditioned, is 0.7-1.7e-2 in
+        relative L2 from float64 where fp32 is 0.5-3.5e-3 (tests/test_gpu_x3.py).
+        "f16x3" (split="f16"; r05): IEEE-half halves (2^-22) in the FORWARD convolutions - the pass whose rounding the loss amplifies ~1e4
+        times - and bf16 halves in the data-gradient chain (gradients span fp32's exponent range; their products are not amplified): the
+        per-pixel image gradient comes back to the exact network's distance from float64 at the same speed (tests/test_gpu_f16x3.py).
+        Feature maps must stay inside half's range (|x| <= 65 504).  conv1_1 keeps its exact fp32 kernel in every mode."""
         if isinstance(dtype, str):
-            if dtype != "bf16x3":     # "f16x3" (IEEE-half halves, the model's parity mode) is refused here: gradients of the chain span fp32's exponent range
-                raise ValueError('compute_dtype must be torch.float32, torch.bfloat16 or "bf16x3" (the loss network keeps bf16 halves: its gradients need fp32\'s range)')
-            dtype, split_bf16 = torch.float32, True
+            if dtype not in ("bf16x3", "f16x3"):
+                raise ValueError('compute_dtype must be torch.float32, torch.bfloat16, "bf16x3" or "f16x3"')
+            dtype, split = torch.float32, dtype[:-2]
+        if split is None and split_bf16:
+            split = "bf16"
         if dtype not in (torch.float32, torch.bfloat16):
-            raise ValueError('compute_dtype must be torch.float32, torch.bfloat16 or "bf16x3"')
-        if split_bf16 and dtype != torch.float32:
-            raise ValueError("split_bf16 goes with torch.float32 maps")
+            raise ValueError('compute_dtype must be torch.float32, torch.bfloat16, "bf16x3" or "f16x3"')
+        if split not in (None, "bf16", "f16"):
+            raise ValueError('split must be None, "bf16" or "f16"')
+        if split and dtype != torch.float32:
+            raise ValueError("the split modes go with torch.float32 maps")
         self.feature_extractor_model.compute_dtype = dtype
-        self.feature_extractor_model.split_weights = bool(split_bf16)
+        self.feature_extractor_model.split_weights = split or False
         return self
 
     def forward(self, content_image, style_image, output_image, distance="euclidian", lambda_value=None,

@@ -187,6 +187,25 @@ class MasterStyleTransferModel(nn.Module):
                         m.compute_dtype = torch.float32
         return self
 
+    def set_encoder_compute_dtype(self, dtype) -> "MasterStyleTransferModel":
+        """The FROZEN Swin encoder alone in torch.float32 (exact kernels) or in a split mode ("f16x3" / "bf16x3"), whatever the rest of the
+        model runs in - meant for the train step (r05): the encoder is frozen there by default (train_only_inner_loop.py:254-257) and runs
+        without a graph, so its 15 GFLOP per pair need no backward kernels; with IEEE-half halves its features sit at the exact kernels'
+        distance from the CPU path and every parameter gradient of the step stays inside the bound the all-fp32 step is held to
+        (tests/test_gpu_f16x3.py::test_train_step_with_f16x3_loss_network_and_encoder).  (With bf16 halves they do not: 7.8e-3 of a tensor's
+        max against the 5e-3 bound, r04.)  A later set_compute_dtype() overrides it."""
+        split = None
+        if dtype in ("f16x3", "bf16x3"):
+            dtype, split = torch.float32, dtype[:-2]
+        if dtype != torch.float32:
+            raise ValueError('the encoder-only switch takes torch.float32, "f16x3" or "bf16x3"')
+        for m in self.swin_encoder.modules():
+            if isinstance(m, (_HipModule, SwinEncoder)):
+                m.compute_dtype = torch.float32
+                m.split_weights = split or False
+        self.swin_encoder.stage1_dtype = torch.float32
+        return self
+
     def forward(self, content_image: Tensor, style_image: Tensor, transformer_layer_count: int = 1) -> Tensor:
         if content_image.shape != style_image.shape:
             raise ValueError("content and style batches must have the same shape")
