@@ -16,7 +16,11 @@ are printed by the asm statement itself, so the list is what the register alloca
 `vmcnt(0)` / `lgkmcnt(0)` (retires every load of that queue).  Waits without a list and with a non-zero count retire nothing here
 (conservative).  A load whose destination is still in flight when the kernel ends, or that is never retired by name, is reported too.
 
+Kernels whose counted waits do not name registers (the bf16-mode kernels) are covered by a second analysis that simulates the two memory
+queues instead (`--counting`, audit_function_counting below).
+
     python profiles/tools/isa_audit.py mastermetastyletransfer_amd/csrc/gemm_x3.hip [more.hip ...]      (uses build.py's flags per file)
+    python profiles/tools/isa_audit.py --counting mastermetastyletransfer_amd/csrc/mlp_bf16.hip ...
 """
 from __future__ import annotations
 
@@ -179,6 +183,133 @@ def audit_function(items: List[object]) -> Tuple[List[str], int, int]:
     return violations, n_loads, n_named
 
 
+VM_RE = re.compile(r"^(global_|buffer_|flat_|scratch_)")
+LGKM_RE = re.compile(r"^(ds_|s_load_|s_buffer_load|s_memtime|s_memrealtime|s_sendmsg|s_dcache)")
+
+
+def _blocks_of(items: List[object]):
+    """basic blocks and successor lists of a kernel listing (shared by both analyses)"""
+    blocks: List[List[Instr]] = [[]]
+    label_block: Dict[str, int] = {}
+    for it in items:
+        if isinstance(it, tuple):
+            if blocks[-1]:
+                blocks.append([])
+            label_block[it[1]] = len(blocks) - 1
+        else:
+            blocks[-1].append(it)
+            if BRANCH_RE.match(it.text) or it.text.startswith(("s_endpgm", "s_setpc")):
+                blocks.append([])
+    succ: List[List[int]] = []
+    for i, b in enumerate(blocks):
+        s_ = []
+        last = b[-1] if b else None
+        m = BRANCH_RE.match(last.text) if last else None
+        if m:
+            if m.group(2) in label_block:
+                s_.append(label_block[m.group(2)])
+            if m.group(1) != "s_branch" and i + 1 < len(blocks):
+                s_.append(i + 1)
+        elif not (last and last.text.startswith(("s_endpgm", "s_setpc"))) and i + 1 < len(blocks):
+            s_.append(i + 1)
+        succ.append(s_)
+    return blocks, succ
+
+
+def audit_function_counting(items: List[object]) -> Tuple[List[str], int]:
+    """The same question for kernels whose counted waits do NOT name registers (the bf16-mode kernels: mlp_bf16, mlp_c128_bf16,
+    linear_ts_bf16, conv_ring_bf16, attn_block_bf16, window_attn_proj_bf16): the two memory queues are simulated instead.  Every
+    vector-memory operation (asm or compiler-issued; loads, stores, LDS-DMA) enters the vm queue, every LDS / scalar-memory operation the
+    lgkm queue, in program order; `s_waitcnt vmcnt(N)` / `lgkmcnt(N)` retires all but the N youngest (operations of one queue complete
+    in order on this ISA; scalar loads may not, which only matters if one is issued next to asm reads in flight: reported).  The
+    destination of an ASM load is in flight until it is retired; any instruction that touches it before is a violation.
+    A queue state is the sequence of operations from the oldest asm load still in flight to the youngest operation (older ones cannot
+    change which asm loads a count retires).  States flow over the kernel's basic blocks to a fixed point; where two paths meet with
+    DIFFERENT states - a branch around a memory operation while asm loads are in flight - the join is reported as not analysable
+    instead of being guessed at.  -> (violations, asm loads seen)"""
+    blocks, succ = _blocks_of(items)
+
+    def norm(q):
+        for i, e in enumerate(q):
+            if e:
+                return tuple(q[i:])
+        return ()
+
+    n_loads = 0
+
+    def transfer(state, b: List[Instr], viol):
+        nonlocal n_loads
+        vmq, lgq = list(state[0]), list(state[1])
+        for ins in b:
+            t = ins.text
+            if t.startswith("s_waitcnt"):
+                m = re.search(r"vmcnt\((\d+)\)", t)
+                if m:
+                    del vmq[: max(0, len(vmq) - int(m.group(1)))]
+                m = re.search(r"lgkmcnt\((\d+)\)", t)
+                if m:
+                    del lgq[: max(0, len(lgq) - int(m.group(1)))]
+                continue
+            fl = set().union(*vmq, *lgq) if (vmq or lgq) else set()
+            m = LOAD_RE.match(t) if ins.in_asm else None
+            if m:
+                bad = regs_of(t[m.end():]) & fl
+                if bad and viol is not None:
+                    viol.append(f"line {ins.line}: `{t}` reads " + " ".join(f"{k}{i}" for k, i in sorted(bad)) + " while an asm load into it is in flight")
+                (lgq if m.group(1).startswith("ds_") else vmq).append(frozenset(regs_of(m.group(2))))
+                if viol is not None:
+                    n_loads += 1
+                continue
+            if fl:
+                bad = regs_of(t) & fl
+                if bad and viol is not None:
+                    viol.append(f"line {ins.line}: `{t}` touches " + " ".join(f"{k}{i}" for k, i in sorted(bad)) + " while an asm load into it is in flight")
+                if viol is not None and t.startswith(("s_load_", "s_buffer_load", "s_memtime", "s_memrealtime")) and any(lgq):
+                    viol.append(f"line {ins.line}: `{t}` (scalar memory, may complete out of order) issued while asm LDS reads are in flight")
+            if VM_RE.match(t):
+                vmq.append(frozenset())
+            elif LGKM_RE.match(t):
+                lgq.append(frozenset())
+        return (norm(vmq), norm(lgq))
+
+    viol: List[str] = []
+    inn: List[object] = [None] * len(blocks)
+    inn[0] = ((), ())
+    work = [0]
+    joins_reported = set()
+    guard = 0
+    while work and guard < 100000:
+        guard += 1
+        i = work.pop(0)
+        out = transfer(inn[i], blocks[i], None)
+        for j in succ[i]:
+            if inn[j] is None:
+                inn[j] = out
+                work.append(j)
+            elif inn[j] != out:
+                if j not in joins_reported:
+                    joins_reported.add(j)
+                    first = blocks[j][0].line if blocks[j] else -1
+                    viol.append(f"line {first}: paths meet with different asm loads in flight / different queue contents behind them (not analysable)")
+    for i, b in enumerate(blocks):
+        if inn[i] is not None:
+            out = transfer(inn[i], b, viol)
+            if b and b[-1].text.startswith("s_endpgm") and (out[0] or out[1]):
+                viol.append(f"line {b[-1].line}: kernel ends with asm loads in flight")
+    return viol, n_loads
+
+
+def audit_source_counting(src: str, extra: List[str] = ()) -> Tuple[Dict[str, List[str]], int]:
+    funcs = parse_functions(compile_to_asm(src, extra))
+    res, loads = {}, 0
+    for name, items in funcs.items():
+        v, nl = audit_function_counting(items)
+        loads += nl
+        if v:
+            res[name] = v
+    return res, loads
+
+
 def build_flags(src: str) -> List[str]:
     sys.path.insert(0, ROOT)
     from mastermetastyletransfer_amd import build as B
@@ -211,8 +342,13 @@ def audit_source(src: str, extra: List[str] = ()) -> Tuple[Dict[str, List[str]],
 
 def main():
     rc = 0
-    for src in sys.argv[1:]:
-        res, loads, named = audit_source(src)
+    counting = "--counting" in sys.argv
+    for src in [a for a in sys.argv[1:] if not a.startswith("--")]:
+        if counting:
+            res, loads = audit_source_counting(src)
+            named = 0
+        else:
+            res, loads, named = audit_source(src)
         print(f"{os.path.basename(src)}: {loads} asm register loads, {named} naming waits, {sum(len(v) for v in res.values())} violations")
         for name, v in res.items():
             rc = 1
