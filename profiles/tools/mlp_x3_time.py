@@ -5,7 +5,7 @@ from mastermetastyletransfer_amd import ops
 dev = torch.device("cuda:0")
 for M, C, ln in [(32768, 256, 1), (32768, 256, 0), (65536, 256, 1), (262144, 128, 1)]:
     x = torch.randn(M, C, device=dev)
-    w1 = ops.split_weights(torch.randn(4 * C, C, device=dev) / C ** 0.5); w2 = ops.split_weights(torch.randn(C, 4 * C, device=dev) / (4 * C) ** 0.5, layout=1)
+    FM = os.environ.get("X3_FMT", "f16"); w1 = ops.split_weights(torch.randn(4 * C, C, device=dev) / C ** 0.5, fmt=FM); w2 = ops.split_weights(torch.randn(C, 4 * C, device=dev) / (4 * C) ** 0.5, layout=1, fmt=FM)
     b1 = torch.randn(4 * C, device=dev) * 0.1; b2 = torch.randn(C, device=dev) * 0.1
     lg = torch.ones(C, device=dev) if ln else None; lb = torch.zeros(C, device=dev) if ln else None
     f = lambda: ops.mlp(x, w1, b1, w2, b2, res=x, ln_gamma=lg, ln_beta=lb)
