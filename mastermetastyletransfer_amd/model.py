@@ -215,6 +215,8 @@ class MasterStyleTransferModel(nn.Module):
         # the two encoder passes of full_model.py:219-220 are independent -> one batch of 2B images
         x, _, h, w = self.swin_encoder.run(content_image, style_image)
         self._check_widths(x.shape[1])
+        if x.dtype != self.compute_dtype:            # set_encoder_compute_dtype() left the encoder in fp32 storage next to a bf16 model
+            x = ops.convert(x, self.compute_dtype)
         fc, fs = x[: B * h * w], x[B * h * w:]
         fcs = self.style_transformer.run(fc, fs, transformer_layer_count, B, h, w)
         # the reference permutes NHWC->NCHW here (:222); the decoder kernels read NHWC directly and the

@@ -407,3 +407,19 @@ def test_train_step_with_f16x3_loss_network_and_encoder(cuda):
         assert errs[-1][0] <= 5e-3, errs[-3:]
     with pytest.raises(ValueError):
         m.set_encoder_compute_dtype(torch.bfloat16)
+
+
+def test_encoder_only_switch_in_eval_mode(cuda):
+    """set_encoder_compute_dtype() next to any model mode: the encoder's fp32 tokens are converted where the rest of the model is bf16;
+    a later set_compute_dtype() overrides the encoder switch"""
+    m, (swin_sd, st_sd, dec_sd) = full_model(cuda, torch.float32)
+    c = seeded_input("c64", (1, 3, 64, 64), 8, kind="image").to(cuda)
+    s = seeded_input("s64", (1, 3, 64, 64), 9, kind="image").to(cuda)
+    with torch.no_grad():
+        y32 = m(c, s, 1)
+        yenc = m.set_encoder_compute_dtype("f16x3")(c, s, 1)                      # fp32 model, split encoder
+        assert float((yenc - y32).abs().max()) <= F16_IMAGE_TOL and not torch.equal(yenc, y32)
+        ybf = m.set_compute_dtype(torch.bfloat16)(c, s, 1).float()
+        ymix = m.set_encoder_compute_dtype("f16x3")(c, s, 1).float()              # bf16 model, split encoder
+        assert torch.isfinite(ymix).all() and float((ymix - ybf).norm() / ybf.norm()) < 3e-2
+        assert torch.equal(m.set_compute_dtype(torch.float32)(c, s, 1), y32)       # back: the encoder follows the model again
