@@ -1,16 +1,14 @@
 #!/bin/bash
-# per-kernel register / LDS / occupancy summary of one source file, with build.py's flags for it
-# usage: profiles/tools/kernel_regs.sh mastermetastyletransfer_amd/csrc/mlp_x3.hip [extra hipcc flags]
+# per-kernel register / spill / occupancy summary of one source file, compiled with build.py's flags for it (run from the repo root)
+# usage: profiles/tools/kernel_regs.sh mastermetastyletransfer_amd/csrc/mlp_x3.hip [extra hipcc flags] | c++filt
 src=$1; shift
-flags=$(python3 - "$src" <<'PY'
+flags=$(python3 -c "
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(sys.argv[0])))) if False else os.getcwd())
+sys.path.insert(0, os.getcwd())
 from mastermetastyletransfer_amd import build as B
-print(" ".join(f for f in [*B.FLAGS, *B.EXTRA_FLAGS.get(os.path.basename(sys.argv[1]), [])] if f != "-fPIC"))
-PY
-)
+print(' '.join(f for f in [*B.FLAGS, *B.EXTRA_FLAGS.get(os.path.basename('$src'), [])] if f != '-fPIC'))")
 /opt/rocm/bin/hipcc $flags "$@" -c --offload-device-only -Rpass-analysis=kernel-resource-usage "$src" -o /dev/null 2>&1 | \
-  awk '/Function Name:/ {name=$NF} /remark:.* Name:/ {n=$0; sub(/.*Name: /,"",n); sub(/ \[.*/,"",n); name=n}
+  awk '/remark:.* Name:/ {n=$0; sub(/.*Name: /,"",n); sub(/ \[.*/,"",n); name=n}
        / VGPRs:/ {v=$0; sub(/.* VGPRs: /,"",v); sub(/ .*/,"",v)} / AGPRs:/ {a=$0; sub(/.* AGPRs: /,"",a); sub(/ .*/,"",a)}
        /VGPRs Spill:/ {s=$0; sub(/.*Spill: /,"",s); sub(/ .*/,"",s)} /Occupancy/ {o=$0; sub(/.*SIMD\]: /,"",o); sub(/ .*/,"",o)}
-       /LDS Size/ {l=$0; sub(/.*block\]: /,"",l); sub(/ .*/,"",l); printf "%-100s vgpr %4s agpr %4s spill %3s occ %s lds %s\n", name, v, a, s, o, l}'
+       /LDS Size/ {printf "%-100s vgpr %4s agpr %4s spill %3s occ %s\n", name, v, a, s, o}'
