@@ -249,6 +249,13 @@ def split_weights(w: torch.Tensor, layout: int = 0, fmt="bf16") -> torch.Tensor:
     if K % 32:
         raise MasterHipError(f"split_weights: K = {K} is not a multiple of 32")
     dt = split_torch_dtype(fmt)
+    if dt == torch.float16 and not torch.cuda.is_current_stream_capturing():
+        # weights are split once per parameter version (derived-weight cache), outside any graph capture: the one place where a range
+        # check costs nothing.  A weight beyond half's range would become inf in every product it takes part in.
+        wmax = float(w.abs().max()) if w.numel() else 0.0
+        if not wmax <= 65504.0:
+            raise MasterHipError(f"split_weights(fmt='f16'): max |w| = {wmax:g} is outside IEEE half's range (65 504); use the bf16 halves "
+                                 "(\"bf16x3\") for this tensor")
     out = torch.empty((rows, K // 32, 2, 32), dtype=dt, device=w.device)
     _check(load_library().master_split_weights(_p(w), _p(out), rows, K, layout | (SPLIT_F16 if dt == torch.float16 else 0), _stream()),
            "master_split_weights")

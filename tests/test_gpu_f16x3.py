@@ -423,3 +423,27 @@ def test_encoder_only_switch_in_eval_mode(cuda):
         ymix = m.set_encoder_compute_dtype("f16x3")(c, s, 1).float()              # bf16 model, split encoder
         assert torch.isfinite(ymix).all() and float((ymix - ybf).norm() / ybf.norm()) < 3e-2
         assert torch.equal(m.set_compute_dtype(torch.float32)(c, s, 1), y32)       # back: the encoder follows the model again
+
+
+def test_half_halves_overflow_is_loud_and_bf16_halves_cover_the_range(cuda):
+    """the documented trade-off: an operand beyond half's range (|x| > 65 504) makes the f16x3 product inf / NaN - never a silently wrong
+    finite number - while the bf16 halves, which keep fp32's exponent, stay accurate; tiny operands (1e-6) underflow the half split's low
+    half gracefully (error bounded by the subnormal floor), the bf16 split keeps its relative accuracy"""
+    from mastermetastyletransfer_amd import ops
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 256, 128, 128
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / 11
+    big = a * 1e5                                                        # |x| up to ~4e5
+    ref = F.linear(big.double(), w.double())
+    out_h = ops.linear(big.to(cuda), sw(w.to(cuda)), None).cpu()
+    out_b = ops.linear(big.to(cuda), ops.split_weights(w.to(cuda)), None)
+    assert not torch.isfinite(out_h).all()
+    assert rel_err(out_b, ref) < 3e-5
+    tiny = a * 1e-6
+    ref_t = F.linear(tiny.double(), w.double())
+    e_h = rel_err(ops.linear(tiny.to(cuda), sw(w.to(cuda)), None), ref_t)
+    e_b = rel_err(ops.linear(tiny.to(cuda), ops.split_weights(w.to(cuda)), None), ref_t)
+    assert e_b < 3e-5 and e_h < 2e-2 and e_h > e_b                       # half: hi alone (11 bits, partly subnormal) is what is left of a 1e-6 operand
+    from mastermetastyletransfer_amd.ops import MasterHipError
+    with pytest.raises(MasterHipError, match="outside IEEE half"):       # static operands are range-checked where they are split
+        sw((w * 1e7).to(cuda))
