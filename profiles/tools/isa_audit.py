@@ -90,9 +90,8 @@ def parse_functions(asm_text: str) -> Dict[str, List[object]]:
     return {k: v for k, v in funcs.items() if any(isinstance(x, Instr) for x in v)}
 
 
-def audit_function(items: List[object]) -> Tuple[List[str], int, int]:
-    """-> (violations, asm loads seen, named retirements seen)"""
-    # basic blocks
+def _blocks_of(items: List[object]):
+    """basic blocks and successor lists of a kernel listing (shared by both analyses)"""
     blocks: List[List[Instr]] = [[]]
     label_block: Dict[str, int] = {}
     for it in items:
@@ -106,17 +105,23 @@ def audit_function(items: List[object]) -> Tuple[List[str], int, int]:
                 blocks.append([])
     succ: List[List[int]] = []
     for i, b in enumerate(blocks):
-        s = []
+        s_ = []
         last = b[-1] if b else None
         m = BRANCH_RE.match(last.text) if last else None
         if m:
             if m.group(2) in label_block:
-                s.append(label_block[m.group(2)])
+                s_.append(label_block[m.group(2)])
             if m.group(1) != "s_branch" and i + 1 < len(blocks):
-                s.append(i + 1)
+                s_.append(i + 1)
         elif not (last and last.text.startswith(("s_endpgm", "s_setpc"))) and i + 1 < len(blocks):
-            s.append(i + 1)
-        succ.append(s)
+            s_.append(i + 1)
+        succ.append(s_)
+    return blocks, succ
+
+
+def audit_function(items: List[object]) -> Tuple[List[str], int, int]:
+    """-> (violations, asm loads seen, named retirements seen)"""
+    blocks, succ = _blocks_of(items)
 
     n_loads = n_named = 0
 
@@ -185,35 +190,6 @@ def audit_function(items: List[object]) -> Tuple[List[str], int, int]:
 
 VM_RE = re.compile(r"^(global_|buffer_|flat_|scratch_)")
 LGKM_RE = re.compile(r"^(ds_|s_load_|s_buffer_load|s_memtime|s_memrealtime|s_sendmsg|s_dcache)")
-
-
-def _blocks_of(items: List[object]):
-    """basic blocks and successor lists of a kernel listing (shared by both analyses)"""
-    blocks: List[List[Instr]] = [[]]
-    label_block: Dict[str, int] = {}
-    for it in items:
-        if isinstance(it, tuple):
-            if blocks[-1]:
-                blocks.append([])
-            label_block[it[1]] = len(blocks) - 1
-        else:
-            blocks[-1].append(it)
-            if BRANCH_RE.match(it.text) or it.text.startswith(("s_endpgm", "s_setpc")):
-                blocks.append([])
-    succ: List[List[int]] = []
-    for i, b in enumerate(blocks):
-        s_ = []
-        last = b[-1] if b else None
-        m = BRANCH_RE.match(last.text) if last else None
-        if m:
-            if m.group(2) in label_block:
-                s_.append(label_block[m.group(2)])
-            if m.group(1) != "s_branch" and i + 1 < len(blocks):
-                s_.append(i + 1)
-        elif not (last and last.text.startswith(("s_endpgm", "s_setpc"))) and i + 1 < len(blocks):
-            s_.append(i + 1)
-        succ.append(s_)
-    return blocks, succ
 
 
 def audit_function_counting(items: List[object]) -> Tuple[List[str], int]:
