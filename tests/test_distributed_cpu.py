@@ -130,6 +130,26 @@ def test_world_size_2_gloo(batch):
     assert all(ok and shape == (batch, 3, 8, 8) for _, ok, shape in res)
 
 
+@pytest.mark.parametrize("batch", [32, 13])
+def test_world_size_8_gloo(batch):
+    """the node size the driver's scaling run uses (8 ranks): sharding, the asynchronous gather with two steps in flight and the in-place
+    two-buffer form, even (32 = 4 per rank) and ragged (13) batches - eight CPU processes over gloo"""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, batch, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(8))
+    assert all(ok and shape == (batch, 3, 8, 8) for _, ok, shape in res)
+
+
 def test_world_size_1_is_identity():
     x = torch.randn(3, 3, 4, 4)
     assert all_gather_images(x, 3, 0, 1) is x
