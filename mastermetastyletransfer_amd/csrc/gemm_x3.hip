@@ -188,8 +188,13 @@ __device__ __forceinline__ void x3_epilogue(const X3Args& p, f32x16 (&acc)[WM / 
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV, int FMT>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3_kernel(X3Args p) {
+// NSTAGE = 3 (default): the ring described above.  NSTAGE = 2 (r05 experiment, MASTER_X3_TILE=7: 128 x 128 tile, four waves, 64 KB of LDS ->
+// TWO workgroups per CU, whose prologues / epilogues / step waits interleave): the weight pieces of chunk kt + 1 go out behind the
+// barrier of step kt into the slot that step kt - 1 read (every wave has left it: it passed the barrier) - one step of look-ahead
+// instead of two; queue per step [W(kt + 1)] [A(kt + 2)], so the step-head wait leaves the 2 APASS loads of A(kt + 1) in flight and the
+// register wait the PER operations of this step.  A is staged through registers two chunks ahead in both forms.
+template <int BM, int BN, int WM, int WN, bool CONV, int FMT, int NSTAGE = 3>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, NSTAGE == 2 ? 2 : 1) void gemm_x3_kernel(X3Args p) {
     constexpr int NWN = BN / WN;
     constexpr int NWAVES = (BM / WM) * NWN;
     constexpr int NT = NWAVES * 64;
@@ -199,7 +204,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3_kernel(X3A
     constexpr int WPIECES = BN / 8;                                       // 1-KB LDS-DMA pieces of the weight tile per chunk
     constexpr int WPW = (WPIECES + NWAVES - 1) / NWAVES;
     constexpr int PER = 2 * APASS + WPW;                                  // vector-memory operations a (DMA-issuing) wave starts per chunk
-    constexpr int NSTAGE = 3;
+    static_assert(NSTAGE == 2 || NSTAGE == 3, "two or three ring slots");
     constexpr int STAGE = (BM + BN) * 128;                                // bytes per ring slot: A rows (hi | lo), then W rows
     static_assert(BM % RP == 0 && APASS >= 1, "A rows must divide over the threads");
     static_assert(WPIECES % WPW == 0, "weight pieces must divide over the issuing waves");
@@ -349,7 +354,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3_kernel(X3A
     // nothing that reads them can be scheduled above the wait (ONE such statement per use: two alternatives behind a branch make
     // hipcc copy the still-loading registers in front of the wait)
     auto wait_regs = [&](f32x4 (&ra)[APASS][2]) __attribute__((always_inline)) {
-        constexpr int WCNT = PER + WPW;
+        constexpr int WCNT = NSTAGE == 3 ? PER + WPW : PER;               // operations issued behind the loads being retired
         // the registers are printed behind the instruction ("; landed v[..] .."): profiles/tools/isa_audit.py reads them from the generated
         // code and checks that no compiler copy / spill touches a register between the asm load that targets it and this wait
         if constexpr (APASS == 1) asm volatile("s_waitcnt vmcnt(%2) ; landed %0 %1" : "+v"(ra[0][0]), "+v"(ra[0][1]) : "n"(WCNT) : "memory");
@@ -360,7 +365,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3_kernel(X3A
     // queue order: [A(0)] [W(0)] [A(1)] [W(1)] | step kt: [A(kt+2)] [W(kt+2)] - 2 APASS loads and WPW pieces per chunk
     f32x4 ra0[APASS][2], ra1[APASS][2];
     load_a(0, ra0); issue_w(0, 0);
-    load_a(1, ra1); issue_w(1, 1);
+    load_a(1, ra1); if constexpr (NSTAGE == 3) issue_w(1, 1);
     wait_regs(ra0);                                                        // A(0): W(0) and the group of chunk 1 stay in flight
     store_a(0, ra0);
 
@@ -371,12 +376,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3_kernel(X3A
 #endif
     auto body = [&](int kt, f32x4 (&nxt)[APASS][2], f32x4 (&fre)[APASS][2]) __attribute__((always_inline)) {
         XPROBE_MARK();
-        wait_vmcnt<PER>();                                                 // W(kt) has landed: only the group of chunk kt + 1 is still in flight
+        wait_vmcnt<NSTAGE == 3 ? PER : 2 * APASS>();                       // W(kt) has landed: only the group of chunk kt + 1 (two slots: the loads of A(kt + 1)) is still in flight
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // this wave's A(kt) stores
         XPROBE_ADD(0);
         __builtin_amdgcn_s_barrier();
         XPROBE_ADD(1);
-        load_a(kt + 2, fre); issue_w(kt + 2, s_nn);
+        if constexpr (NSTAGE == 3) { load_a(kt + 2, fre); issue_w(kt + 2, s_nn); }
+        else { issue_w(kt + 1, s_nxt); load_a(kt + 2, fre); }
         XPROBE_ADD(2);
         compute(s_cur);
         XPROBE_ADD(3);
@@ -385,7 +391,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3_kernel(X3A
         store_a(s_nxt, nxt);
         XPROBE_ADD(5);
         asm volatile("" ::: "memory");
-        const int t = s_cur; s_cur = s_nxt; s_nxt = s_nn; s_nn = t;
+        if constexpr (NSTAGE == 3) { const int t = s_cur; s_cur = s_nxt; s_nxt = s_nn; s_nn = t; }
+        else { const int t = s_cur; s_cur = s_nxt; s_nxt = t; }
     };
     for (int kt = 0; kt < nk; kt += 2) {
         body(kt, ra1, ra0);
@@ -608,19 +615,20 @@ int launch_s(const X3Args& p, hipStream_t s) {
     return master_check_launch("gemm_x3s");
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV, int FMT>
+template <int BM, int BN, int WM, int WN, bool CONV, int FMT, int NSTAGE = 3>
 int launch(const X3Args& p, hipStream_t s) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     const int MT = (p.M + BM - 1) / BM, NTN = (p.N + BN - 1) / BN;
     const int grid = ((MT + 7) / 8) * 8 * NTN;
-    const size_t lds = (size_t)3 * (BM + BN) * 128;
+    const size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
     static LdsLimit lds_limit;
-    lds_limit.ensure((const void*)gemm_x3_kernel<BM, BN, WM, WN, CONV, FMT>, (int)lds);
-    hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, WM, WN, CONV, FMT>), dim3(grid), dim3(NT), lds, s, p);
+    lds_limit.ensure((const void*)gemm_x3_kernel<BM, BN, WM, WN, CONV, FMT, NSTAGE>, (int)lds);
+    hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, WM, WN, CONV, FMT, NSTAGE>), dim3(grid), dim3(NT), lds, s, p);
     return master_check_launch("gemm_x3");
 }
 
-// MASTER_X3_TILE: 0 = by shape (default), 1 = 128x128 / 4 waves, 2 = 128x128 / 8 waves, 3 = 256x128 / 8 waves (A/B runs)
+// MASTER_X3_TILE: 0 = by shape (default), 1 = 128x128 / 4 waves, 2 = 128x128 / 8 waves, 3 = 256x128 / 8 waves, 5 / 6 = 128x64 with 4 / 8 waves,
+// 7 = 128x128 / 4 waves on the two-slot ring, 8 = the by-shape choice of r04 (no two-slot form)  (A/B runs)
 static int x3_tile() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("MASTER_X3_TILE"); v = e ? atoi(e) : 0; }
@@ -636,12 +644,18 @@ int dispatch(const X3Args& p, hipStream_t s) {
         if (force == 3) return launch<256, 128, 64, 64, CONV, FMT>(p, s);
         if (force == 5) return launch<128, 64, 64, 32, CONV, FMT>(p, s);        // 72 KB of LDS, four waves: two workgroups per CU
         if (force == 6) return launch<128, 64, 32, 32, CONV, FMT>(p, s);        // eight waves
+        if (force == 7) return launch<128, 128, 64, 64, CONV, FMT, 2>(p, s);    // r05: two-slot ring, 64 KB, four waves: two workgroups per CU
         // one N tile of 128 with a short K (the stage-1 projection, 262 144 x 128 x 128 + residual): 128 x 64 tiles, eight waves, two
         // workgroups per CU - one tile's epilogue runs under the other's loop (117.6 -> 100.3 us; with more N tiles the re-split of A
         // per N tile costs more than the overlap gives: profiles/r04 A/B of MASTER_X3_TILE=5/6)
-        if (!CONV && force == 0 && p.N <= 128 && p.K <= 128 && p.M >= 65536) return launch<128, 64, 32, 32, CONV, FMT>(p, s);
+        if (!CONV && (force == 0 || force == 8) && p.N <= 128 && p.K <= 128 && p.M >= 65536) return launch<128, 64, 32, 32, CONV, FMT>(p, s);
         // fewer than two 256-row tiles per CU: 128-row tiles (eight waves: two per SIMD) fill the chip better
         const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 127) / 128);
+        // every other Linear layer: the two-slot ring, two workgroups per CU.  Same-box kernel traces of the bs = 32 forward (r05,
+        // profiles/r05_x3_ring2_ab.txt), three-slot form by shape -> this one: 32 768 x 256 x 256 (9 launches) 31.8 -> 28.3 us, 65 536 x 256 x K
+        // 62.5 -> 58.8, 65 536 x 768 x 256 120 -> 114.5, 262 144 x 384 x 128 171 -> 168; the convolutions (+8 %) and the stage-1 projection
+        // above (+10 %) lose with it and keep the three-slot forms
+        if (!CONV && force == 0) return launch<128, 128, 64, 64, CONV, FMT, 2>(p, s);
         if (t256 < 512) return launch<128, 128, 32, 64, CONV, FMT>(p, s);
         return launch<256, 128, 64, 64, CONV, FMT>(p, s);
     }
