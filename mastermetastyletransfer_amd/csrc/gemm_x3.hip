@@ -422,14 +422,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, NSTAGE == 2 ? 2 : 1) vo
 // Ring, k order, waits and epilogue as above; per chunk a wave issues BM / 8 / NWAVES pieces of A (8 rows x 128 B, per-lane row
 // pointers: the convolution gather moves them when the tap changes) and BN / 8 / NWAVES of W.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool CONV, int FMT>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3s_kernel(X3Args p) {
+// NSTAGE = 2 (r05): two ring slots, the pieces of chunk kt + 1 dealt between the MFMA groups of step kt into the slot step kt - 1 read, all of
+// them landed (vmcnt(0)) at the head of step kt + 1: half the look-ahead, but a 128 x 128 tile then takes 64 KB and two workgroups share a CU.
+template <int BM, int BN, int WM, int WN, bool CONV, int FMT, int NSTAGE = 3>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, NSTAGE == 2 ? 2 : 1) void gemm_x3s_kernel(X3Args p) {
     constexpr int NWN = BN / WN;
     constexpr int NWAVES = (BM / WM) * NWN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int APW = BM / 8 / NWAVES, WPW = BN / 8 / NWAVES;          // 1-KB pieces per wave and chunk
     constexpr int PER = APW + WPW;
-    constexpr int NSTAGE = 3;
+    static_assert(NSTAGE == 2 || NSTAGE == 3, "two or three ring slots");
     constexpr int STAGE = (BM + BN) * 128;
     static_assert((BM / 8) % NWAVES == 0 && (BN / 8) % NWAVES == 0 && WPW >= 1, "pieces must divide over the waves");
 
@@ -542,7 +544,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3s_kernel(X3
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.0f;
 
     const int fsw = (r >> 1) & 7;
-    issue(0, 0); issue(1, 1);
+    issue(0, 0); if constexpr (NSTAGE == 3) issue(1, 1);
     int s_cur = 0, s_nxt = 1, s_nn = 2;
     constexpr int NG = 2 * TM * TN;                                        // MFMA groups (3 MFMAs on one accumulator tile) per chunk
 #ifdef X3_CLOCK_PROBE
@@ -551,11 +553,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3s_kernel(X3
 #endif
     for (int kt = 0; kt < nk; ++kt) {
         XPROBE_MARK();
-        wait_vmcnt<PER>();                                                 // chunk kt has landed (this wave's pieces): only chunk kt + 1's are in flight
+        wait_vmcnt<NSTAGE == 3 ? PER : 0>();                               // chunk kt has landed (this wave's pieces): only chunk kt + 1's are in flight (two slots: nothing is)
         XPROBE_ADD(0);
         __builtin_amdgcn_s_barrier();
         XPROBE_ADD(1);
-        begin_issue(kt + 2, s_nn);
+        if constexpr (NSTAGE == 3) begin_issue(kt + 2, s_nn); else begin_issue(kt + 1, s_nxt);
         const unsigned char* ab = ring + s_cur * STAGE + (wm + r) * 128;
         const unsigned char* wb = ring + s_cur * STAGE + BM * 128 + (wn + r) * 128;
         int g = 0, q = 0;                                                  // compile-time after unrolling
@@ -590,7 +592,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3s_kernel(X3
         end_issue();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // this wave's fragment reads of slot s_cur are done before it passes the next barrier
         XPROBE_ADD(3);
-        const int t = s_cur; s_cur = s_nxt; s_nxt = s_nn; s_nn = t;
+        if constexpr (NSTAGE == 3) { const int t = s_cur; s_cur = s_nxt; s_nxt = s_nn; s_nn = t; }
+        else { const int t = s_cur; s_cur = s_nxt; s_nxt = t; }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");            // the two look-ahead groups past the end: the ring is reused below
 #ifdef X3_CLOCK_PROBE
@@ -603,15 +606,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_x3s_kernel(X3
     x3_epilogue<BM, BN, WM, WN, CONV, NSTAGE * STAGE, FMT>(p, acc, ring, m0, n0, wm, wn);
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV, int FMT>
+template <int BM, int BN, int WM, int WN, bool CONV, int FMT, int NSTAGE = 3>
 int launch_s(const X3Args& p, hipStream_t s) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     const int MT = (p.M + BM - 1) / BM, NTN = (p.N + BN - 1) / BN;
     const int grid = ((MT + 7) / 8) * 8 * NTN;
-    const size_t lds = (size_t)3 * (BM + BN) * 128;
+    const size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
     static LdsLimit lds_limit;
-    lds_limit.ensure((const void*)gemm_x3s_kernel<BM, BN, WM, WN, CONV, FMT>, (int)lds);
-    hipLaunchKernelGGL((gemm_x3s_kernel<BM, BN, WM, WN, CONV, FMT>), dim3(grid), dim3(NT), lds, s, p);
+    lds_limit.ensure((const void*)gemm_x3s_kernel<BM, BN, WM, WN, CONV, FMT, NSTAGE>, (int)lds);
+    hipLaunchKernelGGL((gemm_x3s_kernel<BM, BN, WM, WN, CONV, FMT, NSTAGE>), dim3(grid), dim3(NT), lds, s, p);
     return master_check_launch("gemm_x3s");
 }
 
@@ -628,7 +631,8 @@ int launch(const X3Args& p, hipStream_t s) {
 }
 
 // MASTER_X3_TILE: 0 = by shape (default), 1 = 128x128 / 4 waves, 2 = 128x128 / 8 waves, 3 = 256x128 / 8 waves, 5 / 6 = 128x64 with 4 / 8 waves,
-// 7 = 128x128 / 4 waves on the two-slot ring, 8 = the by-shape choice of r04 (no two-slot form)  (A/B runs)
+// 7 = 128x128 / 4 waves on the two-slot ring, 8 = the by-shape choice of r04 (no two-slot form), 9 = the shipped choice + two-slot forms of the
+// split-input kernel (measured: no gain, profiles/r05_x3_ring2_ab.txt section 5)  (A/B runs)
 static int x3_tile() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("MASTER_X3_TILE"); v = e ? atoi(e) : 0; }
@@ -648,14 +652,14 @@ int dispatch(const X3Args& p, hipStream_t s) {
         // one N tile of 128 with a short K (the stage-1 projection, 262 144 x 128 x 128 + residual): 128 x 64 tiles, eight waves, two
         // workgroups per CU - one tile's epilogue runs under the other's loop (117.6 -> 100.3 us; with more N tiles the re-split of A
         // per N tile costs more than the overlap gives: profiles/r04 A/B of MASTER_X3_TILE=5/6)
-        if (!CONV && (force == 0 || force == 8) && p.N <= 128 && p.K <= 128 && p.M >= 65536) return launch<128, 64, 32, 32, CONV, FMT>(p, s);
+        if (!CONV && (force == 0 || force >= 8) && p.N <= 128 && p.K <= 128 && p.M >= 65536) return launch<128, 64, 32, 32, CONV, FMT>(p, s);
         // fewer than two 256-row tiles per CU: 128-row tiles (eight waves: two per SIMD) fill the chip better
         const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 127) / 128);
         // every other Linear layer: the two-slot ring, two workgroups per CU.  Same-box kernel traces of the bs = 32 forward (r05,
         // profiles/r05_x3_ring2_ab.txt), three-slot form by shape -> this one: 32 768 x 256 x 256 (9 launches) 31.8 -> 28.3 us, 65 536 x 256 x K
         // 62.5 -> 58.8, 65 536 x 768 x 256 120 -> 114.5, 262 144 x 384 x 128 171 -> 168; the convolutions (+8 %) and the stage-1 projection
         // above (+10 %) lose with it and keep the three-slot forms
-        if (!CONV && force == 0) return launch<128, 128, 64, 64, CONV, FMT, 2>(p, s);
+        if (!CONV && (force == 0 || force == 9)) return launch<128, 128, 64, 64, CONV, FMT, 2>(p, s);
         if (t256 < 512) return launch<128, 128, 32, 64, CONV, FMT>(p, s);
         return launch<256, 128, 64, 64, CONV, FMT>(p, s);
     }
@@ -665,11 +669,14 @@ int dispatch(const X3Args& p, hipStream_t s) {
 
 template <bool CONV, int FMT>
 int dispatch_s(const X3Args& p, hipStream_t s) {
+    const int force = x3_tile();
     if (p.N > 64) {
+        if (force == 9) return launch_s<128, 128, 64, 64, CONV, FMT, 2>(p, s);     // r05 A/B: two-slot ring, two workgroups per CU
         const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 127) / 128);
         if (t256 < 512) return launch_s<128, 128, 32, 64, CONV, FMT>(p, s);
         return launch_s<256, 128, 64, 64, CONV, FMT>(p, s);
     }
+    if (p.N > 32 && force == 9) return launch_s<128, 64, 64, 32, CONV, FMT, 2>(p, s);   // 48 KB: three workgroups per CU by LDS, two by registers
     if (p.N > 32) return launch_s<256, 64, 64, 32, CONV, FMT>(p, s);
     return launch_s<128, 32, 32, 32, CONV, FMT>(p, s);
 }

@@ -326,12 +326,12 @@ def test_x3_loss_network_repeatable_at_scale(cuda):
 
 
 def test_x3_tile_variants_repeatable(cuda):
-    """the A/B tile forms behind MASTER_X3_TILE = 1..7 and the eight-wave C = 128 MLP (MASTER_MLP_X3_C128=8w) are read once per process,
+    """the A/B tile forms behind MASTER_X3_TILE = 1..7, 9 and the eight-wave C = 128 MLP (MASTER_MLP_X3_C128=8w) are read once per process,
     so each runs the determinism tool in a child process of its own (one at a time; ADVICE r04: the default tiles alone were covered)"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     tool = os.path.join(root, "profiles", "tools", "x3_determinism.py")
-    runs = [({"MASTER_X3_TILE": str(t)}, "linear,conv") for t in range(1, 8)] + [({"MASTER_MLP_X3_C128": "8w"}, "mlp")]
+    runs = [({"MASTER_X3_TILE": str(t)}, "linear,conv,convs" if t == 9 else "linear,conv") for t in (1, 2, 3, 4, 5, 6, 7, 9)] + [({"MASTER_MLP_X3_C128": "8w"}, "mlp")]
     for env, only in runs:
         r = subprocess.run([sys.executable, tool, "4", "--only", only], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, f"{env}: rc {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}"
