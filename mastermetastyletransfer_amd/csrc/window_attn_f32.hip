@@ -86,8 +86,12 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
                                    : p.k_pad + (size_t)b * p.k_pad_bs + coff + 16 * h;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
+#ifdef ATTN_PROBE_NOLOAD
+            qv[t][c] = f32x4{(float)lane, 1.f, (float)c, 0.5f} * 1e-3f; kv[t][c] = f32x4{(float)t, 1.f, (float)lane, 0.25f} * 1e-3f; (void)qp; (void)kp;
+#else
             qv[t][c] = *(const f32x4*)(qp + 4 * c);     // padded query slots: any finite row, never stored
             kv[t][c] = *(const f32x4*)(kp + 4 * c);     // key slots >= N: masked by bias = -1e30
+#endif
         }
     }
 
@@ -111,7 +115,11 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
             for (int e = 0; e < 16; ++e) {
                 const int key0 = kt * 32 + (e & 3) + 8 * (e >> 2);                   // half 0's key; half 1 takes key0 + 4
                 const int off = __builtin_amdgcn_ds_bpermute(bp_sel + 4 * key0, my_voff);
+#ifdef ATTN_PROBE_NOLOAD
+                const float a = (float)(off & 1023) * 1e-3f + (float)lane_off; (void)vb;
+#else
                 const float a = *(const float*)(vb + (unsigned)(off + lane_off));
+#endif
                 // lanes 0-31: is slot key0 real, lanes 32-63: is slot key0 + 4 real (slots >= N count as padded: they read the finite pad
                 // row and their probability is exactly 0 - bias -1e30)
                 const unsigned long long m = (((real_slots >> key0) & 1ull) ? 0x00000000ffffffffull : 0ull) |
@@ -155,6 +163,30 @@ __global__ __launch_bounds__(256) void window_attn_f32_kernel(AttnArgs p) {
                 }
         }
     }
+#ifdef ATTN_PROBE_NOCOMPUTE
+    {   // loads + stores only: every loaded value folded into the stored rows with one add each
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc += qv[t][c][e] + kv[t][c][e];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc += vv0[kt][e];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int idx = __shfl(my_src, qt * 32 + r, 64);
+            if (idx < 0) continue;
+            float* op = (float*)((char*)(p.out0 + tok0 * p.ldo) + (unsigned)((idx * p.ldo + coff + 4 * h) * 4));
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *(f32x4*)(op + 8 * g) = f32x4{acc, acc, acc, acc};
+        }
+        return;
+    }
+#endif
     if constexpr (X3) {
         FragX kh[2][2], kl[2][2], qh[2][2], ql[2][2];                     // [tile][k-step s']: channels 16h + 8s' .. +8
 #pragma unroll
