@@ -14,7 +14,9 @@ Parity pinning (see DESIGN.md "Oracle"):
     ``tests/golden/make_golden.py`` (run in the build container, where /root/reference is
     mounted); the resulting input/output vectors are committed under ``tests/golden``.
   * Swin-B ``features[:4]``: the arithmetic lives in torchvision (absent from the reference tree and
-    from this image, version not pinned by the reference) -> "parity unpinned" for that stage.
+    from this image, version not pinned by the reference) -> cannot be pinned against torchvision here.
+    Since r05 the whole stage is pinned against an INDEPENDENT implementation of the published architecture that is in the image,
+    Hugging Face transformers' SwinModel (tests/golden/make_golden_swin_hf.py -> golden_swin_hf.npz: five geometries, agreement 4e-6).
     It is restated from the reference's own modified copy of torchvision's window attention
     (codes/style_transformer.py:37-169, fused-qkv original kept in comments at :203,:260-272) and
     the block layout documented in codes/load_pretrained_weights_to_style_transformer.py:29-60.

@@ -277,6 +277,34 @@ def test_swin_encoder_vs_oracle(cuda, B, S):
         assert_close(m.swin_encoder(img.to(cuda)), O.swin_encoder(img, swin_sd), f"swin encoder {S}", 2e-4)
 
 
+@pytest.mark.parametrize("mode,tol", [("fp32", 1e-5), ("f16x3", 1e-5), ("bf16", None)])
+def test_swin_encoder_vs_transformers_fixture(cuda, mode, tol):
+    """the HIP Swin-B features[:4] stage against hidden states of Hugging Face transformers' SwinModel on the same seeded weights
+    (tests/golden/golden_swin_hf.npz, made by tests/golden/make_golden_swin_hf.py): an implementation of the published architecture that
+    is independent of this repository and of its oracle - the pin for the stage whose own dependency (torchvision) is absent.
+    Five geometries: 64^2 (maps smaller than two windows), 128^2 x 2, 200^2 (odd map at the merge), 256^2, 96 x 160."""
+    import os
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_swin_hf.npz"))
+    m, _ = full_model(cuda)
+    sd = seeded_state_dict(O.swin_shapes(), int(z["weights_seed"]))
+    m.swin_encoder.load_state_dict(sd)
+    m.set_compute_dtype({"fp32": torch.float32, "f16x3": "f16x3", "bf16": torch.bfloat16}[mode])
+    for c in z["cases"].tolist():
+        name, B, H, W, seed = c.split(":")
+        img = seeded_input("swin_hf_" + name, (int(B), 3, int(H), int(W)), int(seed), kind="image")
+        ref = torch.from_numpy(z["out_" + name])
+        with torch.no_grad():
+            got = m.swin_encoder(img.to(cuda)).float().cpu()
+        if tol is not None:
+            err = assert_close(got, ref, f"swin encoder [{mode}] vs transformers ({name})", tol)
+            print(f"swin encoder [{mode}] vs transformers {z['transformers_version']} ({name}): max|d| {err:.2e}, max|ref| {float(ref.abs().max()):.2f}")
+        else:                                  # bf16 throughput mode: relative L2 (operand rounding through 4 blocks)
+            rel = float((got - ref).norm() / ref.norm())
+            assert torch.isfinite(got).all() and rel <= 2e-2, f"{name}: rel L2 {rel:.3e}"
+            print(f"swin encoder [bf16] vs transformers ({name}): rel L2 {rel:.2e}")
+
+
 def test_full_forward_odd_feature_map(cuda):
     """image sides that are multiples of 4 but not of 8 (260 x 132 -> 65 x 33 tokens): torchvision's PatchMerging pads the map to even
     sides with zeros; the output is 8 * ceil(side / 8) like the reference's"""
@@ -477,7 +505,7 @@ def test_harness_chain_end_to_end(cuda):
 # torchvision pin (Swin-B features[:4] and VGG-19 cfg "E" live in torchvision, which the reference does not vendor or
 # pin): where the GPU box has torchvision, the oracle's restatement AND the HIP path are checked against torchvision's own modules
 # with the same seeded weights.  torchvision is a third-party library, not the reference; nothing is vendored.  Skips where absent
-# (this image has none: the skip is recorded in DESIGN.md as "parity unpinned" for that stage).
+# (this image has none; the Swin stage is pinned against transformers' independent SwinModel instead: test_swin_encoder_vs_transformers_fixture).
 # ---------------------------------------------------------------------------------------------------------------------------------------
 def test_swin_encoder_vs_torchvision(cuda):
     tv = pytest.importorskip("torchvision")

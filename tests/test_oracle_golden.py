@@ -95,3 +95,46 @@ def test_non_default_decoder_branches():
         sd, fc, fs, cfg = MB.case(i)
         for k in (1, 2):
             close(O.style_transformer(fc, fs, k, sd, cfg), gold[f"{tag}_k{k}"], f"{tag}_k{k}")
+
+
+# ---- the torchvision stage (Swin-B features[:4]) pinned against an independent implementation -------------------------------------------
+def _swin_hf_fixture():
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_swin_hf.npz"))
+    cases = [c.split(":") for c in z["cases"].tolist()]
+    return z, [(n, int(b), int(h), int(w), int(s)) for n, b, h, w, s in cases]
+
+
+@torch.no_grad()
+def test_swin_encoder_matches_the_transformers_fixture():
+    """oracle.swin_encoder (the restatement of torchvision's swin_b.features[:4], which is absent here) against hidden states produced by
+    Hugging Face transformers' SwinModel - an independent implementation of the same architecture - loaded with the same seeded weights
+    (tests/golden/make_golden_swin_hf.py): five geometries incl. maps smaller than two windows, odd maps at the merge, a non-square image"""
+    from oracle.seeded import seeded_input, seeded_state_dict
+    z, cases = _swin_hf_fixture()
+    sd = seeded_state_dict(O.swin_shapes(), int(z["weights_seed"]))
+    assert len(cases) == 5
+    for name, B, H, W, seed in cases:
+        img = seeded_input("swin_hf_" + name, (B, 3, H, W), seed, kind="image")
+        close(O.swin_encoder(img, sd), z["out_" + name], f"swin encoder vs transformers {z['transformers_version']} ({name})")
+
+
+@torch.no_grad()
+def test_swin_fixture_is_what_transformers_computes():
+    """the committed fixture against a live run of the generating code, where `transformers` is installed (it is in this image): the fixture
+    is not a copy of the oracle's own output"""
+    import pytest
+    pytest.importorskip("transformers")
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_swin_hf as M
+    from oracle.seeded import seeded_input, seeded_state_dict
+    z, cases = _swin_hf_fixture()
+    tv = seeded_state_dict(O.swin_shapes(), int(z["weights_seed"]))
+    m, _ = M.build_hf_model(tv)
+    # the model's own index buffer (computed by transformers) equals the oracle's relative_position_index
+    idx = [b for n, b in m.named_buffers() if n.endswith("relative_position_index")]
+    assert idx and all(torch.equal(b.reshape(-1).long(), O.relative_position_index((7, 7)).reshape(-1).long()) for b in idx)
+    for name, B, H, W, seed in cases[:3]:
+        img = seeded_input("swin_hf_" + name, (B, 3, H, W), seed, kind="image")
+        close(M.hf_features(m, img), z["out_" + name], f"transformers live vs fixture ({name})")
