@@ -138,3 +138,21 @@ def test_swin_fixture_is_what_transformers_computes():
     for name, B, H, W, seed in cases[:3]:
         img = seeded_input("swin_hf_" + name, (B, 3, H, W), seed, kind="image")
         close(M.hf_features(m, img), z["out_" + name], f"transformers live vs fixture ({name})")
+
+
+def test_swin_b_stochastic_depth_schedule_matches_transformers():
+    """train-mode StochasticDepth of the (frozen, but train-mode) encoder: torchvision's swin_b spreads stochastic_depth_prob = 0.5 linearly
+    over its 24 blocks (block n: 0.5 n / 23); transformers' SwinModel with drop_path_rate = 0.5 and Swin-B's depths builds the same schedule
+    independently - the first four blocks are the ones features[:4] runs"""
+    import pytest
+    pytest.importorskip("transformers")
+    from transformers import SwinConfig
+    from transformers.models.swin.modeling_swin import SwinEncoder
+    cfg = SwinConfig(image_size=224, patch_size=4, embed_dim=8, depths=[2, 2, 18, 2], num_heads=[1, 2, 4, 8], window_size=7, drop_path_rate=0.5)
+    enc = SwinEncoder(cfg, (56, 56))
+    probs = []
+    for layer in enc.layers[:2]:
+        for blk in layer.blocks:
+            dp = blk.drop_path
+            probs.append(float(getattr(dp, "drop_prob", 0.0) or 0.0))
+    assert len(probs) == 4 and all(abs(a - b) < 1e-7 for a, b in zip(probs, O.SWIN_B_SD_PROBS)), (probs, O.SWIN_B_SD_PROBS)
