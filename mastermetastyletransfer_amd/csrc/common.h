@@ -92,6 +92,33 @@ __device__ __forceinline__ float fast_erf(float z) {
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// The same GELU in packed math (r05 experiment, used by mlp_x3.hip under -DMLPX3_GELU_7128 only), two values per instruction: erf by Abramowitz & Stegun 7.1.28,
+// erf(z) = 1 - 1 / (1 + a1 z + ... + a6 z^6)^16 (|error| <= 3e-7), z = |x| / sqrt(2) folded into the coefficients: six v_pk_fma, four
+// v_pk_mul (the 16th power), ONE transcendental per value (v_rcp; 7.1.26 above needs v_rcp and v_exp, and transcendentals issue at quarter
+// rate) - 12.5 issue slots per value instead of 21.  |GELU error| <= 8.8e-7 over |x| <= 12 in fp32 arithmetic (7.1.26: 4.6e-7), i.e. 2 ulp at
+// |x| = 4; large |x|: the power overflows to inf, 1 / inf = 0, erf = 1 exactly.  In two halves so that the MLP can deal them out between MFMA groups.
+__device__ __forceinline__ f32x2 gelu_erf2_pow(f32x2 x) {                 // first half: (1 + a1 z + ... + a6 z^6)^16
+    f32x2 a;
+    a.x = fabsf(x.x); a.y = fabsf(x.y);
+    f32x2 P = a * 5.382975e-06f + 4.8890636e-05f;                             // a6 / 8, a5 / (4 sqrt 2)  (z = |x| / sqrt 2)
+    P = P * a + 3.8003575e-05f;                                           // a4 / 4
+    P = P * a + 3.2776263e-03f;                                           // a3 / (2 sqrt 2)
+    P = P * a + 2.11410062e-02f;                                          // a2 / 2
+    P = P * a + 4.98673469e-02f;                                          // a1 / sqrt 2
+    P = P * a + 1.0f;
+    P = P * P; P = P * P; P = P * P;
+    return P * P;
+}
+__device__ __forceinline__ f32x2 gelu_erf2_finish(f32x2 x, f32x2 P16) {   // second half: x * Phi(x), Phi = 1/2 + copysign(1/2 - r/2, x)
+    f32x2 r;
+    r.x = __builtin_amdgcn_rcpf(P16.x); r.y = __builtin_amdgcn_rcpf(P16.y);
+    const f32x2 h = r * -0.5f + 0.5f;
+    f32x2 sg;
+    sg.x = copysignf(h.x, x.x); sg.y = copysignf(h.y, x.y);
+    return x * sg + x * 0.5f;
+}
+
 // GELU for the bf16 mode: x * clamp01(0.5 + x R(x^2)), R fitted to (Phi(x) - 0.5)/x; beyond the fitted range the polynomial runs off in
 // the right direction (even degree of R, positive leading coefficient) and the clamp pins Phi to 0 or 1, +-inf included.
 //   degree 4 (default, r03): least-squares fit of the GELU error under a N(0, 2) weight on |x| <= 3.2 (where pre-activations live):
@@ -100,7 +127,6 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + f
 //   degree 6 (-DMASTER_GELU_DEG6, r01/r02): |error| <= 1.9e-4.  9 instructions per value.
 // The GELU arithmetic is the exposed VALU time of the fused MLP kernels (18.7 k of 111 k clocks per workgroup with degree 6,
 // profiles/r02_mlp_probe_*.txt); exp / rcp forms cost ~29 op slots (transcendentals issue at quarter rate).  The fp32 parity mode keeps gelu_erf.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {                   // two values per instruction (v_pk_mul / v_pk_fma)
     const f32x2 t = x * x;
 #ifdef MASTER_GELU_DEG6

@@ -234,6 +234,12 @@ __global__ __launch_bounds__(NW * 64, WGPC) void mlp_x3_kernel(MlpX3Args p) {
     // GELU (exact erf) + split of the previous block, one hidden value at a time between the MFMA groups of the next block's phase 1:
     // value v = 0..31 of the lane: tile jt = v >> 4, k-step sg = (v >> 3) & 1, pair i = (v >> 1) & 3, element z = v & 1.  A packed
     // accumulator tile is the B fragment of phase 2 (k order of split_weights layout 1).
+    // r05 experiment, -DMLPX3_GELU_7128: the pair (z = 0, 1) through the packed form of common.h (A&S 7.1.28: one transcendental per value,
+    // v_pk_fma / v_pk_mul for the rest; 12.5 issue slots per value instead of 21) in two halves - the 16th power behind group z = 0,
+    // reciprocal / sign / product / split behind group z = 1.  Measured (profiles/r05_mlp_x3_packed_gelu_ab.txt): C = 128 form -5.5 %, C = 256
+    // form unchanged (its GELU already runs under the MFMAs), the step -0.05 %; its 8.8e-7 GELU error (7.1.26: 4.6e-7) moved the smoke pair's
+    // image error from 1.28e-4 to 1.33e-4 (bf16 halves 6.7e-4 -> 8.0e-4): not worth it, the default stays 7.1.26.
+#ifndef MLPX3_GELU_7128
     float gfine[2];
     auto gelu_fine = [&](int v) __attribute__((always_inline)) {
         const int jt = v >> 4, sg = (v >> 3) & 1, i = (v >> 1) & 3, z = v & 1;
@@ -248,6 +254,25 @@ __global__ __launch_bounds__(NW * 64, WGPC) void mlp_x3_kernel(MlpX3Args p) {
             asm volatile("" :: "v"(gfine[0]));
         }
     };
+#else
+    f32x2 gx, gp16;
+    auto gelu_fine = [&](int v) __attribute__((always_inline)) {
+        const int jt = v >> 4, sg = (v >> 3) & 1, i = (v >> 1) & 3, z = v & 1;
+        if (z == 0) {
+            gx.x = PIPE ? hprev[jt][8 * sg + 2 * i] : hacc[jt][8 * sg + 2 * i];
+            gx.y = PIPE ? hprev[jt][8 * sg + 2 * i + 1] : hacc[jt][8 * sg + 2 * i + 1];
+            gp16 = gelu_erf2_pow(gx);
+            asm volatile("" :: "v"(gp16));                      // pin: LLVM otherwise sinks the arithmetic below the MFMAs
+        } else {
+            const f32x2 g = gelu_erf2_finish(gx, gp16);
+            unsigned a, l;
+            split_x2<FMT>(g.x, g.y, a, l);
+            hfh[jt][sg].u[i] = a;
+            hfl[jt][sg].u[i] = l;
+            asm volatile("" :: "v"(hfl[jt][sg].u[i]));
+        }
+    };
+#endif
 
     // !PIPE forms: the pieces of the look-ahead step behind MFMA group `it` of 8.  With a two-slot ring (one step of look-ahead) a piece
     // issued late in the step has not landed when the next step begins, so they go out two at a time in the first half of the step.
