@@ -102,6 +102,8 @@ int mlp_c128_bf16(const bf16_t*, const float*, const float*, const bf16_t*, cons
                   const bf16_t*, bf16_t*, int, int, int, int, int, int, float, hipStream_t);
 int mlp_2w_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const float*,
                 const bf16_t*, bf16_t*, int, int, int, int, int, int, float, hipStream_t);
+int mlp_8w_bf16(const bf16_t*, const float*, const float*, const bf16_t*, const float*, const bf16_t*, const float*,
+                const bf16_t*, bf16_t*, int, int, int, int, int, int, float, hipStream_t);
 
 int gemm_x3_split_weights(const float*, void*, size_t, size_t, int, hipStream_t, int fmt);
 int conv_tail_x3(const void*, int, const void*, const float*, const void*, const float*, float*, int, int, int, hipStream_t, int fmt);
@@ -665,6 +667,11 @@ int master_mlp_fwd(const void* x, const float* ln_gamma, const float* ln_beta, c
     const char* form = getenv("MASTER_MLP_FORM");              // read per call: tests cover every form in one process
     if (form && !strcmp(form, "2w")) {                        // C = 128: two workgroups per CU, GELU dealt out behind the phase-1 MFMAs (mlp_2w_bf16.hip)
         const int rc = mlp_2w_bf16((const bf16_t*)x, ln_gamma, ln_beta, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, (const bf16_t*)res,
+                                   (bf16_t*)out, M, C, HID, ldx, ldr, ldo, eps, s);
+        if (rc != MASTER_ERR_UNSUPPORTED) return rc;
+    }
+    if (form && !strcmp(form, "8w")) {                        // C = 256: eight waves, two per SIMD on the same tokens (mlp_8w_bf16.hip, r05)
+        const int rc = mlp_8w_bf16((const bf16_t*)x, ln_gamma, ln_beta, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, (const bf16_t*)res,
                                    (bf16_t*)out, M, C, HID, ldx, ldr, ldo, eps, s);
         if (rc != MASTER_ERR_UNSUPPORTED) return rc;
     }

@@ -127,7 +127,7 @@ def test_full_forward_bf16(cuda, B, S):
 
 @pytest.mark.parametrize("M,C,HID,ln,res", [(128, 256, 1024, False, True), (1000, 256, 1024, True, True), (333, 128, 512, True, True),
                                              (4096, 128, 512, False, False), (77, 256, 256, True, False), (700, 128, 128, True, True)])
-@pytest.mark.parametrize("form", ["default", "mono", "2w", "c128"])
+@pytest.mark.parametrize("form", ["default", "mono", "2w", "c128", "8w"])
 def test_fused_mlp_bf16(cuda, monkeypatch, form, M, C, HID, ln, res):
     """one-launch LN -> fc1 -> GELU -> fc2 -> +residual against the same chain in fp32 on the bf16-rounded operands;
     both forms of the kernel: default (256-token specialisation for C = 128, else one wave per SIMD) and the generic one forced
