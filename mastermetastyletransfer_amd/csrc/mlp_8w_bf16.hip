@@ -22,10 +22,10 @@
 // one-wave form: 53.1 us against 49.4 at M = 32 768 without a LayerNorm (62 against 53 with one: both waves of a band load and normalise
 // the row), 56.4 before the fragment reads were pipelined by hand.  Probe builds: no GELU 48.0, no weight stream 46.7, neither 42.6, no
 // step barrier 50.9 - the partner wave does NOT hide the weight stream's issue or the GELU (they cost what they cost the one-wave form),
-// and what is left without them is still 3x the launch's 13.6 us of MFMA.  One reason is arithmetic: a 32x32x16 MFMA (32 clocks per SIMD)
-// consumes a fresh 1-KB A fragment from LDS, four SIMDs take 128 B per clock - exactly the LDS read bandwidth of a CU - and the weight
-// stream writes another 25 % into it (2 640 clocks of LDS traffic per 64 hidden units against 2 048 of MFMA): the token-stationary form
-// with 32 tokens per wave has no LDS slack for a second wave to use.  Opt-in (MASTER_MLP_FORM=8w), not the default.
+// and what is left without them is still 3x the launch's 13.6 us of MFMA.  LDS bandwidth is not the reason (a 32x32x16 MFMA consumes one
+// 1-KB A fragment: 128 B per clock for four SIMDs at full rate, half of the 256 B per clock that ds_read_b128 gets on gfx950; the weight
+// stream adds a quarter): what the second wave cannot hide is per-instruction issue on the SIMD both waves share, and it pays twice for the
+// row loads / LayerNorm and once more for the exchange.  Opt-in (MASTER_MLP_FORM=8w), not the default.
 #include "common.h"
 
 namespace {
