@@ -161,6 +161,48 @@ __device__ __forceinline__ float apply_act(float x) {
     return x;
 }
 
+// LayerNorm of a token row held as bf16 fragments in registers (fragment s of lane (token, half h) = channels 16 s + 8 h .. +7; lane ^ 32 holds
+// the other half of the row), in packed fp32 math (r05: v_pk_add / v_pk_fma, two channels per instruction, normalisation folded to
+// v * rstd + (-mean * rstd)): gamma / beta are fp32 vectors in LDS.  Used by the fused MLP kernels; attn_block_bf16.hip has its own copy.
+template <int KS, typename F>
+__device__ __forceinline__ void layernorm_frags_pk(F (&xf)[KS], const float* lng, const float* lnb, int h, float eps) {
+    constexpr int CH = KS * 16;
+    f32x2 sum2 = {0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum2 += f32x2{__uint_as_float(xf[s].u[e] << 16), __uint_as_float(xf[s].u[e] & 0xffff0000u)};
+    float sum = sum2.x + sum2.y;
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.0f / CH);
+    f32x2 sq2 = {0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x2 d = f32x2{__uint_as_float(xf[s].u[e] << 16), __uint_as_float(xf[s].u[e] & 0xffff0000u)} - mean;
+            sq2 += d * d;
+        }
+    float sq = sq2.x + sq2.y;
+    sq += __shfl_xor(sq, 32, 64);
+    const float rstd = rsqrtf(sq * (1.0f / CH) + eps);
+    const float nmr = -mean * rstd;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const float* gp = lng + 16 * s + 8 * h; const float* bp = lnb + 16 * s + 8 * h;
+        const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4);
+        const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x2 v = f32x2{__uint_as_float(xf[s].u[e] << 16), __uint_as_float(xf[s].u[e] & 0xffff0000u)};
+            const f32x2 g = e < 2 ? f32x2{g0[2 * e], g0[2 * e + 1]} : f32x2{g1[2 * e - 4], g1[2 * e - 3]};
+            const f32x2 b = e < 2 ? f32x2{b0[2 * e], b0[2 * e + 1]} : f32x2{b1[2 * e - 4], b1[2 * e - 3]};
+            const f32x2 o = (v * rstd + nmr) * g + b;
+            xf[s].u[e] = pack_bf16x2(o.x, o.y);
+        }
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

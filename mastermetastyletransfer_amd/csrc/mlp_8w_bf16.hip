@@ -136,43 +136,7 @@ __global__ __launch_bounds__(NW * 64, 1) void mlp_8w_bf16_kernel(MlpArgs p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                         // parameter vectors visible to every wave
-    if (p.ln_g) {
-        // LayerNorm over the C channels of token m: this lane holds half of them, lane ^ 32 the rest (packed math: two values per instruction)
-        f32x2 sum2 = {0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < KS1; ++s)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sum2 += f32x2{__uint_as_float(xf[s].u[e] << 16), __uint_as_float(xf[s].u[e] & 0xffff0000u)};
-        float sum = sum2.x + sum2.y;
-        sum += __shfl_xor(sum, 32, 64);
-        const float mean = sum / (float)C;
-        f32x2 sq2 = {0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < KS1; ++s)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const f32x2 d = f32x2{__uint_as_float(xf[s].u[e] << 16), __uint_as_float(xf[s].u[e] & 0xffff0000u)} - mean;
-                sq2 += d * d;
-            }
-        float sq = sq2.x + sq2.y;
-        sq += __shfl_xor(sq, 32, 64);
-        const float rstd = rsqrtf(sq / (float)C + p.eps);
-        const float nmr = -mean * rstd;
-#pragma unroll
-        for (int s = 0; s < KS1; ++s) {
-            const float* gp = lng + 16 * s + 8 * h; const float* bp = lnb + 16 * s + 8 * h;
-            const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4);
-            const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const f32x2 v = f32x2{__uint_as_float(xf[s].u[e] << 16), __uint_as_float(xf[s].u[e] & 0xffff0000u)};
-                const f32x2 g = e < 2 ? f32x2{g0[2 * e], g0[2 * e + 1]} : f32x2{g1[2 * e - 4], g1[2 * e - 3]};
-                const f32x2 b = e < 2 ? f32x2{b0[2 * e], b0[2 * e + 1]} : f32x2{b1[2 * e - 4], b1[2 * e - 3]};
-                const f32x2 o = (v * rstd + nmr) * g + b;
-                xf[s].u[e] = pack_bf16x2(o.x, o.y);
-            }
-        }
-    }
+    if (p.ln_g) layernorm_frags_pk<KS1>(xf, lng, lnb, h, p.eps);      // packed math (common.h); both waves of a band normalise the row
 
     // ---- per-step synchronisation: my DMAs of step t have landed -> barrier -> everyone's have, everyone is done reading step t - 1 (whose
     //      slot step t + AHEAD goes into), and every exchange write issued before it is visible ---------------------------------------

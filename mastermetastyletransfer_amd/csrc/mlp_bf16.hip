@@ -156,6 +156,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
     {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                     // parameter vectors visible to every wave
+#ifndef MLP_LN_SCALAR        // r05: packed math (common.h); -DMLP_LN_SCALAR keeps the r01-r04 form below for A/B runs
+        if (p.ln_g) layernorm_frags_pk<KS1>(xf, lng, lnb, h, p.eps);
+#else
         if (p.ln_g) {
             // LayerNorm over the C channels of token m: this lane holds half of them, lane^32 the rest
             float v[KS1][8];
@@ -192,6 +195,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs p) {
                 for (int e = 0; e < 4; ++e) xf[s].u[e] = pack_bf16x2(o[2 * e], o[2 * e + 1]);
             }
         }
+#endif
     }
 
     // ---- per-step synchronisation: my DMAs of step t have landed -> barrier -> everyone's have, and everyone

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256, 1) void mlp_c128_kernel(M128Args p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                         // parameter vectors visible
     if (p.ln_g) {
+#ifdef MLP_LN_SCALAR         // the r01-r04 form (un-packed arithmetic), kept for A/B runs
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             float sum = 0.f;
@@ -140,6 +141,10 @@ __global__ __launch_bounds__(256, 1) void mlp_c128_kernel(M128Args p) {
                 for (int e = 0; e < 4; ++e) xf[tt][s].u[e] = pack_bf16x2(o[2 * e], o[2 * e + 1]);
             }
         }
+#else                        // r05: packed math (common.h)
+        layernorm_frags_pk<KS>(xf[0], lng, lnb, h, p.eps);
+        layernorm_frags_pk<KS>(xf[1], lng, lnb, h, p.eps);
+#endif
     }
 
     // ---- per-step synchronisation: my DMAs of step t landed -> barrier -> everyone's have, and everyone left step t-1's slot ------
