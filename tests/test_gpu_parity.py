@@ -305,6 +305,20 @@ def test_swin_encoder_vs_transformers_fixture(cuda, mode, tol):
             print(f"swin encoder [bf16] vs transformers ({name}): rel L2 {rel:.2e}")
 
 
+def test_empty_batch_is_an_error_not_a_crash(cuda):
+    """B = 0: the CPU path cannot run it either (a reshape with an ambiguous -1 in the window partition); the HIP path must answer with an
+    exception - no launch with an empty grid, no device fault - and stay usable afterwards"""
+    m, (swin_sd, st_sd, dec_sd) = full_model(cuda)
+    c = seeded_input("c64", (1, 3, 64, 64), 8, kind="image")
+    with pytest.raises(Exception) as ei, torch.no_grad():
+        m(c[0:0].to(cuda), c[0:0].to(cuda), 1)
+    assert not isinstance(ei.value, (SystemExit, KeyboardInterrupt))
+    with torch.no_grad():
+        got = m(c.to(cuda), c.to(cuda), 1)
+        ref = O.full_forward(c, c, 1, swin_sd, st_sd, dec_sd)
+    assert_close(got, ref, "forward after the refused empty batch", absolute=True)
+
+
 def test_full_forward_odd_feature_map(cuda):
     """image sides that are multiples of 4 but not of 8 (260 x 132 -> 65 x 33 tokens): torchvision's PatchMerging pads the map to even
     sides with zeros; the output is 8 * ceil(side / 8) like the reference's"""
