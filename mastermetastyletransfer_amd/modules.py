@@ -863,8 +863,16 @@ class SwinEncoder(nn.Sequential):
         """fp32 NCHW image batch(es) -> (token matrix [B*H/8*W/8, 2E] in the compute dtype, B, H/8, W/8).  Several
         batches (content, style) are embedded into consecutive slices of one buffer and encoded as one batch."""
         _, _, H, W = imgs[0].shape
+        if H < 4 or W < 4:
+            raise RuntimeError(f"Kernel size can't be greater than actual input size: the 4x4 patch embedding needs images of at least 4x4 (got {H}x{W})")
         if H % 4 or W % 4:
-            raise ValueError("image sides must be multiples of 4 (the 4x4 patch embedding has stride 4 and no padding)")
+            # Conv2d(kernel 4, stride 4, no padding) never reads the trailing H % 4 rows / W % 4 columns (torchvision's patch embedding; the
+            # reference accepts such images): crop them - a copy, on this rare path only
+            for img in imgs:
+                if img.shape[1:] != imgs[0].shape[1:]:
+                    raise ValueError("all image batches must have the same size")
+            H, W = H - H % 4, W - W % 4
+            imgs = tuple(img[:, :, :H, :W] for img in imgs)
         conv, ln = self[0][0], self[0][2]
         B = sum(int(i.shape[0]) for i in imgs)
         dt1 = getattr(self, "stage1_dtype", None) or self.compute_dtype          # fp32 for embed 96 in the bf16 mode (model.set_compute_dtype)

@@ -305,6 +305,22 @@ def test_swin_encoder_vs_transformers_fixture(cuda, mode, tol):
             print(f"swin encoder [bf16] vs transformers ({name}): rel L2 {rel:.2e}")
 
 
+@pytest.mark.parametrize("H,W", [(250, 254), (66, 70), (33, 47)])
+def test_full_forward_sides_not_multiples_of_4(cuda, H, W):
+    """the 4x4 / stride-4 patch embedding has no padding: it ignores the trailing H % 4 rows and W % 4 columns, the reference accepts such
+    images and returns 8 * ceil(floor(side / 4) / 2) pixels per side (250 x 254 -> 248 x 256); so does the HIP path (r05: it used to refuse them)"""
+    m, (swin_sd, st_sd, dec_sd) = full_model(cuda)
+    c = seeded_input("c_n4", (1, 3, H, W), 8, kind="image")
+    s = seeded_input("s_n4", (1, 3, H, W), 9, kind="image")
+    with torch.no_grad():
+        got = m(c.to(cuda), s.to(cuda), 1)
+        ref = O.full_forward(c, s, 1, swin_sd, st_sd, dec_sd)
+    assert got.shape == ref.shape == (1, 3, 8 * (((H // 4) + 1) // 2), 8 * (((W // 4) + 1) // 2))
+    assert_close(got, ref, f"full forward {H}x{W}", absolute=True)
+    with pytest.raises(RuntimeError), torch.no_grad():
+        m(c[:, :, :3].to(cuda), s[:, :, :3].to(cuda), 1)
+
+
 def test_empty_batch_is_an_error_not_a_crash(cuda):
     """B = 0: the CPU path cannot run it either (a reshape with an ambiguous -1 in the window partition); the HIP path must answer with an
     exception - no launch with an empty grid, no device fault - and stay usable afterwards"""
