@@ -154,10 +154,15 @@ __device__ __forceinline__ float gelu_poly1(float xx) {                  // one 
     return xx * __builtin_amdgcn_fmed3f(fmaf(xx, R, 0.5f), 0.0f, 1.0f);
 }
 
+// ReLU that propagates NaN like torch.relu (v_max_f32 returns the other operand for a NaN: fmaxf(NaN, 0) = 0).  The exact-fp32 and the split
+// modes use it: in "f16x3" an activation beyond half's range becomes inf / NaN, and the decoder's ReLUs must not turn that into a clean 0
+// (r05: a k = 5 forward on random weights, activations up to 4.5e7, came out FINITE and wrong before this).
+__device__ __forceinline__ float relu_np(float x) { return x < 0.0f ? 0.0f : x; }
+
 template <int ACT>
 __device__ __forceinline__ float apply_act(float x) {
     if (ACT == MASTER_ACT_GELU) return gelu_erf(x);
-    if (ACT == MASTER_ACT_RELU) return fmaxf(x, 0.0f);
+    if (ACT == MASTER_ACT_RELU) return relu_np(x);
     return x;
 }
 

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv_tail_x3_kernel(TailX3Args p) {
                 for (int g = 0; g < 4; ++g) {
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[4 * g + e] + b8v[4 * g + e], 0.f);
+                    for (int e = 0; e < 4; ++e) v[e] = relu_np(acc[4 * g + e] + b8v[4 * g + e]);
                     unsigned h0, h1, l0, l1;
                     split_x2<FMT>(v[0], v[1], h0, l0);
                     split_x2<FMT>(v[2], v[3], h1, l1);

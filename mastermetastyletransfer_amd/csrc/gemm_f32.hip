@@ -182,7 +182,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(Ge
                 float v = acc[i][jn][e] + bv;
                 if (p.aux) p.aux[(size_t)m * p.ldo + n] = v;
                 if (p.act == MASTER_ACT_GELU) v = gelu_erf(v);
-                else if (p.act == MASTER_ACT_RELU) v = fmaxf(v, 0.0f);
+                else if (p.act == MASTER_ACT_RELU) v = relu_np(v);
                 if (p.mask_relu) {
                     if (p.r2) v += p.r2[(size_t)m * p.ldr + n];
                     if (!(p.r1[(size_t)m * p.ldr + n] > 0.0f)) v = 0.0f;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_dma_kerne
                     for (int c = 0; c < 4; ++c) x[c] = gelu_erf(x[c]);
                 } else if (p.act == MASTER_ACT_RELU) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) x[c] = fmaxf(x[c], 0.0f);
+                    for (int c = 0; c < 4; ++c) x[c] = relu_np(x[c]);
                 }
                 if (p.mask_relu) {
                     if (p.r2) x += a2[it];
@@ -438,7 +438,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_dma_kerne
                 float v = acc[i][jn][e] + bv;
                 if (p.aux) p.aux[(size_t)m * p.ldo + n] = v;
                 if (p.act == MASTER_ACT_GELU) v = gelu_erf(v);
-                else if (p.act == MASTER_ACT_RELU) v = fmaxf(v, 0.0f);
+                else if (p.act == MASTER_ACT_RELU) v = relu_np(v);
                 if (p.mask_relu) {
                     if (p.r2) v += p.r2[(size_t)m * p.ldr + n];
                     if (!(p.r1[(size_t)m * p.ldr + n] > 0.0f)) v = 0.0f;
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_cout_kernel(GemmArgs p) {
     for (int co = 0; co < COUT; ++co) {
         float v = acc[co];
         if (p.act == MASTER_ACT_GELU) v = gelu_erf(v);
-        else if (p.act == MASTER_ACT_RELU) v = fmaxf(v, 0.0f);
+        else if (p.act == MASTER_ACT_RELU) v = relu_np(v);
         if (p.out_nchw) p.out[((size_t)b * COUT + co) * hw + pix] = v;
         else p.out[((size_t)b * hw + pix) * p.ldo + co] = v;
     }

@@ -128,7 +128,7 @@ __device__ __forceinline__ void x3_epilogue(const X3Args& p, f32x16 (&acc)[WM / 
                     for (int c = 0; c < 4; ++c) x[c] = gelu_erf(x[c]);
                 } else if (p.act == MASTER_ACT_RELU) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) x[c] = fmaxf(x[c], 0.0f);
+                    for (int c = 0; c < 4; ++c) x[c] = relu_np(x[c]);
                 }
                 if (p.mask_relu) {
                     if (p.r2) x += a2[it];
@@ -169,7 +169,7 @@ __device__ __forceinline__ void x3_epilogue(const X3Args& p, f32x16 (&acc)[WM / 
                 if (m >= p.M) continue;
                 float v = acc[i][jn][e] + bv;
                 if (p.act == MASTER_ACT_GELU) v = gelu_erf(v);
-                else if (p.act == MASTER_ACT_RELU) v = fmaxf(v, 0.0f);
+                else if (p.act == MASTER_ACT_RELU) v = relu_np(v);
                 if (p.mask_relu) {
                     if (p.r2) v += p.r2[(size_t)m * p.ldr + n];
                     if (!(p.r1[(size_t)m * p.ldr + n] > 0.0f)) v = 0.0f;

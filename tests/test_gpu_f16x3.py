@@ -425,6 +425,29 @@ def test_encoder_only_switch_in_eval_mode(cuda):
         assert torch.equal(m.set_compute_dtype(torch.float32)(c, s, 1), y32)       # back: the encoder follows the model again
 
 
+def test_overflow_inside_the_model_reaches_the_image(cuda):
+    """whole-model form of the trade-off below: a forward whose activations leave half's range (seeded random weights at k = 5: the exact
+    modes produce values up to 4.5e7) must come out of the f16x3 mode with inf / NaN in the image - the decoder's ReLUs propagate NaN like
+    torch.relu (r05: they used v_max_f32, which answers 0 for a NaN, and this forward came out finite and wrong).  The exact-fp32 kernels and
+    the bf16 halves, which keep fp32's exponent, stay finite on the same input."""
+    import warnings
+    from mastermetastyletransfer_amd import MasterStyleTransferModel
+    sds = (seeded_state_dict(O.swin_shapes(), 31), seeded_state_dict(O.style_transformer_shapes(), 32), seeded_state_dict(O.decoder_shapes(), 33))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7], allow_random_swin_encoder=True)
+    m.swin_encoder.load_state_dict(sds[0]); m.style_transformer.load_state_dict(sds[1]); m.decoder.load_state_dict(sds[2])
+    m = m.to(cuda).eval()
+    c = seeded_input("c", (2, 3, 96, 64), 8, kind="image").to(cuda); s = seeded_input("s", (2, 3, 96, 64), 9, kind="image").to(cuda)
+    with torch.no_grad():
+        y32 = m.set_compute_dtype(torch.float32)(c, s, 5)
+        assert torch.isfinite(y32).all() and float(y32.abs().max()) > 1e6
+        yh = m.set_compute_dtype("f16x3")(c, s, 5)
+        assert not torch.isfinite(yh).all(), "an overflow of half's range inside the model must not produce a finite image"
+        yb = m.set_compute_dtype("bf16x3")(c, s, 5)
+        assert torch.isfinite(yb).all() and float((yb - y32).abs().max()) <= 2e-3 * float(y32.abs().max())
+
+
 def test_half_halves_overflow_is_loud_and_bf16_halves_cover_the_range(cuda):
     """the documented trade-off: an operand beyond half's range (|x| > 65 504) makes the f16x3 product inf / NaN - never a silently wrong
     finite number - while the bf16 halves, which keep fp32's exponent, stay accurate; tiny operands (1e-6) underflow the half split's low
