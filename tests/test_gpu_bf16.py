@@ -380,5 +380,8 @@ def test_default_constructor_window8_both_modes(cuda, S):
         m.set_compute_dtype(BF)
         got16 = m(c.to(cuda), s.to(cuda), 1).cpu()
     assert (got32 - ref).abs().max() < 1e-3
+    m.set_compute_dtype("f16x3")
+    with torch.no_grad():
+        assert (m(c.to(cuda), s.to(cuda), 1).cpu() - ref).abs().max() < 1e-3       # the split mode on 8x8 windows (r05)
     mx, l2 = rel_err(got16, ref)
     assert l2 < 5e-2 and mx < 0.25, (mx, l2)

@@ -253,6 +253,9 @@ def test_swin_t_s_full_forward_vs_oracle(cuda, variant, B, S, k):
         got16 = m(c.to(cuda), s.to(cuda), k).cpu()
     l2 = float((got16 - ref).norm() / ref.norm())
     assert torch.isfinite(got16).all() and l2 < 2.5e-2, l2
+    m.set_compute_dtype("f16x3")                                   # the split mode on the 96 / 192-wide variants (generic split GEMMs; r05)
+    with torch.no_grad():
+        assert_close(m(c.to(cuda), s.to(cuda), k), ref, f"{variant} f16x3")
     m.set_compute_dtype(torch.float32)
     with torch.no_grad():
         assert_close(m(c.to(cuda), s.to(cuda), k), ref, f"{variant} back in fp32")
@@ -578,7 +581,7 @@ def test_vgg19_vs_torchvision(cuda):
 
 
 @pytest.mark.parametrize("i", range(5))
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "f16x3"])
 def test_non_default_decoder_branches(cuda, i, mode):
     """decoder_use_instance_norm_with_affine, decoder_use_regular_MHA_instead_of_Swin_at_the_end and
     decoder_use_Key_instance_norm_after_linear_transformation=False on the HIP path against the reference's own outputs
@@ -597,13 +600,14 @@ def test_non_default_decoder_branches(cuda, i, mode):
     m = m.to(cuda).eval()
     for mod in m.modules():
         if hasattr(mod, "compute_dtype"):
-            mod.compute_dtype = torch.float32 if mode == "fp32" else torch.bfloat16
+            mod.compute_dtype = torch.bfloat16 if mode == "bf16" else torch.float32
+            mod.split_weights = "f16" if mode == "f16x3" else False
     for k in (1, 2):
         with torch.no_grad():
             got = m(fc.to(cuda), fs.to(cuda), k).float().cpu()
         ref = torch.from_numpy(gold[f"{tag}_k{k}"])
-        if mode == "fp32":
-            assert_close(got, ref, f"{tag} k={k}", 1e-4)
+        if mode in ("fp32", "f16x3"):
+            assert_close(got, ref, f"{tag} k={k} [{mode}]", 1e-4)
         else:
             l2 = float((got - ref).norm() / ref.norm())
             assert l2 < 3e-2, (tag, k, l2)
