@@ -433,7 +433,7 @@ int master_bias_tile_bwd(const float* dtile, const long long* index, float* dtab
 }
 
 int master_maxpool2x2_bwd(const void* g, const void* y, void* dx, int N, int H, int W, int C, int dtype, master_stream_t stream) {
-    REQUIRE(g && y && dx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0, "maxpool2x2_bwd: bad arguments");
+    REQUIRE(g && y && dx && N > 0 && H >= 2 && W >= 2 && C > 0, "maxpool2x2_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(MASTER_K_TRAIN_MISC, s);
     return dtype == MASTER_F32 ? maxpool2_bwd_launch<float>(g, y, dx, N, H, W, C, s) : maxpool2_bwd_launch<bf16_t>(g, y, dx, N, H, W, C, s);

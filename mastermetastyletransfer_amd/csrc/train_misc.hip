@@ -560,6 +560,9 @@ int fold_reflect_launch(const float* dxp, float* out, int B, int H, int W, int C
 }
 template <typename T> int maxpool2_bwd_launch(const void* g, const void* y, void* dx, int N, int H, int W, int C, hipStream_t s) {
     const size_t total = (size_t)N * (H / 2) * (W / 2) * C;
+    // odd H or W (floor mode, like torch's MaxPool2d): the last row / column belongs to no 2x2 block and takes a zero gradient; the kernel
+    // writes only the blocks, so dx is cleared first on this rare path (r05: an 88 x 136 image reaches VGG-19's fourth pool as 11 x 17)
+    if ((H | W) & 1) (void)hipMemsetAsync(dx, 0, (size_t)N * H * W * C * sizeof(T), s);
     hipLaunchKernelGGL((maxpool2_bwd_kernel<T>), dim3(blocks_for(total)), dim3(256), 0, s, (const T*)g, (const T*)y, (T*)dx, H, W, C, total);
     return master_check_launch("maxpool2_bwd");
 }

@@ -55,7 +55,7 @@ def test_linear_backward(cuda, M, N, K):
     check("da", ad.grad, a.grad); check("dw", wd.grad, w.grad); check("db", bd.grad, b.grad)
 
 
-@pytest.mark.parametrize("M,C,HID,ln", [(2048, 256, 1024, True), (700, 256, 1024, False), (130, 128, 512, True), (500, 192, 768, True)])
+@pytest.mark.parametrize("M,C,HID,ln", [(2048, 256, 1024, True), (700, 256, 1024, False), (130, 128, 512, True), (500, 192, 768, True), (561, 256, 1024, True)])
 def test_mlp_backward(cuda, M, C, HID, ln):
     from mastermetastyletransfer_amd.autograd import MLPFn
     g = torch.Generator().manual_seed(M)
@@ -199,7 +199,7 @@ def test_reduce_segments(cuda):
         check("segment", o, ref.float(), 1e-5)
 
 
-@pytest.mark.parametrize("B,T,C,n_pad", [(2, 1024, 256, 201), (3, 64, 256, 132), (2, 100, 64, 0), (1, 4096, 128, 0), (2, 100, 192, 30)])
+@pytest.mark.parametrize("B,T,C,n_pad", [(2, 1024, 256, 201), (3, 64, 256, 132), (2, 100, 64, 0), (1, 4096, 128, 0), (2, 100, 192, 30), (3, 187, 256, 107)])
 def test_instnorm_backward(cuda, B, T, C, n_pad):
     """InstanceNorm over T rows + n_pad copies of a parameter row; gradients w.r.t. x and the row (style_transformer.py:520-530)"""
     from mastermetastyletransfer_amd.autograd import InstNormFn
@@ -235,7 +235,7 @@ def _attn_module(cuda, dim, nh, shift, seed):
     return m.to(cuda), sd
 
 
-@pytest.mark.parametrize("H,W,shift", [(7, 7, (0, 0)), (14, 14, (3, 3)), (9, 9, (4, 4)), (9, 12, (4, 4)), (14, 9, (4, 0)), (32, 32, (4, 4))])
+@pytest.mark.parametrize("H,W,shift", [(7, 7, (0, 0)), (14, 14, (3, 3)), (9, 9, (4, 4)), (9, 12, (4, 4)), (14, 9, (4, 0)), (32, 32, (4, 4)), (11, 17, (4, 4))])
 @pytest.mark.parametrize("mode", ["qkv", "qk_v", "q_k_v", "dual"])
 def test_window_attention_backward(cuda, H, W, shift, mode):
     """train_forward.attention (projections + master_window_attn_bwd + proj) vs autograd through the oracle's attention: gradients of
@@ -274,7 +274,7 @@ def test_window_attention_backward(cuda, H, W, shift, mode):
         check(n, prm.grad, p[n].grad, floor=1e-3 * gscale)        # Wk.bias: zero in exact arithmetic (softmax shift invariance)
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 9, 9), (2, 32, 32), (1, 14, 12)])
+@pytest.mark.parametrize("B,H,W", [(2, 9, 9), (2, 32, 32), (1, 14, 12), (3, 11, 17)])
 def test_sigma_mu_attention_backward(cuda, B, H, W):
     from mastermetastyletransfer_amd import StyleTransformer
     from mastermetastyletransfer_amd import train_forward as TF
@@ -303,7 +303,9 @@ def test_sigma_mu_attention_backward(cuda, B, H, W):
 @pytest.mark.parametrize("B,H,W,Cin,Cout,up,relu,nchw", [(2, 8, 8, 256, 128, False, True, False), (1, 16, 16, 128, 128, True, True, False),
                                                          (2, 12, 20, 64, 32, True, True, False), (2, 16, 16, 32, 3, False, False, True),
                                                          (1, 2, 2, 32, 32, True, True, False), (1, 6, 10, 128, 64, False, True, False),
-                                                         (1, 8, 8, 192, 96, False, True, False), (2, 6, 6, 96, 64, True, True, False)])
+                                                         (1, 8, 8, 192, 96, False, True, False), (2, 6, 6, 96, 64, True, True, False),
+                                                         (3, 11, 17, 256, 128, False, True, False), (3, 11, 17, 128, 128, True, True, False),
+                                                         (1, 5, 7, 64, 64, True, True, False), (2, 9, 13, 128, 64, False, True, False)])
 def test_conv_reflect_backward(cuda, B, H, W, Cin, Cout, up, relu, nchw):
     """Upsample? -> ReflectionPad -> Conv3x3 -> ReLU? (decoder.py:24-54): data, weight and bias gradients"""
     from mastermetastyletransfer_amd.autograd import ConvReflectFn
@@ -404,7 +406,7 @@ def _model(cuda):
     return m
 
 
-def _compare_grads(named_params, ref64, ref32):
+def _compare_grads(named_params, ref64, ref32, worst=3e-3):
     """The gradient of this loss is ill-conditioned in fp32: |.| distances and ReLU/max-pool switches are discontinuous, and
     InstanceNorm (eps 1e-5) amplifies rounding on nearly constant channels - the fp32 CPU oracle itself sits ~1e-3 (relative to each
     tensor's max-abs) from its float64 evaluation (profiles/r02_grad_conditioning.txt).  So both fp32 implementations are measured
@@ -423,7 +425,7 @@ def _compare_grads(named_params, ref64, ref32):
         den = max(float(ref64[n].abs().max()), 1e-6 * gscale)
         h = float((p.grad.cpu().double() - ref64[n]).abs().max()) / den
         c = float((ref32[n].double() - ref64[n]).abs().max()) / den
-        assert h <= max(3e-3, 4 * c), f"{n}: HIP gradient error vs float64 {h:.3e} (CPU fp32: {c:.3e})"
+        assert h <= max(worst, 4 * c), f"{n}: HIP gradient error vs float64 {h:.3e} (CPU fp32: {c:.3e})"
         eh.append(h); ec.append(c)
     mh, mc = float(np.median(eh)), float(np.median(ec))
     assert mh <= max(1e-3, 2 * mc), (mh, mc)
@@ -520,7 +522,7 @@ def test_graphed_train_step_matches_the_eager_step(cuda):
         check("eval after graph replays", m2(batches[0][0], batches[0][1], 1), m1(batches[0][0], batches[0][1], 1), 2e-3)
 
 
-@pytest.mark.parametrize("B,S", [(2, 64), (8, 256)])
+@pytest.mark.parametrize("B,S", [(2, 64), (8, 256), (3, (88, 136))])
 def test_full_train_step(cuda, B, S):
     """MasterStyleTransferModel in train mode (frozen Swin encoder with its StochasticDepth, k from random.seed(0)), custom_loss,
     backward, FusedAdam step - against the oracle's autograd step with the same masks (BASELINE config 4 at B=8, 256^2)."""
@@ -528,7 +530,10 @@ def test_full_train_step(cuda, B, S):
     from mastermetastyletransfer_amd import train_forward as TF
     sds = (seeded_state_dict(O.swin_shapes(), 1), seeded_state_dict(O.style_transformer_shapes(), 2), seeded_state_dict(O.decoder_shapes(), 3))
     vgg = seeded_state_dict(L.vgg19_shapes(), 4)
-    c = seeded_input("fts_c", (B, 3, S, S), 5, kind="image"); s = seeded_input("fts_s", (B, 3, S, S), 6, kind="image")
+    # (88, 136): a non-square image with an 11 x 17 feature map - every window of the StyleTransformer padded, forward and backward (r05; sides that
+    # are not multiples of 8 change the output size, which the reference's loss cannot take either)
+    SH, SW = S if isinstance(S, tuple) else (S, S)
+    c = seeded_input("fts_c", (B, 3, SH, SW), 5, kind="image"); s = seeded_input("fts_s", (B, 3, SH, SW), 6, kind="image")
     random.seed(0)
     k = random.randint(1, 2)                                        # train_only_inner_loop.py:519 with max_layers = 2
     g = torch.Generator().manual_seed(7)
@@ -556,7 +561,10 @@ def test_full_train_step(cuda, B, S):
     opt.zero_grad(); total.backward()
     named = [("style_transformer." + n, p) for n, p in m.style_transformer.named_parameters()] + \
             [("decoder." + n, p) for n, p in m.decoder.named_parameters()]
-    wh, mh, wc, mc = _compare_grads(named, ref64, ref32)
+    # the 11 x 17 map has 187 pixels per image: ONE ReLU of the first decoder layer that switches differently in fp32 than in float64 moves
+    # that layer's weight gradient by ~0.5 % (measured: 6.0e-3 on decoder.0.weight, every other tensor <= 2.6x the CPU-fp32 error; the
+    # decoder's backward chain replayed in float64 torch from the HIP path's own tensors agrees to 2e-7, profiles/r05_edge_sweep_mi355x.txt)
+    wh, mh, wc, mc = _compare_grads(named, ref64, ref32, worst=1e-2 if isinstance(S, tuple) else 3e-3)
     print(f"B={B} S={S} k={k}: loss {float(total):.4f}; gradient error vs float64 oracle: HIP worst {wh:.2e} median {mh:.2e} | "
           f"CPU fp32 oracle worst {wc:.2e} median {mc:.2e}")
     # Adam: the device optimizer on ITS gradients vs the oracle's Adam on the same (device) gradients
