@@ -312,7 +312,7 @@ def test_f16x3_kernels_repeatable_at_scale(cuda):
 
 
 @pytest.mark.parametrize("B,H,W,dc,ds", [(2, 64, 64, "euclidian", "euclidian"), (2, 128, 128, "euclidian_squared", "euclidian_squared"),
-                                         (1, 256, 256, "euclidian", "euclidian")])
+                                         (1, 256, 256, "euclidian", "euclidian"), (2, 88, 136, "euclidian_squared", "euclidian_squared")])
 def test_perceptual_loss_backward_f16x3_network(cuda, B, H, W, dc, ds):
     """custom_loss.set_compute_dtype("f16x3"): IEEE-half halves in the frozen VGG-19's FORWARD convolutions (the pass whose rounding this
     loss amplifies ~1e4 times), bf16 halves in its data-gradient chain (gradients span fp32's exponent range).  The per-pixel image

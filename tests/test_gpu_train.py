@@ -328,7 +328,8 @@ def test_conv_reflect_backward(cuda, B, H, W, Cin, Cout, up, relu, nchw):
 
 
 @pytest.mark.parametrize("B,H,W,dc,ds", [(2, 64, 64, "euclidian", "euclidian"), (1, 48, 80, "euclidian_squared", "euclidian_squared"),
-                                         (2, 32, 32, "euclidian", "euclidian_squared")])
+                                         (2, 32, 32, "euclidian", "euclidian_squared"), (2, 88, 136, "euclidian_squared", "euclidian_squared"),
+                                         (1, 52, 44, "euclidian_squared", "euclidian")])
 def test_perceptual_loss_backward(cuda, B, H, W, dc, ds):
     """custom_loss with an output image that requires grad: loss values and d(total)/d(output image) vs autograd through the oracle
     (VGG-19 data gradients, max-pool + ReLU backward, InstanceNorm'd L1/L2 and mean/std terms)"""
@@ -351,8 +352,14 @@ def test_perceptual_loss_backward(cuda, B, H, W, dc, ds):
     # maximum (measured 1.02e-3) and are held to 1e-3 in L2 and 4e-3 on the maximum; the smooth squared distances to 1e-3 on both.
     got, ref = od.grad.cpu().double(), o64.grad
     l2 = float((got - ref).norm() / ref.norm())
-    assert l2 <= 1e-3, l2
-    check("d_output", got, ref, 1e-3 if dc == "euclidian_squared" and ds == "euclidian_squared" else 4e-3)
+    # r05: sizes whose maps turn odd (88 x 136 -> 11 x 17 -> 5 x 8, floor-mode pools) joined the list.  With the seeded random VGG-19 a ReLU / max-pool
+    # switch that falls differently in fp32 than in float64 moves the whole gradient: at 2 x 88 x 136 the CPU fp32 oracle is 7.87e-3 in L2 from its
+    # own float64 evaluation - and the HIP path sits at the same 7.87e-3 (profiles/r05_edge_sweep_mi355x.txt) - so the bounds scale with the CPU
+    # fp32 oracle's own distance where that is larger
+    cpu32 = o.grad.double()
+    l2_cpu = float((cpu32 - ref).norm() / ref.norm()); mx_cpu = float((cpu32 - ref).abs().max() / ref.abs().max())
+    assert l2 <= max(1e-3, 2 * l2_cpu), (l2, l2_cpu)
+    check("d_output", got, ref, max(1e-3 if dc == "euclidian_squared" and ds == "euclidian_squared" else 4e-3, 2 * mx_cpu))
 
 
 def test_rowscale_and_muladd(cuda):
