@@ -324,6 +324,25 @@ def test_full_forward_sides_not_multiples_of_4(cuda, H, W):
         m(c[:, :, :3].to(cuda), s[:, :, :3].to(cuda), 1)
 
 
+@pytest.mark.parametrize("B,H,W,k", [(3, 200, 200, 1), (5, 72, 104, 2), (7, 40, 56, 1)])
+def test_ragged_batches_in_every_mode(cuda, B, H, W, k):
+    """token counts per image that are not multiples of the kernels' 128-token tiles (625, 117, 35): tiles cross image boundaries, per-image
+    norms and windows must not - all three modes against the oracle, and image 1 of the batch bit-identical to the same image alone"""
+    m, (swin_sd, st_sd, dec_sd) = full_model(cuda)
+    c = seeded_input("c_rag", (B, 3, H, W), 8, kind="image"); s = seeded_input("s_rag", (B, 3, H, W), 9, kind="image")
+    with torch.no_grad():
+        ref = O.full_forward(c, s, k, swin_sd, st_sd, dec_sd)
+        for mode in (torch.float32, "f16x3", torch.bfloat16):
+            m.set_compute_dtype(mode)
+            got = m(c.to(cuda), s.to(cuda), k)
+            one = m(c[1:2].to(cuda), s[1:2].to(cuda), k)
+            assert torch.equal(got[1:2], one), f"{mode}: not batch-independent"
+            if mode == torch.bfloat16:
+                assert float((got.float().cpu() - ref).norm() / ref.norm()) <= 3e-2
+            else:
+                assert_close(got, ref, f"ragged batch {B}x{H}x{W} k{k} [{mode}]", absolute=True)
+
+
 def test_empty_batch_is_an_error_not_a_crash(cuda):
     """B = 0: the CPU path cannot run it either (a reshape with an ambiguous -1 in the window partition); the HIP path must answer with an
     exception - no launch with an empty grid, no device fault - and stay usable afterwards"""
