@@ -54,14 +54,31 @@ class _HipModule(nn.Module):
     compute_dtype = torch.float32
     split_weights = False          # "bf16" / "f16" (or True = "bf16"): the split fast parity modes (ops.F32X3 / ops.F16X3) - fp32 activations, GEMM / conv weights as 16-bit hi + lo
 
+    def __getstate__(self):
+        """pickling / copy.deepcopy / torch.save(module): the caches of derived device tensors (and their events) are rebuilt on demand"""
+        d = dict(self.__dict__)
+        d.pop("_derived_cache", None); d.pop("_zero_bias", None)
+        return d
+
     def _derived(self, name: str, srcs: Sequence[Tensor], build: Callable[[], Tensor]) -> Tensor:
         cache = self.__dict__.setdefault("_derived_cache", {})
         key = tuple((s.data_ptr(), s._version, s.dtype, str(s.device)) for s in srcs) + (self.compute_dtype, self.split_weights)
         hit = cache.get(name)
         if hit is None or hit[0] != key:
             with torch.no_grad():
-                hit = (key, build())
+                t = build()
+            # the tensor is built on the CURRENT stream; a forward issued later on another stream (multi-stream serving) must not read it
+            # before that work is done: remember where and when it was built (r05)
+            ev = None
+            if t.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record()
+            hit = (key, t, ev, torch.cuda.current_stream().cuda_stream if t.is_cuda else None)
             cache[name] = hit
+        elif hit[2] is not None:
+            cs = torch.cuda.current_stream()
+            if cs.cuda_stream != hit[3] and not torch.cuda.is_current_stream_capturing():
+                cs.wait_event(hit[2])
         return hit[1]
 
     def _w(self, name: str, *params: Tensor) -> Tensor:

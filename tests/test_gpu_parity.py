@@ -343,6 +343,31 @@ def test_ragged_batches_in_every_mode(cuda, B, H, W, k):
                 assert_close(got, ref, f"ragged batch {B}x{H}x{W} k{k} [{mode}]", absolute=True)
 
 
+def test_concurrent_streams_and_module_copies(cuda, tmp_path):
+    """multi-stream serving: four forwards issued on four streams at once (the FIRST use of the model: the derived-weight caches are built by
+    whichever stream comes first and carry an event for the others) equal the sequential results bit for bit; and a used model still
+    pickles / deep-copies (caches and their events are dropped from the state)"""
+    import copy
+    m, (swin_sd, st_sd, dec_sd) = full_model(cuda)
+    ins = [(seeded_input(f"cs_c{i}", (2, 3, 96, 96), 8 + i, kind="image").to(cuda), seeded_input(f"cs_s{i}", (2, 3, 96, 96), 90 + i, kind="image").to(cuda)) for i in range(4)]
+    streams = [torch.cuda.Stream() for _ in ins]
+    outs = [None] * 4
+    with torch.no_grad():
+        for i, (st, (c, s)) in enumerate(zip(streams, ins)):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                outs[i] = m(c, s, 1)
+        torch.cuda.synchronize()
+        seq = [m(c, s, 1) for c, s in ins]
+        for i in range(4):
+            assert torch.equal(outs[i], seq[i]), i
+        m2 = copy.deepcopy(m)
+        torch.save(m.decoder, tmp_path / "dec.pt")
+        assert torch.equal(m2(*ins[0], 1), seq[0])
+    ref = O.full_forward(ins[0][0].cpu(), ins[0][1].cpu(), 1, swin_sd, st_sd, dec_sd)
+    assert_close(seq[0], ref, "stream test forward", absolute=True)
+
+
 def test_empty_batch_is_an_error_not_a_crash(cuda):
     """B = 0: the CPU path cannot run it either (a reshape with an ambiguous -1 in the window partition); the HIP path must answer with an
     exception - no launch with an empty grid, no device fault - and stay usable afterwards"""
