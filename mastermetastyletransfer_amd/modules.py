@@ -146,6 +146,22 @@ def _mlp_fwd(owner: _HipModule, name: str, mlp: nn.Sequential, x: Tensor, residu
     """residual + fc2(gelu(fc1(norm?(x))))   (torchvision MLP, call sites style_transformer.py:366,839-841,991).
     bf16 mode: one fused launch (hidden activations stay in registers, LayerNorm folded in);
     fp32 mode: LayerNorm, GEMM+GELU, GEMM+residual."""
+    pad = (-mlp[0].weight.shape[0]) % 64         # the bf16 GEMM steps K in 64s, the fp32 / split ones in 32s
+    if pad:
+        # a hidden width that is not a multiple of 64 (mlp_ratio 1.1 at dim 256: 281; the reference takes any width): zero rows of fc1 (and of
+        # its bias) and zero columns of fc2 - gelu(0) = relu(0) = 0 meets a zero weight, so the padded units contribute nothing (r05; inference)
+        Fp = torch.nn.functional.pad
+
+        def conv(t: Tensor) -> Tensor:
+            return ops.split_weights(t, fmt=owner.split_weights) if owner.split_weights else ops.convert(t.contiguous(), owner.compute_dtype)
+        w1 = owner._derived("w:" + name + ".0:pad", [mlp[0].weight], lambda: conv(Fp(mlp[0].weight.detach(), (0, 0, 0, pad))))
+        b1 = owner._derived("b:" + name + ".0:pad", [mlp[0].bias], lambda: Fp(mlp[0].bias.detach().float(), (0, pad)).contiguous())
+        w2 = owner._derived("w:" + name + ".3:pad", [mlp[3].weight], lambda: conv(Fp(mlp[3].weight.detach(), (0, pad))))
+        b2 = owner._b(name + ".3", mlp[3].bias)
+        if norm is not None:
+            x = ops.layernorm(x, owner._b(name + ".ln_w", norm.weight), owner._b(name + ".ln_b", norm.bias), norm.eps)
+        h = ops.linear(x, w1, b1, act=ops.ACT_RELU if isinstance(mlp[1], nn.ReLU) else ops.ACT_GELU)
+        return ops.linear(h, w2, b2, r2=residual)
     w1, b1 = owner._w(name + ".0", mlp[0].weight), owner._b(name + ".0", mlp[0].bias)
     b2 = owner._b(name + ".3", mlp[3].bias)
     g = owner._b(name + ".ln_w", norm.weight) if norm is not None else None

@@ -368,6 +368,29 @@ def test_concurrent_streams_and_module_copies(cuda, tmp_path):
     assert_close(seq[0], ref, "stream test forward", absolute=True)
 
 
+@pytest.mark.parametrize("ratio", [1.1, 1.5, 0.25])
+def test_mlp_ratios_incl_a_hidden_width_that_is_not_a_multiple_of_32(cuda, ratio):
+    """style_encoder_mlp_ratio / style_decoder_mlp_ratio other than 4 (full_model.py:34-35): hidden 384 and 64 run on the kernels as they are,
+    281 (ratio 1.1) is zero-padded to 320 on the host side - all three modes against the oracle"""
+    from mastermetastyletransfer_amd import MasterStyleTransferModel
+    sds = (seeded_state_dict(O.swin_shapes(), 31), seeded_state_dict(O.style_transformer_shapes(mlp_ratio=ratio), 32), seeded_state_dict(O.decoder_shapes(), 33))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = MasterStyleTransferModel(style_encoder_window_size=[7, 7], style_decoder_window_size=[7, 7], allow_random_swin_encoder=True,
+                                     style_encoder_mlp_ratio=ratio, style_decoder_mlp_ratio=ratio)
+    m.swin_encoder.load_state_dict(sds[0]); m.style_transformer.load_state_dict(sds[1]); m.decoder.load_state_dict(sds[2])
+    m = m.to(cuda).eval()
+    c = seeded_input("c_mr", (2, 3, 96, 64), 8, kind="image"); s = seeded_input("s_mr", (2, 3, 96, 64), 9, kind="image")
+    with torch.no_grad():
+        ref = O.full_forward(c, s, 1, *sds)
+        for mode in (torch.float32, "f16x3", torch.bfloat16):
+            got = m.set_compute_dtype(mode)(c.to(cuda), s.to(cuda), 1)
+            if mode == torch.bfloat16:
+                assert float((got.float().cpu() - ref).norm() / ref.norm()) <= 3e-2
+            else:
+                assert_close(got, ref, f"mlp_ratio {ratio} [{mode}]", absolute=True)
+
+
 def test_empty_batch_is_an_error_not_a_crash(cuda):
     """B = 0: the CPU path cannot run it either (a reshape with an ambiguous -1 in the window partition); the HIP path must answer with an
     exception - no launch with an empty grid, no device fault - and stay usable afterwards"""
