@@ -391,6 +391,30 @@ def test_mlp_ratios_incl_a_hidden_width_that_is_not_a_multiple_of_32(cuda, ratio
                 assert_close(got, ref, f"mlp_ratio {ratio} [{mode}]", absolute=True)
 
 
+@pytest.mark.parametrize("ws,sh", [((4, 4), (2, 2)), ((7, 5), (3, 2)), ((3, 9), (1, 4)), ((8, 8), (0, 0))])
+def test_window_and_shift_geometries_in_every_mode(cuda, ws, sh):
+    """style_encoder / style_decoder window_size and shift_size other than the benchmark's 7 x 7 / 4 (full_model.py:30-33): small, non-square and
+    unshifted windows through the whole model in the three modes (any window of at most 64 tokens runs on the same kernels)"""
+    from mastermetastyletransfer_amd import MasterStyleTransferModel
+    sds = (seeded_state_dict(O.swin_shapes(), 31), seeded_state_dict(O.style_transformer_shapes(ws=ws), 32, ws=ws), seeded_state_dict(O.decoder_shapes(), 33))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = MasterStyleTransferModel(style_encoder_window_size=list(ws), style_decoder_window_size=list(ws), style_encoder_shift_size=list(sh),
+                                     style_decoder_shift_size=list(sh), allow_random_swin_encoder=True)
+    m.swin_encoder.load_state_dict(sds[0]); m.style_transformer.load_state_dict(sds[1]); m.decoder.load_state_dict(sds[2])
+    m = m.to(cuda).eval()
+    c = seeded_input("c_ws", (2, 3, 96, 128), 8, kind="image"); s = seeded_input("s_ws", (2, 3, 96, 128), 9, kind="image")
+    cfg = dict(O.DEFAULT_ST_CFG, encoder_window_size=ws, decoder_window_size=ws, encoder_shift_size=sh, decoder_shift_size=sh)
+    with torch.no_grad():
+        ref = O.full_forward(c, s, 1, *sds, cfg=cfg)
+        for mode in (torch.float32, "f16x3", torch.bfloat16):
+            got = m.set_compute_dtype(mode)(c.to(cuda), s.to(cuda), 1)
+            if mode == torch.bfloat16:
+                assert float((got.float().cpu() - ref).norm() / ref.norm()) <= 3e-2
+            else:
+                assert_close(got, ref, f"windows {ws} shift {sh} [{mode}]", absolute=True)
+
+
 def test_empty_batch_is_an_error_not_a_crash(cuda):
     """B = 0: the CPU path cannot run it either (a reshape with an ambiguous -1 in the window partition); the HIP path must answer with an
     exception - no launch with an empty grid, no device fault - and stay usable afterwards"""
